@@ -1,0 +1,377 @@
+"""CPU oracle for the dn-splatter rendering hot path (TEST INFRASTRUCTURE ONLY).
+
+Python face of ``oracle/dnsplat_oracle.c``: the four symbols dn-splatter imports
+from gsplat (``dn_splatter/dn_model.py:29-35``) restated on the CPU with torch
+autograd wiring, so a parity test can call them exactly the way
+``DNSplatterModel.get_outputs`` (``dn_splatter/dn_model.py:495-516``, ``:564-575``)
+calls gsplat.
+
+PARITY UNPINNED: gsplat==1.0.0 is neither vendored in the reference nor
+installable here; see the header of ``dnsplat_oracle.c``.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module.  The product package never does.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+from pathlib import Path
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "_build" / "libdnsplat_oracle.so"
+_lib = None
+
+ALPHA_MIN = 1.0 / 255.0
+ALPHA_MAX = 0.999
+T_MIN = 1e-4
+
+
+def build(force: bool = False) -> Path:
+    """Compile the oracle with gcc (``make -C oracle``)."""
+    if force or not _LIB_PATH.exists() or any(
+        (_HERE / f).stat().st_mtime > _LIB_PATH.stat().st_mtime
+        for f in ("dnsplat_oracle.c", "oracle_impl.inc")
+    ):
+        subprocess.run(["make", "-C", str(_HERE)] + (["-B"] if force else []), check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(str(_LIB_PATH))
+        _lib.orc_isect_tiles_f32.restype = ctypes.c_int64
+        _lib.orc_isect_tiles_f64.restype = ctypes.c_int64
+    return _lib
+
+
+_KEEP: list = []  # tensors whose storage must outlive the current C call (``x.contiguous()`` temporaries)
+
+
+def _p(t: Optional[Tensor]):
+    """Pointer to a contiguous CPU tensor.  The tensor is parked in _KEEP so a temporary made by
+    ``.contiguous()`` cannot be freed (and its storage recycled) before the C call runs."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    assert t.is_contiguous() and t.device.type == "cpu", "oracle wants contiguous CPU tensors"
+    _KEEP.append(t)
+    if len(_KEEP) > 256:
+        del _KEEP[:128]
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _suffix(t: Tensor) -> str:
+    if t.dtype == torch.float32:
+        return "f32"
+    if t.dtype == torch.float64:
+        return "f64"
+    raise TypeError(f"oracle supports float32/float64, got {t.dtype}")
+
+
+def _real(t: Tensor, v: float):
+    return ctypes.c_float(v) if t.dtype == torch.float32 else ctypes.c_double(v)
+
+
+# --------------------------------------------------------------------------- helpers
+
+
+def num_sh_bases(degree: int) -> int:
+    """gsplat.cuda_legacy._wrapper.num_sh_bases (dn_model.py:35,139)."""
+    table = {0: 1, 1: 4, 2: 9, 3: 16, 4: 25}
+    if degree not in table:
+        raise AssertionError("We don't support degree greater than 4.")
+    return table[degree]
+
+
+def quat_to_rotmat(quat: Tensor) -> Tensor:
+    """gsplat.cuda_legacy._torch_impl.quat_to_rotmat (dn_model.py:34,547): wxyz, normalises."""
+    assert quat.shape[-1] == 4, quat.shape
+    w, x, y, z = torch.unbind(torch.nn.functional.normalize(quat, dim=-1), dim=-1)
+    mat = torch.stack(
+        [
+            1 - 2 * (y**2 + z**2), 2 * (x * y - w * z), 2 * (x * z + w * y),
+            2 * (x * y + w * z), 1 - 2 * (x**2 + z**2), 2 * (y * z - w * x),
+            2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x**2 + y**2),
+        ],
+        dim=-1,
+    )
+    return mat.reshape(quat.shape[:-1] + (3, 3))
+
+
+# --------------------------------------------------------------------------- raw kernels
+
+
+def project_fwd(means, quats, scales, viewmat, K, width, height, eps2d=0.3, near_plane=0.01,
+                far_plane=1e10, radius_clip=0.0, tile_size=16, calc_compensations=False):
+    N = means.shape[0]
+    dt = means.dtype
+    radii = torch.zeros(N, dtype=torch.int32)
+    means2d = torch.zeros(N, 2, dtype=dt)
+    depths = torch.zeros(N, dtype=dt)
+    conics = torch.zeros(N, 3, dtype=dt)
+    comp = torch.zeros(N, dtype=dt) if calc_compensations else None
+    tiles = torch.zeros(N, dtype=torch.int32)
+    fn = getattr(lib(), "orc_project_fwd_" + _suffix(means))
+    fn(ctypes.c_int(N), _p(means.contiguous()), _p(quats.contiguous()), _p(scales.contiguous()),
+       _p(viewmat.contiguous()), _p(K.contiguous()), ctypes.c_int(width), ctypes.c_int(height),
+       _real(means, eps2d), _real(means, near_plane), _real(means, far_plane), _real(means, radius_clip),
+       ctypes.c_int(tile_size), _p(radii), _p(means2d), _p(depths), _p(conics), _p(comp), _p(tiles))
+    return radii, means2d, depths, conics, comp, tiles
+
+
+def project_bwd(means, quats, scales, viewmat, K, width, height, eps2d, near_plane, far_plane,
+                radius_clip, radii, v_means2d, v_depths, v_conics, v_compensations=None):
+    N = means.shape[0]
+    dt = means.dtype
+    v_means = torch.zeros(N, 3, dtype=dt)
+    v_quats = torch.zeros(N, 4, dtype=dt)
+    v_scales = torch.zeros(N, 3, dtype=dt)
+    fn = getattr(lib(), "orc_project_bwd_" + _suffix(means))
+    fn(ctypes.c_int(N), _p(means.contiguous()), _p(quats.contiguous()), _p(scales.contiguous()),
+       _p(viewmat.contiguous()), _p(K.contiguous()), ctypes.c_int(width), ctypes.c_int(height),
+       _real(means, eps2d), _real(means, near_plane), _real(means, far_plane), _real(means, radius_clip),
+       _p(radii), _p(v_means2d.contiguous()), _p(v_depths.contiguous()), _p(v_conics.contiguous()),
+       _p(v_compensations.contiguous() if v_compensations is not None else None),
+       _p(v_means), _p(v_quats), _p(v_scales))
+    return v_means, v_quats, v_scales
+
+
+def sh_fwd(degree, dirs, coeffs, radii=None):
+    N, Ktot = coeffs.shape[0], coeffs.shape[1]
+    colors = torch.zeros(N, 3, dtype=coeffs.dtype)
+    fn = getattr(lib(), "orc_sh_fwd_" + _suffix(coeffs))
+    fn(ctypes.c_int(N), ctypes.c_int(degree), ctypes.c_int(Ktot), _p(dirs.contiguous()),
+       _p(coeffs.contiguous()), _p(radii), _p(colors))
+    return colors
+
+
+def sh_bwd(degree, dirs, coeffs, radii, v_colors, need_dirs=True):
+    N, Ktot = coeffs.shape[0], coeffs.shape[1]
+    v_coeffs = torch.zeros_like(coeffs)
+    v_dirs = torch.zeros(N, 3, dtype=coeffs.dtype) if need_dirs else None
+    fn = getattr(lib(), "orc_sh_bwd_" + _suffix(coeffs))
+    fn(ctypes.c_int(N), ctypes.c_int(degree), ctypes.c_int(Ktot), _p(dirs.contiguous()),
+       _p(coeffs.contiguous()), _p(radii), _p(v_colors.contiguous()), _p(v_coeffs), _p(v_dirs))
+    return v_coeffs, v_dirs
+
+
+def isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height, sort=True):
+    """A.3: (tiles_per_gauss, isect_ids[int64], flatten_ids[int32]) for one camera."""
+    N = means2d.shape[0]
+    sfx = _suffix(means2d)
+    fn = getattr(lib(), "orc_isect_tiles_" + sfx)
+    tiles = torch.zeros(N, dtype=torch.int32)
+    m2 = means2d.contiguous()
+    d = depths.contiguous()
+    r = radii.contiguous()
+    n = fn(ctypes.c_int(N), _p(m2), _p(r), _p(d), ctypes.c_int(tile_size), ctypes.c_int(tile_width),
+           ctypes.c_int(tile_height), _p(tiles), _p(None), _p(None))
+    isect_ids = torch.zeros(n, dtype=torch.int64)
+    flatten_ids = torch.zeros(n, dtype=torch.int32)
+    fn(ctypes.c_int(N), _p(m2), _p(r), _p(d), ctypes.c_int(tile_size), ctypes.c_int(tile_width),
+       ctypes.c_int(tile_height), _p(tiles), _p(isect_ids), _p(flatten_ids))
+    if sort:
+        lib().orc_sort_isects(ctypes.c_int64(n), _p(isect_ids), _p(flatten_ids))
+    return tiles, isect_ids, flatten_ids
+
+
+def isect_offset_encode(isect_ids, tile_width, tile_height):
+    T = tile_width * tile_height
+    offsets = torch.zeros(T, dtype=torch.int32)
+    lib().orc_isect_offsets(ctypes.c_int64(isect_ids.shape[0]), _p(isect_ids.contiguous()),
+                            ctypes.c_int(T), _p(offsets))
+    return offsets.reshape(tile_height, tile_width)
+
+
+def rasterize_fwd(means2d, conics, colors, opacities, background, width, height, tile_size,
+                  isect_offsets, flatten_ids):
+    N, D = colors.shape
+    dt = colors.dtype
+    render = torch.zeros(height, width, D, dtype=dt)
+    alphas = torch.zeros(height, width, dtype=dt)
+    last_ids = torch.zeros(height, width, dtype=torch.int32)
+    fn = getattr(lib(), "orc_rasterize_fwd_" + _suffix(colors))
+    fn(ctypes.c_int(N), ctypes.c_int(D), _p(means2d.contiguous()), _p(conics.contiguous()),
+       _p(colors.contiguous()), _p(opacities.contiguous()),
+       _p(background.contiguous() if background is not None else None),
+       ctypes.c_int(width), ctypes.c_int(height), ctypes.c_int(tile_size),
+       _p(isect_offsets.contiguous()), _p(flatten_ids.contiguous()), ctypes.c_int64(flatten_ids.shape[0]),
+       _p(render), _p(alphas), _p(last_ids))
+    return render, alphas, last_ids
+
+
+def rasterize_bwd(means2d, conics, colors, opacities, background, width, height, tile_size,
+                  isect_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, absgrad=False):
+    N, D = colors.shape
+    dt = colors.dtype
+    v_means2d = torch.zeros(N, 2, dtype=dt)
+    v_abs = torch.zeros(N, 2, dtype=dt) if absgrad else None
+    v_conics = torch.zeros(N, 3, dtype=dt)
+    v_colors = torch.zeros(N, D, dtype=dt)
+    v_opac = torch.zeros(N, dtype=dt)
+    fn = getattr(lib(), "orc_rasterize_bwd_" + _suffix(colors))
+    fn(ctypes.c_int(N), ctypes.c_int(D), _p(means2d.contiguous()), _p(conics.contiguous()),
+       _p(colors.contiguous()), _p(opacities.contiguous()),
+       _p(background.contiguous() if background is not None else None),
+       ctypes.c_int(width), ctypes.c_int(height), ctypes.c_int(tile_size),
+       _p(isect_offsets.contiguous()), _p(flatten_ids.contiguous()), ctypes.c_int64(flatten_ids.shape[0]),
+       _p(alphas.contiguous()), _p(last_ids.contiguous()), _p(v_render.contiguous()), _p(v_alphas.contiguous()),
+       _p(v_means2d), _p(v_abs), _p(v_conics), _p(v_colors), _p(v_opac))
+    return v_means2d, v_abs, v_conics, v_colors, v_opac
+
+
+# --------------------------------------------------------------------------- autograd wiring
+
+
+class _Projection(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, quats, scales, viewmat, K, width, height, eps2d, near, far, radius_clip,
+                tile_size, calc_comp):
+        radii, means2d, depths, conics, comp, tiles = project_fwd(
+            means, quats, scales, viewmat, K, width, height, eps2d, near, far, radius_clip, tile_size, calc_comp)
+        ctx.save_for_backward(means, quats, scales, viewmat, K, radii)
+        ctx.cfg = (width, height, eps2d, near, far, radius_clip)
+        ctx.calc_comp = calc_comp
+        ctx.mark_non_differentiable(radii, tiles)
+        if comp is None:
+            comp = torch.zeros(0, dtype=means.dtype)
+        return radii, means2d, depths, conics, comp, tiles
+
+    @staticmethod
+    def backward(ctx, _vr, v_means2d, v_depths, v_conics, v_comp, _vt):
+        means, quats, scales, viewmat, K, radii = ctx.saved_tensors
+        width, height, eps2d, near, far, radius_clip = ctx.cfg
+        v_means, v_quats, v_scales = project_bwd(
+            means, quats, scales, viewmat, K, width, height, eps2d, near, far, radius_clip, radii,
+            v_means2d, v_depths, v_conics, v_comp if ctx.calc_comp else None)
+        return (v_means, v_quats, v_scales) + (None,) * 10
+
+
+class _SphericalHarmonics(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, degree, dirs, coeffs, radii):
+        colors = sh_fwd(degree, dirs, coeffs, radii)
+        ctx.save_for_backward(dirs, coeffs, radii)
+        ctx.degree = degree
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        dirs, coeffs, radii = ctx.saved_tensors
+        v_coeffs, v_dirs = sh_bwd(ctx.degree, dirs, coeffs, radii, v_colors, ctx.needs_input_grad[1])
+        return None, v_dirs, v_coeffs, None
+
+
+class _RasterizeToPixels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, background, width, height, tile_size,
+                isect_offsets, flatten_ids, absgrad):
+        # means2d may arrive as [1,N,2] (the tensor dn_model.py:517-519 retains grad on) or [N,2]
+        render, alphas, last_ids = rasterize_fwd(means2d.reshape(-1, 2), conics, colors, opacities, background,
+                                                 width, height, tile_size, isect_offsets, flatten_ids)
+        ctx.save_for_backward(means2d, conics, colors, opacities, isect_offsets, flatten_ids, alphas, last_ids)
+        ctx.background = background
+        ctx.cfg = (width, height, tile_size, absgrad)
+        return render, alphas
+
+    @staticmethod
+    def backward(ctx, v_render, v_alphas):
+        means2d, conics, colors, opacities, isect_offsets, flatten_ids, alphas, last_ids = ctx.saved_tensors
+        width, height, tile_size, absgrad = ctx.cfg
+        v_means2d, v_abs, v_conics, v_colors, v_opac = rasterize_bwd(
+            means2d.reshape(-1, 2), conics, colors, opacities, ctx.background, width, height, tile_size, isect_offsets,
+            flatten_ids, alphas, last_ids, v_render, v_alphas, absgrad)
+        if absgrad:
+            means2d.absgrad = v_abs.reshape(means2d.shape)
+        return (v_means2d.reshape(means2d.shape), v_conics, v_colors, v_opac) + (None,) * 7
+
+
+# --------------------------------------------------------------------------- gsplat-shaped API
+
+
+def rasterization(
+    means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Tensor,
+    viewmats: Tensor, Ks: Tensor, width: int, height: int,
+    near_plane: float = 0.01, far_plane: float = 1e10, radius_clip: float = 0.0, eps2d: float = 0.3,
+    sh_degree: Optional[int] = None, packed: bool = False, tile_size: int = 16,
+    backgrounds: Optional[Tensor] = None, render_mode: str = "RGB", sparse_grad: bool = False,
+    absgrad: bool = False, rasterize_mode: str = "classic",
+) -> Tuple[Tensor, Tensor, Dict]:
+    """CPU restatement of ``gsplat.rendering.rasterization`` as called at
+    ``dn_splatter/dn_model.py:495-516`` (single camera, packed=False)."""
+    assert viewmats.shape[0] == 1 and Ks.shape[0] == 1, "oracle renders one camera per call"
+    assert render_mode in ("RGB", "D", "ED", "RGB+D", "RGB+ED"), render_mode
+    assert not packed and not sparse_grad
+    N = means.shape[0]
+    viewmat, K = viewmats[0], Ks[0]
+    tw, th = math.ceil(width / tile_size), math.ceil(height / tile_size)
+
+    radii, means2d, depths, conics, comp, tiles = _Projection.apply(
+        means, quats, scales, viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip,
+        tile_size, rasterize_mode == "antialiased")
+    if rasterize_mode == "antialiased":
+        opacities = opacities * comp
+
+    with torch.no_grad():
+        _t, isect_ids, flatten_ids = isect_tiles(means2d.detach(), radii, depths.detach(), tile_size, tw, th)
+        isect_offsets = isect_offset_encode(isect_ids, tw, th)
+
+    if sh_degree is None:
+        cols = colors.reshape(N, -1)
+    else:
+        camtoworld = torch.inverse(viewmat)
+        dirs = means - camtoworld[:3, 3][None, :]
+        cols = _SphericalHarmonics.apply(sh_degree, dirs, colors, radii)
+        cols = torch.clamp_min(cols + 0.5, 0.0)
+
+    if render_mode in ("RGB+D", "RGB+ED"):
+        cols = torch.cat([cols, depths[:, None]], dim=-1)
+    elif render_mode in ("D", "ED"):
+        cols = depths[:, None]
+
+    bg = backgrounds[0] if backgrounds is not None else None
+    means2d_c = means2d[None]  # [1,N,2]: the object the caller retains grad / reads .absgrad on
+    render, alphas = _RasterizeToPixels.apply(means2d_c, conics, cols, opacities, bg, width, height,
+                                              tile_size, isect_offsets, flatten_ids, absgrad)
+    if render_mode in ("ED", "RGB+ED"):
+        render = torch.cat([render[..., :-1], render[..., -1:] / alphas[..., None].clamp(min=1e-10)], dim=-1)
+
+    meta = {
+        "camera_ids": None, "gaussian_ids": None,
+        "radii": radii[None], "means2d": means2d_c, "depths": depths[None], "conics": conics[None],
+        "opacities": opacities[None], "tile_width": tw, "tile_height": th,
+        "tiles_per_gauss": tiles[None], "isect_ids": isect_ids, "flatten_ids": flatten_ids,
+        "isect_offsets": isect_offsets[None], "width": width, "height": height, "tile_size": tile_size,
+        "n_cameras": 1,
+    }
+    return render[None], alphas[None, ..., None], meta
+
+
+def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height,
+                        img_width, block_width, background=None, return_alpha=False):
+    """CPU restatement of the legacy ``gsplat.rasterize_gaussians`` as called at
+    ``dn_splatter/dn_model.py:564-575``: re-bin, re-sort, composite with background
+    defaulting to ones."""
+    assert 1 < block_width <= 16
+    if background is None:
+        background = torch.ones(colors.shape[-1], dtype=colors.dtype)
+    tw, th = math.ceil(img_width / block_width), math.ceil(img_height / block_width)
+    with torch.no_grad():
+        _t, isect_ids, flatten_ids = isect_tiles(xys.detach(), radii, depths.detach(), block_width, tw, th)
+        offsets = isect_offset_encode(isect_ids, tw, th)
+    if flatten_ids.shape[0] < 1:
+        out = torch.ones(img_height, img_width, colors.shape[-1], dtype=colors.dtype) * background
+        return (out, torch.zeros(img_height, img_width, dtype=colors.dtype)) if return_alpha else out
+    opac = opacity.reshape(-1)
+    render, alphas = _RasterizeToPixels.apply(xys, conics, colors, opac, background, img_width, img_height,
+                                              block_width, offsets, flatten_ids, False)
+    return (render, alphas) if return_alpha else render
