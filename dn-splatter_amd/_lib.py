@@ -1,0 +1,144 @@
+"""ctypes binding of ``libdnsplat.so`` (C ABI in ``include/dnsplat.h``).
+
+The library is the product: there is NO fallback.  If the shared object is missing or a call
+fails, this module raises — it never routes to a CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_float, c_int32, c_int64, c_size_t, c_void_p
+from pathlib import Path
+
+_PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = _PKG_DIR / "libdnsplat.so"
+CSRC_DIR = _PKG_DIR / "csrc"
+
+ABI_VERSION = 1
+RECORD_FLOATS = 16
+MAX_CHANNELS = 8
+
+
+class DnsplatError(RuntimeError):
+    pass
+
+
+class Scene(ctypes.Structure):
+    _fields_ = [
+        ("N", c_int32),
+        ("means", c_void_p), ("quats", c_void_p), ("scales", c_void_p), ("opacities", c_void_p),
+        ("scales_are_log", c_int32), ("opacities_are_logit", c_int32),
+        ("sh_degree", c_int32), ("sh_K", c_int32),
+        ("sh0", c_void_p), ("sh0_stride", c_int32),
+        ("shN", c_void_p), ("shN_stride", c_int32),
+        ("colors", c_void_p), ("n_colors", c_int32),
+    ]
+
+
+class Camera(ctypes.Structure):
+    _fields_ = [
+        ("viewmat", c_void_p), ("K", c_void_p), ("normal_frame", c_void_p),
+        ("width", c_int32), ("height", c_int32), ("tile_size", c_int32),
+        ("eps2d", c_float), ("near_plane", c_float), ("far_plane", c_float), ("radius_clip", c_float),
+        ("antialiased", c_int32),
+    ]
+
+
+class ProjOut(ctypes.Structure):
+    _fields_ = [
+        ("radii", c_void_p), ("means2d", c_void_p), ("depths", c_void_p), ("conics", c_void_p),
+        ("compensations", c_void_p), ("tiles_per_gauss", c_void_p), ("splats", c_void_p),
+        ("normals_world", c_void_p),
+        ("with_depth_channel", c_int32), ("with_normal_channels", c_int32),
+    ]
+
+
+class BinArgs(ctypes.Structure):
+    _fields_ = [
+        ("N", c_int32), ("width", c_int32), ("height", c_int32), ("tile_size", c_int32),
+        ("means2d", c_void_p), ("radii", c_void_p), ("depths", c_void_p), ("tiles_per_gauss", c_void_p),
+        ("isect_capacity", c_int64),
+        ("flatten_ids", c_void_p), ("tile_offsets", c_void_p),
+        ("n_isects", c_void_p), ("n_isects_host", c_void_p),
+        ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+    ]
+
+
+class RasterArgs(ctypes.Structure):
+    _fields_ = [
+        ("width", c_int32), ("height", c_int32), ("tile_size", c_int32), ("D", c_int32),
+        ("splats", c_void_p), ("flatten_ids", c_void_p), ("tile_offsets", c_void_p), ("background", c_void_p),
+        ("ed_channel", c_int32),
+        ("render", c_void_p), ("alphas", c_void_p), ("last_ids", c_void_p),
+        ("v_render", c_void_p), ("v_alphas", c_void_p),
+        ("xy_split", c_int32),
+        ("v_splats", c_void_p),
+    ]
+
+
+class ProjGrads(ctypes.Structure):
+    _fields_ = [
+        ("radii", c_void_p), ("v_splats", c_void_p), ("v_means2d", c_void_p), ("v_depths", c_void_p),
+        ("v_conics", c_void_p), ("v_compensations", c_void_p),
+        ("v_means", c_void_p), ("v_quats", c_void_p), ("v_scales", c_void_p), ("v_opacities", c_void_p),
+        ("v_sh0", c_void_p), ("v_sh0_stride", c_int32),
+        ("v_shN", c_void_p), ("v_shN_stride", c_int32),
+        ("v_colors", c_void_p),
+    ]
+
+
+# every symbol include/dnsplat.h declares (tests/test_abi.py checks the .so exports all of them)
+EXPORTS = [
+    "dnsplat_strerror", "dnsplat_abi_version",
+    "dnsplat_project_fwd", "dnsplat_pack_splats",
+    "dnsplat_bin_workspace_bytes", "dnsplat_bin_prepare", "dnsplat_bin_emit_sort", "dnsplat_bin_isect_ids",
+    "dnsplat_raster_fwd", "dnsplat_raster_bwd",
+    "dnsplat_project_bwd",
+]
+
+_lib = None
+
+
+def build(force: bool = False) -> Path:
+    """Compile the HIP sources for gfx950 into ``libdnsplat.so`` next to this file (hipcc cross-compiles
+    without a GPU)."""
+    srcs = list(CSRC_DIR.glob("*.hip")) + list(CSRC_DIR.glob("*.h")) + list((_PKG_DIR.parent / "include").glob("*.h"))
+    stale = force or not LIB_PATH.exists() or any(s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs)
+    if stale:
+        subprocess.run(["bash", str(CSRC_DIR / "build.sh")], check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded library.  Raises if it is not built — no silent fallback."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise DnsplatError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `bash {CSRC_DIR / 'build.sh'}`. There is no CPU fallback.")
+        L = ctypes.CDLL(str(LIB_PATH))
+        L.dnsplat_strerror.restype = ctypes.c_char_p
+        L.dnsplat_strerror.argtypes = [ctypes.c_int]
+        L.dnsplat_abi_version.restype = ctypes.c_int
+        L.dnsplat_bin_workspace_bytes.restype = c_size_t
+        L.dnsplat_bin_workspace_bytes.argtypes = [c_int32, c_int64, c_int32]
+        L.dnsplat_project_fwd.argtypes = [ctypes.POINTER(Scene), ctypes.POINTER(Camera), ctypes.POINTER(ProjOut), c_void_p]
+        L.dnsplat_project_bwd.argtypes = [ctypes.POINTER(Scene), ctypes.POINTER(Camera), ctypes.POINTER(ProjOut),
+                                          ctypes.POINTER(ProjGrads), c_void_p]
+        L.dnsplat_pack_splats.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]
+        L.dnsplat_bin_prepare.argtypes = [ctypes.POINTER(BinArgs), c_void_p]
+        L.dnsplat_bin_emit_sort.argtypes = [ctypes.POINTER(BinArgs), c_void_p]
+        L.dnsplat_bin_isect_ids.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
+        L.dnsplat_raster_fwd.argtypes = [ctypes.POINTER(RasterArgs), c_void_p]
+        L.dnsplat_raster_bwd.argtypes = [ctypes.POINTER(RasterArgs), c_void_p]
+        if L.dnsplat_abi_version() != ABI_VERSION:
+            raise DnsplatError(f"libdnsplat ABI {L.dnsplat_abi_version()} != binding {ABI_VERSION}; rebuild")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise DnsplatError(f"{what} failed: {lib().dnsplat_strerror(rc).decode()} (code {rc})")

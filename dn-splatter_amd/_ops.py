@@ -1,0 +1,465 @@
+"""Tensor-level wrappers over the C ABI and the two autograd nodes everything else is built from.
+
+Graph shape (same cut as gsplat 1.0.0, so the tensors dn-splatter reads back keep their meaning):
+
+    params --_ProjectFn--> means2d, depths, conics, splats --_RasterFn--> render, alphas
+              (stage 1/5)        ^ info["means2d"]: .grad / .absgrad            (stages 2-4)
+
+``_ProjectFn`` fuses what gsplat splits into fully_fused_projection + spherical_harmonics and what
+dn_model.py:543-560 does in torch; ``_RasterFn`` fuses isect_tiles + sort + rasterize_to_pixels.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import BinArgs, Camera, ProjGrads, ProjOut, RasterArgs, Scene, RECORD_FLOATS
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(t: Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise _lib.DnsplatError(
+            f"{name} is on {t.device}: the dn-splatter_amd renderer runs only on the GPU through libdnsplat.so "
+            "(there is no CPU fallback; the CPU oracle under oracle/ is test infrastructure)")
+
+
+def _f32c(t: Tensor, name: str) -> Tensor:
+    _need_gpu(t, name)
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------------------------------
+# configuration records
+
+
+@dataclass(frozen=True)
+class ProjCfg:
+    width: int
+    height: int
+    tile_size: int = 16
+    eps2d: float = 0.3
+    near_plane: float = 0.01
+    far_plane: float = 1e10
+    radius_clip: float = 0.0
+    antialiased: bool = False
+    scales_are_log: bool = False
+    opacities_are_logit: bool = False
+    sh_degree: int = -1          # -1: direct colours
+    with_depth: bool = False
+    with_normals: bool = False
+    want_normals_world: bool = False
+
+    @property
+    def tiles(self):
+        return math.ceil(self.width / self.tile_size), math.ceil(self.height / self.tile_size)
+
+
+class _Buffers:
+    """Grow-only per-device scratch (binning workspace, pinned counters) so steady-state frames do not
+    touch the allocator."""
+
+    def __init__(self):
+        self.ws: Dict[torch.device, Tensor] = {}
+        self.pinned: Dict[torch.device, Tensor] = {}
+        self.capacity_hint: Dict[tuple, int] = {}
+
+    def workspace(self, device, nbytes: int) -> Tensor:
+        cur = self.ws.get(device)
+        if cur is None or cur.numel() < nbytes:
+            cur = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+            self.ws[device] = cur
+        return cur
+
+    def pinned_i64(self, device) -> Tensor:
+        cur = self.pinned.get(device)
+        if cur is None:
+            cur = torch.zeros(1, dtype=torch.int64).pin_memory()
+            self.pinned[device] = cur
+        return cur
+
+
+BUFFERS = _Buffers()
+
+# "sync": read n_isects back before emitting (one host round-trip per frame, what gsplat does).
+# "capacity": size the intersection buffers from the previous frames (x1.25), enqueue everything,
+#             then verify n_isects <= capacity while the compositing kernel already runs; an overflow
+#             re-runs the emit+composite with exact sizes.  No GPU bubble, always correct.
+BIN_POLICY = {"mode": "sync"}
+
+
+def set_bin_policy(mode: str) -> None:
+    if mode not in ("sync", "capacity"):
+        raise ValueError(mode)
+    BIN_POLICY["mode"] = mode
+
+
+# --------------------------------------------------------------------------------------------------
+# stage 1 / 5
+
+
+def _scene_struct(N, means, quats, scales, opacities, cfg: ProjCfg, sh0, sh0_stride, shN, shN_stride, sh_K, colors):
+    s = Scene()
+    s.N = N
+    s.means, s.quats, s.scales, s.opacities = _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities)
+    s.scales_are_log = int(cfg.scales_are_log)
+    s.opacities_are_logit = int(cfg.opacities_are_logit)
+    s.sh_degree = cfg.sh_degree
+    s.sh_K = sh_K
+    s.sh0, s.sh0_stride = _ptr(sh0), sh0_stride
+    s.shN, s.shN_stride = _ptr(shN), shN_stride
+    s.colors = _ptr(colors)
+    s.n_colors = 0 if colors is None else colors.shape[-1]
+    return s
+
+
+def _camera_struct(viewmat, K, normal_frame, cfg: ProjCfg):
+    c = Camera()
+    c.viewmat, c.K, c.normal_frame = _ptr(viewmat), _ptr(K), _ptr(normal_frame)
+    c.width, c.height, c.tile_size = cfg.width, cfg.height, cfg.tile_size
+    c.eps2d, c.near_plane, c.far_plane, c.radius_clip = cfg.eps2d, cfg.near_plane, cfg.far_plane, cfg.radius_clip
+    c.antialiased = int(cfg.antialiased)
+    return c
+
+
+class _ProjectFn(torch.autograd.Function):
+    """Stage 1 forward / stage 5 backward.  SH coefficients come either as one tensor ``coeffs``
+    [N,K,3] (gsplat layout, dn_model.py:466-468 concatenates it) or split ``sh0`` [N,3] +
+    ``shN`` [N,K-1,3] (the model's own features_dc / features_rest — no 192 B/Gaussian cat copy)."""
+
+    @staticmethod
+    def forward(ctx, means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, cfg: ProjCfg):
+        means = _f32c(means, "means"); quats = _f32c(quats, "quats"); scales = _f32c(scales, "scales")
+        opacities = _f32c(opacities, "opacities")
+        viewmat = _f32c(viewmat, "viewmats"); K = _f32c(K, "Ks")
+        N = means.shape[0]
+        dev = means.device
+        sh_K = 0
+        p_sh0 = p_shN = None
+        s0 = sN = 0
+        if cfg.sh_degree >= 0:
+            if coeffs is not None:
+                coeffs = _f32c(coeffs, "colors")
+                sh_K = coeffs.shape[1]
+                p_sh0, s0 = coeffs, 3 * sh_K
+                p_shN, sN = coeffs.view(-1)[3:], 3 * sh_K
+            else:
+                sh0 = _f32c(sh0, "features_dc")
+                sh_K = 1
+                p_sh0, s0 = sh0, 3
+                if shN is not None and shN.shape[1] > 0:
+                    shN = _f32c(shN, "features_rest")
+                    sh_K = 1 + shN.shape[1]
+                    p_shN, sN = shN, 3 * (sh_K - 1)
+            if sh_K < (cfg.sh_degree + 1) ** 2:
+                raise ValueError(f"sh_degree={cfg.sh_degree} needs {(cfg.sh_degree + 1) ** 2} bases, got {sh_K}")
+        elif colors is not None:
+            colors = _f32c(colors, "colors")
+        if normal_frame is not None:
+            normal_frame = _f32c(normal_frame, "normal_frame")
+
+        radii = torch.empty(N, dtype=torch.int32, device=dev)
+        tiles = torch.empty(N, dtype=torch.int32, device=dev)
+        means2d = torch.empty(1, N, 2, dtype=torch.float32, device=dev)
+        depths = torch.empty(1, N, dtype=torch.float32, device=dev)
+        conics = torch.empty(1, N, 3, dtype=torch.float32, device=dev)
+        comp = torch.empty(1, N, dtype=torch.float32, device=dev) if cfg.antialiased else None
+        splats = torch.empty(N, RECORD_FLOATS, dtype=torch.float32, device=dev)
+        nworld = torch.empty(N, 3, dtype=torch.float32, device=dev) if cfg.want_normals_world else None
+
+        scene = _scene_struct(N, means, quats, scales, opacities, cfg, p_sh0, s0, p_shN, sN, sh_K, colors)
+        cam = _camera_struct(viewmat, K, normal_frame, cfg)
+        out = ProjOut()
+        out.radii, out.means2d, out.depths, out.conics = _ptr(radii), _ptr(means2d), _ptr(depths), _ptr(conics)
+        out.compensations, out.tiles_per_gauss, out.splats = _ptr(comp), _ptr(tiles), _ptr(splats)
+        out.normals_world = _ptr(nworld)
+        out.with_depth_channel = int(cfg.with_depth)
+        out.with_normal_channels = int(cfg.with_normals)
+        _lib.check(_lib.lib().dnsplat_project_fwd(ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(out), _stream()),
+                   "dnsplat_project_fwd")
+
+        ctx.cfg = cfg
+        ctx.sh_K = sh_K
+        ctx.layout = "cat" if coeffs is not None else ("split" if cfg.sh_degree >= 0 else "colors")
+        ctx.save_for_backward(means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, radii)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(radii, tiles)
+        empty = torch.empty(0, device=dev)
+        if nworld is not None:
+            ctx.mark_non_differentiable(nworld)
+        return (means2d, depths, conics, comp if comp is not None else empty, splats, radii, tiles,
+                nworld if nworld is not None else empty)
+
+    @staticmethod
+    def backward(ctx, v_means2d, v_depths, v_conics, v_comp, v_splats, _r, _t, _n):
+        means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, radii = ctx.saved_tensors
+        cfg: ProjCfg = ctx.cfg
+        N = means.shape[0]
+        dev = means.device
+        if v_splats is None:
+            v_splats = torch.zeros(N, RECORD_FLOATS, dtype=torch.float32, device=dev)
+        v_splats = v_splats.contiguous()
+        # means2d's gradient normally IS columns 0-1 of the record (see _RasterFn.backward); only when the
+        # caller hung extra terms on info["means2d"] does a separate tensor arrive.
+        v_m2d = None
+        if v_means2d is not None:
+            same = (v_means2d.data_ptr() == v_splats.data_ptr() and v_means2d.stride()[-2:] == (RECORD_FLOATS, 1))
+            if not same:
+                v_m2d = v_means2d.reshape(N, 2).contiguous()
+        v_dep = v_depths.reshape(N).contiguous() if v_depths is not None else None
+        v_con = v_conics.reshape(N, 3).contiguous() if v_conics is not None else None
+        v_cmp = v_comp.reshape(N).contiguous() if (v_comp is not None and cfg.antialiased) else None
+
+        v_means = torch.empty_like(means)
+        v_quats = torch.empty_like(quats)
+        v_scales = torch.empty_like(scales)
+        v_opac = torch.empty_like(opacities)
+        sh_K = ctx.sh_K
+        p_sh0 = p_shN = None
+        s0 = sN = 0
+        g = ProjGrads()
+        v_coeffs = v_sh0 = v_shN = v_colors = None
+        if ctx.layout == "cat":
+            p_sh0, s0 = coeffs, 3 * sh_K
+            p_shN, sN = coeffs.view(-1)[3:], 3 * sh_K
+            v_coeffs = torch.empty_like(coeffs)
+            g.v_sh0, g.v_sh0_stride = _ptr(v_coeffs), 3 * sh_K
+            g.v_shN, g.v_shN_stride = _ptr(v_coeffs.view(-1)[3:]), 3 * sh_K
+        elif ctx.layout == "split":
+            p_sh0, s0 = sh0, 3
+            v_sh0 = torch.empty_like(sh0)
+            g.v_sh0, g.v_sh0_stride = _ptr(v_sh0), 3
+            if sh_K > 1:
+                p_shN, sN = shN, 3 * (sh_K - 1)
+                v_shN = torch.empty_like(shN)
+                g.v_shN, g.v_shN_stride = _ptr(v_shN), 3 * (sh_K - 1)
+        elif colors is not None:
+            v_colors = torch.empty_like(colors)
+            g.v_colors = _ptr(v_colors)
+
+        scene = _scene_struct(N, means, quats, scales, opacities, cfg, p_sh0, s0, p_shN, sN, sh_K, colors)
+        cam = _camera_struct(viewmat, K, normal_frame, cfg)
+        fwd = ProjOut()
+        fwd.with_depth_channel = int(cfg.with_depth)
+        fwd.with_normal_channels = int(cfg.with_normals)
+        g.radii, g.v_splats = _ptr(radii), _ptr(v_splats)
+        g.v_means2d, g.v_depths, g.v_conics, g.v_compensations = _ptr(v_m2d), _ptr(v_dep), _ptr(v_con), _ptr(v_cmp)
+        g.v_means, g.v_quats, g.v_scales, g.v_opacities = _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac)
+        _lib.check(_lib.lib().dnsplat_project_bwd(ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(fwd),
+                                                  ctypes.byref(g), _stream()), "dnsplat_project_bwd")
+        need = ctx.needs_input_grad
+        return (v_means if need[0] else None, v_quats if need[1] else None, v_scales if need[2] else None,
+                v_opac if need[3] else None, v_coeffs if need[4] else None, v_sh0 if need[5] else None,
+                v_shN if need[6] else None, v_colors if need[7] else None, None, None, None, None)
+
+
+def project(means, quats, scales, opacities, *, coeffs=None, sh0=None, shN=None, colors=None, viewmat, K,
+            normal_frame=None, cfg: ProjCfg):
+    """-> dict(means2d[1,N,2], depths[1,N], conics[1,N,3], compensations, splats[N,16], radii[N], tiles[N],
+    normals_world)"""
+    m2d, dep, con, comp, splats, radii, tiles, nworld = _ProjectFn.apply(
+        means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, cfg)
+    return dict(means2d=m2d, depths=dep, conics=con, compensations=comp if comp.numel() else None, splats=splats,
+                radii=radii, tiles_per_gauss=tiles, normals_world=nworld if nworld.numel() else None)
+
+
+# --------------------------------------------------------------------------------------------------
+# stage 2: binning
+
+
+@dataclass
+class Binning:
+    flatten_ids: Tensor      # [capacity] int32 (first n_isects valid)
+    tile_offsets: Tensor     # [T+1] int32
+    n_isects: int
+    tile_width: int
+    tile_height: int
+
+
+def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, width: int, height: int,
+              tile_size: int, after_emit=None) -> Binning:
+    """Stage 2.  ``after_emit(binning)`` (optional) is called right after the emit/sort kernels are
+    enqueued and BEFORE any host wait, so the caller can queue the compositing kernel behind them; in
+    "capacity" mode it is called again if the capacity guess turned out too small."""
+    lib = _lib.lib()
+    dev = means2d.device
+    N = radii.shape[0]
+    tw, th = math.ceil(width / tile_size), math.ceil(height / tile_size)
+    T = tw * th
+    n_dev = torch.empty(1, dtype=torch.int64, device=dev)
+    n_host = BUFFERS.pinned_i64(dev)
+    key = (dev, N, width, height)
+
+    def make_args(capacity, flatten_ids, tile_offsets):
+        nbytes = lib.dnsplat_bin_workspace_bytes(N, capacity, T)
+        ws = BUFFERS.workspace(dev, nbytes)
+        a = BinArgs()
+        a.N, a.width, a.height, a.tile_size = N, width, height, tile_size
+        a.means2d, a.radii, a.depths, a.tiles_per_gauss = _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(tiles)
+        a.isect_capacity = capacity
+        a.flatten_ids, a.tile_offsets = _ptr(flatten_ids), _ptr(tile_offsets)
+        a.n_isects, a.n_isects_host = _ptr(n_dev), ctypes.c_void_p(n_host.data_ptr())
+        a.workspace, a.workspace_bytes = _ptr(ws), ws.numel()
+        return a, ws
+
+    tile_offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
+    mode = BIN_POLICY["mode"]
+    hint = BUFFERS.capacity_hint.get(key, 0)
+    if mode == "capacity" and hint:
+        capacity = hint
+        flatten_ids = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+        args, ws0 = make_args(capacity, flatten_ids, tile_offsets)
+        _lib.check(lib.dnsplat_bin_prepare(ctypes.byref(args), _stream()), "dnsplat_bin_prepare")
+        ev = torch.cuda.Event()
+        ev.record()
+        _lib.check(lib.dnsplat_bin_emit_sort(ctypes.byref(args), _stream()), "dnsplat_bin_emit_sort")
+        b = Binning(flatten_ids, tile_offsets, -1, tw, th)
+        if after_emit is not None:
+            after_emit(b)
+        ev.synchronize()  # waits for the (early) depth sort only; compositing keeps running
+        n = int(n_host.item())
+        if n <= capacity:
+            b.n_isects = n
+            BUFFERS.capacity_hint[key] = max(hint, int(n * 1.25) + 4096)
+            return b
+        # guess too small: fall through and redo with the exact size
+    else:
+        # the N-sized front of the workspace has the same layout for every capacity, so the depth sort
+        # done here stays valid for the emit below as long as the buffer is not re-allocated
+        args, ws0 = make_args(hint, None, tile_offsets)
+        _lib.check(lib.dnsplat_bin_prepare(ctypes.byref(args), _stream()), "dnsplat_bin_prepare")
+        torch.cuda.current_stream().synchronize()
+        n = int(n_host.item())
+    capacity = n
+    BUFFERS.capacity_hint[key] = max(hint, int(n * 1.25) + 4096)
+    flatten_ids = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+    args, ws1 = make_args(capacity, flatten_ids, tile_offsets)
+    if ws1.data_ptr() != ws0.data_ptr():
+        _lib.check(lib.dnsplat_bin_prepare(ctypes.byref(args), _stream()), "dnsplat_bin_prepare")
+    _lib.check(lib.dnsplat_bin_emit_sort(ctypes.byref(args), _stream()), "dnsplat_bin_emit_sort")
+    b = Binning(flatten_ids, tile_offsets, n, tw, th)
+    if after_emit is not None:
+        after_emit(b)
+    return b
+
+
+def isect_ids(b: Binning, depths: Tensor) -> Tensor:
+    """gsplat's 64-bit sorted keys (tile << 32 | depth bits), rebuilt on demand for the info dict."""
+    out = torch.empty(max(b.n_isects, 1), dtype=torch.int64, device=depths.device)
+    _lib.check(_lib.lib().dnsplat_bin_isect_ids(b.tile_width * b.tile_height, _ptr(b.tile_offsets), _ptr(b.flatten_ids),
+                                                _ptr(depths.reshape(-1)), _ptr(out), b.n_isects, _stream()),
+               "dnsplat_bin_isect_ids")
+    return out[: b.n_isects]
+
+
+# --------------------------------------------------------------------------------------------------
+# stages 3/4: compositing
+
+
+class _RasterFn(torch.autograd.Function):
+    """Bins, then composites D channels.  ``means2d`` is an input only so that autograd routes the
+    xy-gradient through the tensor dn-splatter calls retain_grad() on (dn_model.py:517-519); the
+    kernels read xy from ``splats``."""
+
+    @staticmethod
+    def forward(ctx, means2d, splats, depths, radii, tiles, background, width, height, tile_size, D, ed_channel,
+                xy_split, absgrad, holder):
+        dev = splats.device
+        render = torch.empty(height, width, D, dtype=torch.float32, device=dev)
+        alphas = torch.empty(height, width, dtype=torch.float32, device=dev)
+        last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
+        bg = _f32c(background, "background") if background is not None else None
+
+        def composite(b: Binning):
+            a = RasterArgs()
+            a.width, a.height, a.tile_size, a.D = width, height, tile_size, D
+            a.splats, a.flatten_ids, a.tile_offsets = _ptr(splats), _ptr(b.flatten_ids), _ptr(b.tile_offsets)
+            a.background = _ptr(bg)
+            a.ed_channel = ed_channel
+            a.render, a.alphas, a.last_ids = _ptr(render), _ptr(alphas), _ptr(last_ids)
+            _lib.check(_lib.lib().dnsplat_raster_fwd(ctypes.byref(a), _stream()), "dnsplat_raster_fwd")
+
+        b = bin_tiles(means2d.detach().reshape(-1, 2), radii, depths.detach().reshape(-1), tiles, width, height,
+                      tile_size, after_emit=composite)
+        if holder is not None:
+            holder["binning"] = b
+        ctx.save_for_backward(means2d, splats, b.flatten_ids, b.tile_offsets, render, alphas, last_ids)
+        ctx.bg = bg
+        ctx.cfg = (width, height, tile_size, D, ed_channel, xy_split, absgrad)
+        ctx.set_materialize_grads(False)
+        return render, alphas
+
+    @staticmethod
+    def backward(ctx, v_render, v_alphas):
+        means2d, splats, flatten_ids, tile_offsets, render, alphas, last_ids = ctx.saved_tensors
+        width, height, tile_size, D, ed_channel, xy_split, absgrad = ctx.cfg
+        N = splats.shape[0]
+        dev = splats.device
+        v_splats = torch.zeros(N, RECORD_FLOATS, dtype=torch.float32, device=dev)
+        if v_render is None and v_alphas is None:
+            return (v_splats[:, 0:2].view(means2d.shape), v_splats) + (None,) * 12
+        if v_render is None:
+            v_render = torch.zeros_like(render)
+        v_render = v_render.contiguous()
+        v_alphas = v_alphas.contiguous() if v_alphas is not None else None
+        a = RasterArgs()
+        a.width, a.height, a.tile_size, a.D = width, height, tile_size, D
+        a.splats, a.flatten_ids, a.tile_offsets = _ptr(splats), _ptr(flatten_ids), _ptr(tile_offsets)
+        a.background = _ptr(ctx.bg)
+        a.ed_channel = ed_channel
+        a.render, a.alphas, a.last_ids = _ptr(render), _ptr(alphas), _ptr(last_ids)
+        a.v_render, a.v_alphas = _ptr(v_render), _ptr(v_alphas)
+        a.xy_split = xy_split
+        a.v_splats = _ptr(v_splats)
+        _lib.check(_lib.lib().dnsplat_raster_bwd(ctypes.byref(a), _stream()), "dnsplat_raster_bwd")
+        if absgrad:
+            # gsplat contract (dn_model.py:512, consumed by nerfstudio after_train via self.xys.absgrad)
+            means2d.absgrad = v_splats[:, 14:16].reshape(means2d.shape)
+        return (v_splats[:, 0:2].view(means2d.shape), v_splats) + (None,) * 12
+
+
+def rasterize(means2d, splats, depths, radii, tiles, *, background=None, width, height, tile_size=16, D,
+              ed_channel=-1, xy_split=None, absgrad=False, holder=None):
+    if tile_size != 16:
+        raise NotImplementedError("libdnsplat composites 16x16 tiles (dn_model.py:470-472 uses BLOCK_WIDTH = 16)")
+    if xy_split is None:
+        xy_split = D
+    render, alphas = _RasterFn.apply(means2d, splats, depths, radii, tiles, background, width, height, tile_size, D,
+                                     ed_channel, xy_split, absgrad, holder)
+    return render, alphas
+
+
+class _PackFn(torch.autograd.Function):
+    """(xys, conics, opacity, colors) -> records; front end of the legacy rasterize_gaussians call."""
+
+    @staticmethod
+    def forward(ctx, xys, conics, opacity, colors):
+        xys = _f32c(xys, "xys"); conics = _f32c(conics, "conics")
+        opacity = _f32c(opacity, "opacity"); colors = _f32c(colors, "colors")
+        N, C = colors.shape
+        splats = torch.empty(N, RECORD_FLOATS, dtype=torch.float32, device=xys.device)
+        _lib.check(_lib.lib().dnsplat_pack_splats(N, _ptr(xys), _ptr(conics), _ptr(opacity.reshape(-1)), _ptr(colors), C,
+                                                  _ptr(splats), _stream()), "dnsplat_pack_splats")
+        ctx.C = C
+        ctx.oshape = opacity.shape
+        return splats
+
+    @staticmethod
+    def backward(ctx, v_splats):
+        C = ctx.C
+        return (v_splats[:, 0:2], v_splats[:, 2:5], v_splats[:, 5].reshape(ctx.oshape), v_splats[:, 6:6 + C])

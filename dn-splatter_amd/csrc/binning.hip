@@ -1,0 +1,498 @@
+// binning.hip — tile binning (stage 2 of include/dnsplat.h).
+//
+// Replaces gsplat 1.0.0 isect_tiles (count + emit), cub::DeviceRadixSort::SortPairs over 64-bit
+// (tile | depth) keys, and isect_offset_encode; for the legacy
+// normal pass also map_gaussian_to_intersects + torch.sort + get_tile_bin_edges (A8).
+//
+// Same result, different route.  The reference sorts I = n_isects 12-byte pairs on ~45 key bits
+// (6 radix passes over I).  Here:
+//   1. the N Gaussians are stably radix-sorted once by their 32 depth bits (4 passes over N, N << I);
+//   2. (tile, gaussian) pairs are emitted in that depth order — one wave per 64 Gaussians, lanes
+//      write a Gaussian's tiles cooperatively so stores are coalesced;
+//   3. the pairs are stably radix-sorted on the tile id alone (ceil(log2(T)/8) = 2 passes over I).
+// A stable sort by tile of a depth-ordered stream is exactly the (tile, depth, emission index)
+// order the reference's stable 64-bit sort yields, so flatten_ids / tile offsets are bit-identical
+// while the I-sized traffic drops from 6 passes x 12 B to 2 passes x 8 B.
+//
+// All ranking inside a radix pass is done with wave64 ballots (match-by-digit) and LDS counters:
+// no atomics on the data path, fully deterministic.  Every kernel takes its element count from a
+// device word, so the whole stage can be enqueued without a host round-trip on n_isects (the
+// caller bounds it with `isect_capacity`).
+
+#include "splat_common.h"
+
+namespace {
+
+constexpr int RS_THREADS = 256;                  // 4 waves per workgroup
+constexpr int RS_ITEMS = 16;                     // keys per lane per pass
+constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
+constexpr int RS_WAVES = RS_THREADS / DNS_WAVE;
+constexpr int RS_DIGITS = 256;
+
+constexpr int SC_THREADS = 256;
+constexpr int SC_ITEMS = 8;
+constexpr int SC_CHUNK = SC_THREADS * SC_ITEMS;
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (DNS_WAVE - 1); }
+
+// ------------------------------------------------------------------------------------------------
+// wave / block scan helpers (wave64 DPP-free version via __shfl_up; these kernels are tiny)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+#pragma unroll
+    for (int off = 1; off < DNS_WAVE; off <<= 1) {
+        uint32_t t = __shfl_up(v, off, DNS_WAVE);
+        if ((int)lane_id() >= off) v += t;
+    }
+    return v;
+}
+
+// inclusive scan over a 256-thread block; returns inclusive value, total in `total`
+__device__ __forceinline__ uint32_t block_incl_scan_256(uint32_t v, uint32_t *lds_wave /*[4]*/, uint32_t &total)
+{
+    const int w = threadIdx.x / DNS_WAVE;
+    uint32_t inc = wave_incl_scan(v);
+    if (lane_id() == DNS_WAVE - 1) lds_wave[w] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t s = lds_wave[i];
+        if (i < w) base += s;
+    }
+    total = lds_wave[0] + lds_wave[1] + lds_wave[2] + lds_wave[3];
+    __syncthreads();
+    return inc + base;
+}
+
+__global__ void set_u32_kernel(uint32_t *p, uint32_t v) { *p = v; }
+
+// ------------------------------------------------------------------------------------------------
+// 1. depth keys
+__global__ __launch_bounds__(256) void depth_keys_kernel(int N, const int32_t *__restrict__ radii,
+                                                         const float *__restrict__ depths,
+                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    // visible Gaussians have depth >= near_plane > 0, so the raw bits order like the floats; culled
+    // ones sort to the very end and emit nothing.
+    keys[g] = radii[g] > 0 ? __float_as_uint(depths[g]) : 0xFFFFFFFFu;
+    vals[g] = (uint32_t)g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. one LSD radix pass = histogram, per-digit scan, stable scatter
+__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t *__restrict__ keys,
+                                                                const uint32_t *__restrict__ n_ptr, uint32_t n_cap,
+                                                                int shift, uint32_t *__restrict__ table, int nb)
+{
+    __shared__ uint32_t hist[RS_DIGITS];
+    const uint32_t n = min(*n_ptr, n_cap);
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * RS_CHUNK;
+    if (base < n) {
+#pragma unroll
+        for (int i = 0; i < RS_ITEMS; ++i) {
+            uint32_t idx = base + i * RS_THREADS + threadIdx.x;
+            if (idx < n) atomicAdd(&hist[(keys[idx] >> shift) & 0xff], 1u);
+        }
+    }
+    __syncthreads();
+    table[(size_t)threadIdx.x * nb + blockIdx.x] = hist[threadIdx.x];
+}
+
+// one workgroup per digit: exclusive scan of table[d][0..nb) in place, totals[d] = row sum
+__global__ __launch_bounds__(SC_THREADS) void radix_scan_kernel(uint32_t *__restrict__ table, int nb,
+                                                                uint32_t *__restrict__ totals)
+{
+    __shared__ uint32_t lds_wave[4];
+    uint32_t *row = table + (size_t)blockIdx.x * nb;
+    uint32_t carry = 0;
+    for (int start = 0; start < nb; start += SC_THREADS) {
+        int i = start + threadIdx.x;
+        uint32_t v = (i < nb) ? row[i] : 0u;
+        uint32_t tot;
+        uint32_t inc = block_incl_scan_256(v, lds_wave, tot);
+        if (i < nb) row[i] = carry + inc - v;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+template <bool WRITE_KEYS>
+__global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ n_ptr, uint32_t n_cap, int shift,
+    const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nb)
+{
+    __shared__ uint32_t wave_cnt[RS_WAVES][RS_DIGITS];
+    __shared__ uint32_t wave_base[RS_WAVES][RS_DIGITS];
+    __shared__ uint32_t lds_wave[4];
+    const uint32_t n = min(*n_ptr, n_cap);
+    const uint32_t base = blockIdx.x * RS_CHUNK;
+    if (base >= n) return;
+    const int w = threadIdx.x / DNS_WAVE;
+    const uint32_t lane = lane_id();
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; ++i) wave_cnt[i][threadIdx.x] = 0;
+    __syncthreads();
+
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], rnk[RS_ITEMS];
+    const uint32_t wave_start = base + w * (DNS_WAVE * RS_ITEMS);
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const uint32_t idx = wave_start + r * DNS_WAVE + lane;
+        const bool valid = idx < n;
+        key[r] = valid ? keys_in[idx] : 0u;
+        val[r] = valid ? vals_in[idx] : 0u;
+        const uint32_t d = (key[r] >> shift) & 0xff;
+        // match-any by digit: 8 ballots partition the wave into equal-digit lane sets
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool b = (d >> bit) & 1;
+            const uint64_t bal = __ballot(b);
+            m &= b ? bal : ~bal;
+        }
+        const uint32_t prior = wave_cnt[w][d];            // same address across the set -> LDS broadcast
+        const uint32_t below = __popcll(m & lt_mask);
+        rnk[r] = prior + below;
+        if (valid && below == 0) wave_cnt[w][d] = prior + __popcll(m);  // set leader bumps the counter
+    }
+    __syncthreads();
+    {
+        // digit d = threadIdx.x: global base = (#keys with smaller digit) + (#same digit in earlier blocks)
+        const uint32_t tot = totals[threadIdx.x];
+        uint32_t t2;
+        const uint32_t inc = block_incl_scan_256(tot, lds_wave, t2);
+        uint32_t run = (inc - tot) + table[(size_t)threadIdx.x * nb + blockIdx.x];
+#pragma unroll
+        for (int i = 0; i < RS_WAVES; ++i) {
+            wave_base[i][threadIdx.x] = run;
+            run += wave_cnt[i][threadIdx.x];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const uint32_t idx = wave_start + r * DNS_WAVE + lane;
+        if (idx < n) {
+            const uint32_t d = (key[r] >> shift) & 0xff;
+            const uint32_t dst = wave_base[w][d] + rnk[r];
+            if (WRITE_KEYS) keys_out[dst] = key[r];
+            vals_out[dst] = val[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. inclusive scan of tiles_per_gauss gathered in depth order  -> cum[N], total
+__global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(int N, const uint32_t *__restrict__ order,
+                                                               const int32_t *__restrict__ tiles,
+                                                               uint32_t *__restrict__ sums)
+{
+    __shared__ uint32_t lds_wave[4];
+    const int base = blockIdx.x * SC_CHUNK + threadIdx.x * SC_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SC_ITEMS; ++i) {
+        int j = base + i;
+        if (j < N) s += (uint32_t)tiles[order[j]];
+    }
+    uint32_t tot;
+    block_incl_scan_256(s, lds_wave, tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SC_THREADS) void scan_sums_excl_kernel(uint32_t *__restrict__ sums, int nb)
+{
+    __shared__ uint32_t lds_wave[4];
+    uint32_t carry = 0;
+    for (int start = 0; start < nb; start += SC_THREADS) {
+        int i = start + threadIdx.x;
+        uint32_t v = (i < nb) ? sums[i] : 0u;
+        uint32_t tot;
+        uint32_t inc = block_incl_scan_256(v, lds_wave, tot);
+        if (i < nb) sums[i] = carry + inc - v;
+        carry += tot;
+    }
+}
+
+__global__ __launch_bounds__(SC_THREADS) void scan_final_kernel(int N, const uint32_t *__restrict__ order,
+                                                                const int32_t *__restrict__ tiles,
+                                                                const uint32_t *__restrict__ sums,
+                                                                uint32_t *__restrict__ cum, uint32_t *__restrict__ total_u32,
+                                                                int64_t *__restrict__ total_i64)
+{
+    __shared__ uint32_t lds_wave[4];
+    const int base = blockIdx.x * SC_CHUNK + threadIdx.x * SC_ITEMS;
+    uint32_t v[SC_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SC_ITEMS; ++i) {
+        int j = base + i;
+        v[i] = (j < N) ? (uint32_t)tiles[order[j]] : 0u;
+        s += v[i];
+    }
+    uint32_t tot;
+    uint32_t inc = block_incl_scan_256(s, lds_wave, tot);
+    uint32_t run = sums[blockIdx.x] + inc - s;
+#pragma unroll
+    for (int i = 0; i < SC_ITEMS; ++i) {
+        int j = base + i;
+        run += v[i];
+        if (j < N) {
+            cum[j] = run;
+            if (j == N - 1) { *total_u32 = run; *total_i64 = (int64_t)run; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 4. emission in depth order.  One wave owns 64 consecutive sorted Gaussians; for each one that hits
+// tiles, the 64 lanes write its (tile, gaussian) pairs side by side (row-major over its tile bbox,
+// the reference's emission order).
+__global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__restrict__ order,
+                                                   const uint32_t *__restrict__ cum,
+                                                   const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+                                                   int tile_size, int tw, int th, uint32_t cap,
+                                                   uint32_t *__restrict__ tkeys, uint32_t *__restrict__ tvals)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = lane_id();
+    uint32_t gid = 0, end = 0, start = 0;
+    int x0 = 0, y0 = 0, bw = 0;
+    if (j < N) {
+        gid = order[j];
+        end = cum[j];
+        start = (j == 0) ? 0u : cum[j - 1];
+        if (end > start) {
+            int x1, y1;
+            dns_tile_bbox(means2d[2 * gid], means2d[2 * gid + 1], (float)radii[gid], tile_size, tw, th, x0, y0, x1, y1);
+            bw = x1 - x0;
+        }
+    }
+    uint64_t todo = __ballot(end > start);
+    while (todo) {
+        const int src = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t s_gid = __shfl(gid, src, DNS_WAVE);
+        const uint32_t s_start = __shfl(start, src, DNS_WAVE);
+        const uint32_t s_cnt = __shfl(end, src, DNS_WAVE) - s_start;
+        const int s_x0 = __shfl(x0, src, DNS_WAVE), s_y0 = __shfl(y0, src, DNS_WAVE), s_bw = __shfl(bw, src, DNS_WAVE);
+        for (uint32_t t = lane; t < s_cnt; t += DNS_WAVE) {
+            const uint32_t dst = s_start + t;
+            if (dst < cap) {
+                const int ty = s_y0 + (int)(t / (uint32_t)s_bw), tx = s_x0 + (int)(t % (uint32_t)s_bw);
+                tkeys[dst] = (uint32_t)(ty * tw + tx);
+                tvals[dst] = s_gid;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 5. tile offsets from the tile-sorted keys (gsplat isect_offset_encode), T+1 entries
+__global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t *__restrict__ tkeys,
+                                                           const uint32_t *__restrict__ n_ptr, uint32_t n_cap,
+                                                           int n_tiles, int32_t *__restrict__ offsets)
+{
+    const uint32_t n = min(*n_ptr, n_cap);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0) {
+        if (i <= (uint32_t)n_tiles) offsets[i] = 0;
+        return;
+    }
+    if (i >= n) return;
+    const int cur = (int)tkeys[i];
+    const int prev = (i == 0) ? -1 : (int)tkeys[i - 1];
+    for (int t = prev + 1; t <= cur; ++t) offsets[t] = (int32_t)i;
+    if (i == n - 1)
+        for (int t = cur + 1; t <= n_tiles; ++t) offsets[t] = (int32_t)n;
+}
+
+__global__ __launch_bounds__(256) void isect_ids_kernel(int n_tiles, const int32_t *__restrict__ offsets,
+                                                        const int32_t *__restrict__ flatten_ids,
+                                                        const float *__restrict__ depths, int64_t *__restrict__ isect_ids,
+                                                        int64_t cap)
+{
+    // one workgroup per tile
+    const int t = blockIdx.x;
+    const int s = offsets[t], e = offsets[t + 1];
+    for (int i = s + threadIdx.x; i < e && i < cap; i += blockDim.x) {
+        const uint32_t bits = __float_as_uint(depths[flatten_ids[i]]);
+        isect_ids[i] = ((int64_t)t << 32) | (int64_t)bits;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct BinWs {
+    uint32_t *key_a, *key_b, *val_a, *val_b;  // [N]
+    uint32_t *cum;                            // [N]
+    uint32_t *tab_n;                          // [256 * nb_n]
+    uint32_t *totals;                         // [256]
+    uint32_t *sums;                           // [nb_scan]
+    uint32_t *n_gauss;                        // [1] = N (device copy so the radix kernels are generic)
+    uint32_t *total;                          // [1] n_isects as u32
+    uint32_t *tkey_a, *tkey_b, *tval_a, *tval_b;  // [cap]
+    uint32_t *tab_i;                          // [256 * nb_i]
+    int nb_n, nb_i, nb_scan;
+    size_t bytes;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+BinWs carve(void *ws, int N, int64_t cap)
+{
+    BinWs b{};
+    b.nb_n = (N + RS_CHUNK - 1) / RS_CHUNK;
+    b.nb_i = (int)((cap + RS_CHUNK - 1) / RS_CHUNK);
+    b.nb_scan = (N + SC_CHUNK - 1) / SC_CHUNK;
+    if (b.nb_n < 1) b.nb_n = 1;
+    if (b.nb_i < 1) b.nb_i = 1;
+    if (b.nb_scan < 1) b.nb_scan = 1;
+    size_t off = 0;
+    char *base = (char *)ws;
+    auto take = [&](size_t elems) {
+        uint32_t *p = (uint32_t *)(base + off);
+        off += align_up(elems * sizeof(uint32_t), 256);
+        return p;
+    };
+    size_t n = (size_t)(N > 0 ? N : 1), c = (size_t)(cap > 0 ? cap : 1);
+    b.key_a = take(n); b.key_b = take(n); b.val_a = take(n); b.val_b = take(n);
+    b.cum = take(n);
+    b.tab_n = take((size_t)RS_DIGITS * b.nb_n);
+    b.totals = take(RS_DIGITS);
+    b.sums = take(b.nb_scan);
+    b.n_gauss = take(1);
+    b.total = take(1);
+    b.tkey_a = take(c); b.tkey_b = take(c); b.tval_a = take(c); b.tval_b = take(c);
+    b.tab_i = take((size_t)RS_DIGITS * b.nb_i);
+    b.bytes = off;
+    return b;
+}
+
+int tile_bits(int n_tiles)
+{
+    int bits = 1;
+    while ((1 << bits) < n_tiles) ++bits;
+    return bits;
+}
+
+}  // namespace
+
+extern "C" size_t dnsplat_bin_workspace_bytes(int32_t N, int64_t isect_capacity, int32_t n_tiles)
+{
+    (void)n_tiles;
+    if (N < 0 || isect_capacity < 0) return 0;
+    return carve(nullptr, N, isect_capacity).bytes;
+}
+
+static int check_bin(const dnsplat_bin_args *a)
+{
+    if (!a) return DNSPLAT_ERR_INVALID_ARG;
+    if (a->N < 0 || a->width <= 0 || a->height <= 0 || a->tile_size <= 0) return DNSPLAT_ERR_INVALID_ARG;
+    if (a->isect_capacity < 0 || a->isect_capacity > 0x7fffffffLL) return DNSPLAT_ERR_INVALID_ARG;
+    if (!a->n_isects || !a->workspace) return DNSPLAT_ERR_INVALID_ARG;
+    if (a->N > 0 && (!a->means2d || !a->radii || !a->depths || !a->tiles_per_gauss)) return DNSPLAT_ERR_INVALID_ARG;
+    if (a->workspace_bytes < carve(nullptr, a->N, a->isect_capacity).bytes) return DNSPLAT_ERR_WORKSPACE;
+    return DNSPLAT_OK;
+}
+
+extern "C" int dnsplat_bin_prepare(const dnsplat_bin_args *a, dnsplat_stream_t stream_)
+{
+    int rc = check_bin(a);
+    if (rc != DNSPLAT_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    BinWs w = carve(a->workspace, a->N, a->isect_capacity);
+    const int N = a->N;
+    if (N == 0) {
+        if (hipMemsetAsync(a->n_isects, 0, sizeof(int64_t), stream) != hipSuccess) return DNSPLAT_ERR_LAUNCH;
+        if (hipMemsetAsync(w.total, 0, sizeof(uint32_t), stream) != hipSuccess) return DNSPLAT_ERR_LAUNCH;
+    } else {
+        const uint32_t n_u32 = (uint32_t)N;
+        hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, stream, w.n_gauss, n_u32);
+        hipLaunchKernelGGL(depth_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, a->radii, a->depths,
+                           w.key_a, w.val_a);
+        uint32_t *ka = w.key_a, *kb = w.key_b, *va = w.val_a, *vb = w.val_b;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 8 * pass;
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(w.nb_n), dim3(RS_THREADS), 0, stream, ka, w.n_gauss, n_u32, shift,
+                               w.tab_n, w.nb_n);
+            hipLaunchKernelGGL(radix_scan_kernel, dim3(RS_DIGITS), dim3(SC_THREADS), 0, stream, w.tab_n, w.nb_n, w.totals);
+            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(w.nb_n), dim3(RS_THREADS), 0, stream, ka, va, kb, vb,
+                               w.n_gauss, n_u32, shift, w.tab_n, w.totals, w.nb_n);
+            uint32_t *t = ka; ka = kb; kb = t;
+            t = va; va = vb; vb = t;
+        }
+        // after 4 passes the sorted order is back in val_a
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.val_a, a->tiles_per_gauss,
+                           w.sums);
+        hipLaunchKernelGGL(scan_sums_excl_kernel, dim3(1), dim3(SC_THREADS), 0, stream, w.sums, w.nb_scan);
+        hipLaunchKernelGGL(scan_final_kernel, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.val_a,
+                           a->tiles_per_gauss, w.sums, w.cum, w.total, a->n_isects);
+        DNS_CHECK_LAUNCH();
+    }
+    if (a->n_isects_host) {
+        if (hipMemcpyAsync(a->n_isects_host, a->n_isects, sizeof(int64_t), hipMemcpyDeviceToHost, stream) != hipSuccess)
+            return DNSPLAT_ERR_LAUNCH;
+    }
+    return DNSPLAT_OK;
+}
+
+extern "C" int dnsplat_bin_emit_sort(const dnsplat_bin_args *a, dnsplat_stream_t stream_)
+{
+    int rc = check_bin(a);
+    if (rc != DNSPLAT_OK) return rc;
+    if (!a->tile_offsets || (a->isect_capacity > 0 && !a->flatten_ids)) return DNSPLAT_ERR_INVALID_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    BinWs w = carve(a->workspace, a->N, a->isect_capacity);
+    const int tw = dns_tiles_w(a->width, a->tile_size), th = dns_tiles_h(a->height, a->tile_size);
+    const int n_tiles = tw * th;
+    const uint32_t cap = (uint32_t)a->isect_capacity;
+    if (a->N == 0 || cap == 0) {
+        if (hipMemsetAsync(a->tile_offsets, 0, sizeof(int32_t) * (size_t)(n_tiles + 1), stream) != hipSuccess)
+            return DNSPLAT_ERR_LAUNCH;
+        return DNSPLAT_OK;
+    }
+    hipLaunchKernelGGL(emit_kernel, dim3((a->N + 255) / 256), dim3(256), 0, stream, a->N, w.val_a, w.cum, a->means2d,
+                       a->radii, a->tile_size, tw, th, cap, w.tkey_a, w.tval_a);
+    const int bits = tile_bits(n_tiles);
+    const int passes = (bits + 7) / 8;
+    uint32_t *ka = w.tkey_a, *kb = w.tkey_b, *va = w.tval_a, *vb = w.tval_b;
+    for (int pass = 0; pass < passes; ++pass) {
+        const int shift = 8 * pass;
+        const bool last = pass == passes - 1;
+        uint32_t *vout = last ? (uint32_t *)a->flatten_ids : vb;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(w.nb_i), dim3(RS_THREADS), 0, stream, ka, w.total, cap, shift, w.tab_i,
+                           w.nb_i);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3(RS_DIGITS), dim3(SC_THREADS), 0, stream, w.tab_i, w.nb_i, w.totals);
+        hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(w.nb_i), dim3(RS_THREADS), 0, stream, ka, va, kb, vout, w.total,
+                           cap, shift, w.tab_i, w.totals, w.nb_i);
+        uint32_t *t = ka; ka = kb; kb = t;
+        t = va; va = vb; vb = t;
+    }
+    // sorted tile keys are in `ka` after the swap
+    const uint32_t cover = cap > (uint32_t)(n_tiles + 1) ? cap : (uint32_t)(n_tiles + 1);
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3((cover + 255) / 256), dim3(256), 0, stream, ka, w.total, cap, n_tiles,
+                       a->tile_offsets);
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}
+
+extern "C" int dnsplat_bin_isect_ids(int32_t n_tiles, const int32_t *tile_offsets, const int32_t *flatten_ids,
+                                     const float *depths, int64_t *isect_ids, int64_t capacity,
+                                     dnsplat_stream_t stream)
+{
+    if (n_tiles <= 0 || !tile_offsets || !isect_ids) return DNSPLAT_ERR_INVALID_ARG;
+    if (capacity == 0) return DNSPLAT_OK;
+    if (!flatten_ids || !depths) return DNSPLAT_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(isect_ids_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, n_tiles, tile_offsets,
+                       flatten_ids, depths, isect_ids, capacity);
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}

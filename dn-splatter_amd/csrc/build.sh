@@ -1,0 +1,17 @@
+#!/usr/bin/env bash
+# Builds libdnsplat.so for gfx950 (MI355X) in-tree.  project.hip is compiled without FMA contraction
+# (bit-exact radii / tile counts against the oracle); the compositing kernels keep contraction on.
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+mkdir -p _obj
+pids=()
+$HIPCC $COMMON -ffp-contract=off -c project.hip    -o _obj/project.o & pids+=($!)
+$HIPCC $COMMON                   -c binning.hip    -o _obj/binning.o & pids+=($!)
+$HIPCC $COMMON                   -c raster_fwd.hip -o _obj/raster_fwd.o & pids+=($!)
+$HIPCC $COMMON                   -c raster_bwd.hip -o _obj/raster_bwd.o & pids+=($!)
+$HIPCC $COMMON                   -c c_api.hip      -o _obj/c_api.o & pids+=($!)
+for p in "${pids[@]}"; do wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC _obj/project.o _obj/binning.o _obj/raster_fwd.o _obj/raster_bwd.o _obj/c_api.o -o ../libdnsplat.so
+echo "built $(realpath ../libdnsplat.so)"

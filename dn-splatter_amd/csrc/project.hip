@@ -1,0 +1,704 @@
+// project.hip — per-Gaussian front end and back end (stage 1 and stage 5 of include/dnsplat.h).
+//
+// Replaces, fused into one kernel each way:
+//   A0  activations               dn_splatter/dn_model.py:497-499
+//   A1  fully_fused_projection    gsplat 1.0.0 (call site dn_model.py:495; math SURVEY.md A.2)
+//   A2a tile count                gsplat isect_tiles pass 1
+//   A5  spherical harmonics       gsplat spherical_harmonics + clamp_min(c+0.5,0)
+//   A7  per-Gaussian normals      dn_model.py:543-560
+//   A10 projection backward       SURVEY.md A.8
+//
+// THIS FILE IS COMPILED WITH -ffp-contract=off.  The integer products of this stage (radii,
+// tiles_per_gauss, and the depth bits that order the tile lists) must be bit-identical to the CPU
+// oracle, so the geometry is evaluated with IEEE +,-,*,/,sqrt in the very order
+// oracle/oracle_impl.inc spells out, without FMA contraction.  The kernel is bandwidth-trivial
+// (one thread per Gaussian, ~0.3 KB each way), so nothing is lost.
+//
+// Mapping: one lane per Gaussian, 256-thread workgroups (4 waves).  Camera constants are read
+// through wave-uniform pointers, i.e. they live in SGPRs.
+
+#include "splat_common.h"
+
+namespace {
+
+struct Cam {
+    float Rv[9], t[3];
+    float fx, fy, cx, cy;
+    float pos[3];  // camera centre in world = -Rv^T t
+};
+
+__device__ __forceinline__ Cam load_cam(const float *__restrict__ vm, const float *__restrict__ K)
+{
+    Cam c;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c.Rv[3 * i + j] = vm[4 * i + j];
+        c.t[i] = vm[4 * i + 3];
+    }
+    c.fx = K[0]; c.fy = K[4]; c.cx = K[2]; c.cy = K[5];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        c.pos[i] = -(c.Rv[0 + i] * c.t[0] + c.Rv[3 + i] * c.t[1] + c.Rv[6 + i] * c.t[2]);
+    return c;
+}
+
+struct Proj {
+    float Rq[9], qn[4], inv_norm;
+    float M[9];
+    float mean_c[3], covar_c[9];
+    float rz, rz2, tx, ty;
+    bool x_in, y_in;
+    float J[6];
+    float cov2d[3], cov2d_blur[3], det_orig, det_blur;
+    float conic[3], compensation, mean2d[2], radius;
+};
+
+__device__ __forceinline__ void quat_to_rotmat(const float *q, float *R, float *qn, float &inv)
+{
+    float w = q[0], x = q[1], y = q[2], z = q[3];
+    float s = x * x + y * y + z * z + w * w;
+    inv = 1.f / sqrtf(s);
+    w *= inv; x *= inv; y *= inv; z *= inv;
+    float x2 = x * x, y2 = y * y, z2 = z * z;
+    float xy = x * y, xz = x * z, yz = y * z;
+    float wx = w * x, wy = w * y, wz = w * z;
+    R[0] = 1.f - 2.f * (y2 + z2);
+    R[1] = 2.f * (xy - wz);
+    R[2] = 2.f * (xz + wy);
+    R[3] = 2.f * (xy + wz);
+    R[4] = 1.f - 2.f * (x2 + z2);
+    R[5] = 2.f * (yz - wx);
+    R[6] = 2.f * (xz - wy);
+    R[7] = 2.f * (yz + wx);
+    R[8] = 1.f - 2.f * (x2 + y2);
+    qn[0] = w; qn[1] = x; qn[2] = y; qn[3] = z;
+}
+
+__device__ __forceinline__ void mm3(const float *A, const float *B, float *C)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            C[3 * i + j] = A[3 * i + 0] * B[0 + j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+__device__ __forceinline__ void mm3_abt(const float *A, const float *B, float *C)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            C[3 * i + j] = A[3 * i + 0] * B[3 * j + 0] + A[3 * i + 1] * B[3 * j + 1] + A[3 * i + 2] * B[3 * j + 2];
+}
+__device__ __forceinline__ void mm3_atb(const float *A, const float *B, float *C)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            C[3 * i + j] = A[0 + i] * B[0 + j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+
+// SURVEY.md A.2 steps 1-6; same expression tree as oracle project_one().
+__device__ __forceinline__ bool project_one(const float *mean, const float *quat, const float *scale, const Cam &c,
+                                            int W, int H, float eps2d, float near_plane, float far_plane,
+                                            float radius_clip, Proj &st)
+{
+    st.radius = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        st.mean_c[i] = c.Rv[3 * i + 0] * mean[0] + c.Rv[3 * i + 1] * mean[1] + c.Rv[3 * i + 2] * mean[2] + c.t[i];
+    if (st.mean_c[2] < near_plane || st.mean_c[2] > far_plane) return false;
+
+    quat_to_rotmat(quat, st.Rq, st.qn, st.inv_norm);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) st.M[3 * i + j] = st.Rq[3 * i + j] * scale[j];
+    float covar[9], tmp[9];
+    mm3_abt(st.M, st.M, covar);
+    mm3(c.Rv, covar, tmp);
+    mm3_abt(tmp, c.Rv, st.covar_c);
+
+    float x = st.mean_c[0], y = st.mean_c[1], z = st.mean_c[2];
+    float tan_fovx = 0.5f * (float)W / c.fx;
+    float tan_fovy = 0.5f * (float)H / c.fy;
+    float lim_x = (float)DNS_FOV_CLAMP * tan_fovx;
+    float lim_y = (float)DNS_FOV_CLAMP * tan_fovy;
+    float rz = 1.f / z;
+    float rz2 = rz * rz;
+    float xz = x * rz, yz = y * rz;
+    st.x_in = (xz <= lim_x && xz >= -lim_x);
+    st.y_in = (yz <= lim_y && yz >= -lim_y);
+    float tx = z * fminf(lim_x, fmaxf(-lim_x, xz));
+    float ty = z * fminf(lim_y, fmaxf(-lim_y, yz));
+    st.rz = rz; st.rz2 = rz2; st.tx = tx; st.ty = ty;
+    float *J = st.J;
+    J[0] = c.fx * rz; J[1] = 0.f; J[2] = -c.fx * tx * rz2;
+    J[3] = 0.f; J[4] = c.fy * rz; J[5] = -c.fy * ty * rz2;
+    const float *Cc = st.covar_c;
+    float JC[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        JC[j] = J[0] * Cc[0 + j] + J[2] * Cc[6 + j];
+        JC[3 + j] = J[4] * Cc[3 + j] + J[5] * Cc[6 + j];
+    }
+    st.cov2d[0] = JC[0] * J[0] + JC[2] * J[2];
+    st.cov2d[1] = JC[1] * J[4] + JC[2] * J[5];
+    st.cov2d[2] = JC[4] * J[4] + JC[5] * J[5];
+    st.mean2d[0] = c.fx * x * rz + c.cx;
+    st.mean2d[1] = c.fy * y * rz + c.cy;
+
+    st.det_orig = st.cov2d[0] * st.cov2d[2] - st.cov2d[1] * st.cov2d[1];
+    st.cov2d_blur[0] = st.cov2d[0] + eps2d;
+    st.cov2d_blur[1] = st.cov2d[1];
+    st.cov2d_blur[2] = st.cov2d[2] + eps2d;
+    st.det_blur = st.cov2d_blur[0] * st.cov2d_blur[2] - st.cov2d_blur[1] * st.cov2d_blur[1];
+    st.compensation = sqrtf(fmaxf(0.f, st.det_orig / st.det_blur));
+    if (st.det_blur <= 0.f) return false;
+
+    float inv_det = 1.f / st.det_blur;
+    st.conic[0] = st.cov2d_blur[2] * inv_det;
+    st.conic[1] = -st.cov2d_blur[1] * inv_det;
+    st.conic[2] = st.cov2d_blur[0] * inv_det;
+
+    float b = 0.5f * (st.cov2d_blur[0] + st.cov2d_blur[2]);
+    float v1 = b + sqrtf(fmaxf((float)DNS_RADIUS_DISC_FLOOR, b * b - st.det_blur));
+    float radius = ceilf((float)DNS_RADIUS_SIGMAS * sqrtf(v1));
+    if (radius <= radius_clip) return false;
+    if (st.mean2d[0] + radius <= 0.f || st.mean2d[0] - radius >= (float)W ||
+        st.mean2d[1] + radius <= 0.f || st.mean2d[1] - radius >= (float)H)
+        return false;
+    st.radius = radius;
+    return true;
+}
+
+// SURVEY.md A.5 real SH basis (Sloan "fast" form), degree <= 3.
+__device__ __forceinline__ void sh_basis(int degree, float x, float y, float z, float *bas)
+{
+    bas[0] = 0.2820947917738781f;
+    if (degree < 1) return;
+    bas[1] = -0.48860251190292f * y;
+    bas[2] = 0.48860251190292f * z;
+    bas[3] = -0.48860251190292f * x;
+    if (degree < 2) return;
+    float z2 = z * z;
+    float fTmp0B = -1.092548430592079f * z;
+    float fC1 = x * x - y * y;
+    float fS1 = 2.f * x * y;
+    bas[4] = 0.5462742152960395f * fS1;
+    bas[5] = fTmp0B * y;
+    bas[6] = 0.9461746957575601f * z2 - 0.3153915652525201f;
+    bas[7] = fTmp0B * x;
+    bas[8] = 0.5462742152960395f * fC1;
+    if (degree < 3) return;
+    float fTmp0C = -2.285228997322329f * z2 + 0.4570457994644658f;
+    float fTmp1B = 1.445305721320277f * z;
+    float fC2 = x * fC1 - y * fS1;
+    float fS2 = x * fS1 + y * fC1;
+    bas[9] = -0.5900435899266435f * fS2;
+    bas[10] = fTmp1B * fS1;
+    bas[11] = fTmp0C * y;
+    bas[12] = z * (1.865881662950577f * z2 - 1.119528997770346f);
+    bas[13] = fTmp0C * x;
+    bas[14] = fTmp1B * fC1;
+    bas[15] = -0.5900435899266435f * fC2;
+}
+
+__device__ __forceinline__ void sh_basis_grad(int degree, float x, float y, float z, float *dx, float *dy, float *dz)
+{
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dx[k] = dy[k] = dz[k] = 0.f;
+    if (degree < 1) return;
+    dy[1] = -0.48860251190292f;
+    dz[2] = 0.48860251190292f;
+    dx[3] = -0.48860251190292f;
+    if (degree < 2) return;
+    const float c2 = 0.5462742152960395f, c1 = 1.092548430592079f, c0 = 0.9461746957575601f;
+    dx[4] = c2 * 2.f * y; dy[4] = c2 * 2.f * x;
+    dy[5] = -c1 * z;      dz[5] = -c1 * y;
+    dz[6] = 2.f * c0 * z;
+    dx[7] = -c1 * z;      dz[7] = -c1 * x;
+    dx[8] = c2 * 2.f * x; dy[8] = -c2 * 2.f * y;
+    if (degree < 3) return;
+    float z2 = z * z;
+    float fC1 = x * x - y * y, fS1 = 2.f * x * y;
+    float fTmp0C = -2.285228997322329f * z2 + 0.4570457994644658f;
+    float fTmp1B = 1.445305721320277f * z;
+    const float c3 = 0.5900435899266435f;
+    float dS2dx = 6.f * x * y, dS2dy = 3.f * x * x - 3.f * y * y;
+    float dC2dx = 3.f * x * x - 3.f * y * y, dC2dy = -6.f * x * y;
+    dx[9] = -c3 * dS2dx; dy[9] = -c3 * dS2dy;
+    dx[10] = fTmp1B * 2.f * y; dy[10] = fTmp1B * 2.f * x; dz[10] = 1.445305721320277f * fS1;
+    dy[11] = fTmp0C; dz[11] = -2.f * 2.285228997322329f * z * y;
+    dz[12] = 3.f * 1.865881662950577f * z2 - 1.119528997770346f;
+    dx[13] = fTmp0C; dz[13] = -2.f * 2.285228997322329f * z * x;
+    dx[14] = fTmp1B * 2.f * x; dy[14] = -fTmp1B * 2.f * y; dz[14] = 1.445305721320277f * fC1;
+    dx[15] = -c3 * dC2dx; dy[15] = -c3 * dC2dy;
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+// dn_model.py:543-556: normal = +-R(q) e_argmin(scales), facing the camera.  Returns the world
+// normal in n[], the axis in k, the column norm and the flip sign.
+__device__ __forceinline__ void gaussian_normal(const float *Rq, const float *scale_raw, const float *mean,
+                                                const float *campos, float *n, int &k, float &nrm, float &sgn)
+{
+    k = 0;
+    float m = scale_raw[0];
+    if (scale_raw[1] < m) { m = scale_raw[1]; k = 1; }
+    if (scale_raw[2] < m) { m = scale_raw[2]; k = 2; }
+    float c0 = Rq[0 + k], c1 = Rq[3 + k], c2 = Rq[6 + k];
+    nrm = fmaxf(sqrtf(c0 * c0 + c1 * c1 + c2 * c2), 1e-12f);
+    n[0] = c0 / nrm; n[1] = c1 / nrm; n[2] = c2 / nrm;
+    float vx = campos[0] - mean[0], vy = campos[1] - mean[1], vz = campos[2] - mean[2];
+    float dot = n[0] * vx + n[1] * vy + n[2] * vz;
+    sgn = (dot < 0.f) ? -1.f : 1.f;
+    n[0] *= sgn; n[1] *= sgn; n[2] *= sgn;
+}
+
+struct FwdParams {
+    dnsplat_scene s;
+    dnsplat_camera c;
+    dnsplat_proj_out o;
+};
+
+__global__ __launch_bounds__(256) void project_fwd_kernel(FwdParams p)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.s.N) return;
+    const Cam cam = load_cam(p.c.viewmat, p.c.K);
+
+    float mean[3], quat[4], sc_raw[3], sc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) mean[i] = p.s.means[3 * g + i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) quat[i] = p.s.quats[4 * g + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        sc_raw[i] = p.s.scales[3 * g + i];
+        sc[i] = p.s.scales_are_log ? expf(sc_raw[i]) : sc_raw[i];
+    }
+    float opac = p.s.opacities[g];
+    if (p.s.opacities_are_logit) opac = sigmoidf(opac);
+
+    Proj st;
+    const bool ok = project_one(mean, quat, sc, cam, p.c.width, p.c.height, p.c.eps2d, p.c.near_plane,
+                                p.c.far_plane, p.c.radius_clip, st);
+
+    float *rec = p.o.splats + (size_t)g * DNS_REC;
+    float4 *rec4 = reinterpret_cast<float4 *>(rec);
+    if (!ok) {
+        p.o.radii[g] = 0;
+        p.o.means2d[2 * g] = 0.f; p.o.means2d[2 * g + 1] = 0.f;
+        p.o.depths[g] = 0.f;
+        p.o.conics[3 * g] = 0.f; p.o.conics[3 * g + 1] = 0.f; p.o.conics[3 * g + 2] = 0.f;
+        if (p.o.compensations) p.o.compensations[g] = 0.f;
+        p.o.tiles_per_gauss[g] = 0;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        rec4[0] = z4; rec4[1] = z4; rec4[2] = z4; rec4[3] = z4;
+        if (p.o.normals_world) {
+            // the reference computes the normal for every Gaussian, visible or not (dn_model.py:544-558)
+            float Rq[9], qn[4], inv, n[3], nrm, sgn; int k;
+            quat_to_rotmat(quat, Rq, qn, inv);
+            const float *np = p.c.normal_frame ? p.c.normal_frame + 9 : cam.pos;
+            float campos[3] = {np[0], np[1], np[2]};
+            gaussian_normal(Rq, sc_raw, mean, campos, n, k, nrm, sgn);
+            p.o.normals_world[3 * g] = n[0]; p.o.normals_world[3 * g + 1] = n[1]; p.o.normals_world[3 * g + 2] = n[2];
+        }
+        return;
+    }
+
+    const int tw = (p.c.width + p.c.tile_size - 1) / p.c.tile_size;
+    const int th = (p.c.height + p.c.tile_size - 1) / p.c.tile_size;
+    int x0, y0, x1, y1;
+    dns_tile_bbox(st.mean2d[0], st.mean2d[1], st.radius, p.c.tile_size, tw, th, x0, y0, x1, y1);
+
+    p.o.radii[g] = (int32_t)st.radius;
+    p.o.means2d[2 * g] = st.mean2d[0]; p.o.means2d[2 * g + 1] = st.mean2d[1];
+    p.o.depths[g] = st.mean_c[2];
+    p.o.conics[3 * g] = st.conic[0]; p.o.conics[3 * g + 1] = st.conic[1]; p.o.conics[3 * g + 2] = st.conic[2];
+    if (p.o.compensations) p.o.compensations[g] = st.compensation;
+    p.o.tiles_per_gauss[g] = (y1 - y0) * (x1 - x0);
+    if (p.c.antialiased) opac *= st.compensation;
+
+    float r[DNS_REC];
+#pragma unroll
+    for (int i = 0; i < DNS_REC; ++i) r[i] = 0.f;
+    r[REC_X] = st.mean2d[0]; r[REC_Y] = st.mean2d[1];
+    r[REC_CA] = st.conic[0]; r[REC_CB] = st.conic[1]; r[REC_CC] = st.conic[2];
+    r[REC_OPAC] = opac;
+    int ch = 0;
+    if (p.s.sh_degree >= 0) {
+        float dx = mean[0] - cam.pos[0], dy = mean[1] - cam.pos[1], dz = mean[2] - cam.pos[2];
+        float inorm = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+        dx *= inorm; dy *= inorm; dz *= inorm;
+        float bas[16];
+        sh_basis(p.s.sh_degree, dx, dy, dz, bas);
+        const float *c0 = p.s.sh0 + (size_t)g * p.s.sh0_stride;
+        float col[3] = {bas[0] * c0[0], bas[0] * c0[1], bas[0] * c0[2]};
+        const int nb = (p.s.sh_degree + 1) * (p.s.sh_degree + 1);
+        const float *cN = p.s.shN + (size_t)g * p.s.shN_stride;
+        for (int k = 1; k < nb; ++k) {
+            col[0] += bas[k] * cN[3 * (k - 1) + 0];
+            col[1] += bas[k] * cN[3 * (k - 1) + 1];
+            col[2] += bas[k] * cN[3 * (k - 1) + 2];
+        }
+        r[REC_CH0 + 0] = fmaxf(col[0] + 0.5f, 0.f);
+        r[REC_CH0 + 1] = fmaxf(col[1] + 0.5f, 0.f);
+        r[REC_CH0 + 2] = fmaxf(col[2] + 0.5f, 0.f);
+        ch = 3;
+    } else {
+        for (int k = 0; k < p.s.n_colors; ++k) r[REC_CH0 + k] = p.s.colors[(size_t)g * p.s.n_colors + k];
+        ch = p.s.n_colors;
+    }
+    if (p.o.with_depth_channel) { r[REC_CH0 + ch] = st.mean_c[2]; ch += 1; }
+    if (p.o.with_normal_channels || p.o.normals_world) {
+        const float *np = p.c.normal_frame ? p.c.normal_frame + 9 : cam.pos;
+        float campos[3] = {np[0], np[1], np[2]};
+        float n[3], nrm, sgn; int k;
+        gaussian_normal(st.Rq, sc_raw, mean, campos, n, k, nrm, sgn);
+        if (p.o.normals_world) {
+            p.o.normals_world[3 * g] = n[0]; p.o.normals_world[3 * g + 1] = n[1]; p.o.normals_world[3 * g + 2] = n[2];
+        }
+        if (p.o.with_normal_channels) {
+            const float *Mn = p.c.normal_frame;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                r[REC_CH0 + ch + i] = Mn[3 * i + 0] * n[0] + Mn[3 * i + 1] * n[1] + Mn[3 * i + 2] * n[2];
+        }
+    }
+    rec4[0] = make_float4(r[0], r[1], r[2], r[3]);
+    rec4[1] = make_float4(r[4], r[5], r[6], r[7]);
+    rec4[2] = make_float4(r[8], r[9], r[10], r[11]);
+    rec4[3] = make_float4(r[12], r[13], r[14], r[15]);
+}
+
+struct BwdParams {
+    dnsplat_scene s;
+    dnsplat_camera c;
+    dnsplat_proj_out o;
+    dnsplat_proj_grads g;
+};
+
+__global__ __launch_bounds__(256) void project_bwd_kernel(BwdParams p)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.s.N) return;
+    const int nbK = (p.s.sh_degree >= 0) ? (p.s.sh_degree + 1) * (p.s.sh_degree + 1) : 0;
+
+    float v_mean[3] = {0.f, 0.f, 0.f}, v_quat[4] = {0.f, 0.f, 0.f, 0.f}, v_scale[3] = {0.f, 0.f, 0.f}, v_opac = 0.f;
+    const bool visible = p.g.radii[g] > 0;
+
+    // Gradient rows of culled Gaussians are zero; SH rows beyond the active degree are zero too.
+    float *vsh0 = p.g.v_sh0 ? p.g.v_sh0 + (size_t)g * p.g.v_sh0_stride : nullptr;
+    float *vshN = p.g.v_shN ? p.g.v_shN + (size_t)g * p.g.v_shN_stride : nullptr;
+    const int restK = (p.g.v_shN && p.s.sh_K > 1) ? p.s.sh_K - 1 : 0;  // higher-band bases stored per Gaussian
+
+    Cam cam;
+    Proj st;
+    float mean[3], quat[4], sc_raw[3], sc[3];
+    bool ok = false;
+    if (visible) {
+        cam = load_cam(p.c.viewmat, p.c.K);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) mean[i] = p.s.means[3 * g + i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) quat[i] = p.s.quats[4 * g + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            sc_raw[i] = p.s.scales[3 * g + i];
+            sc[i] = p.s.scales_are_log ? expf(sc_raw[i]) : sc_raw[i];
+        }
+        ok = project_one(mean, quat, sc, cam, p.c.width, p.c.height, p.c.eps2d, p.c.near_plane, p.c.far_plane,
+                         p.c.radius_clip, st);
+    }
+
+    if (!ok) {
+        if (vsh0) { vsh0[0] = 0.f; vsh0[1] = 0.f; vsh0[2] = 0.f; }
+        if (vshN) for (int k = 0; k < 3 * restK; ++k) vshN[k] = 0.f;
+        if (p.g.v_colors) for (int k = 0; k < p.s.n_colors; ++k) p.g.v_colors[(size_t)g * p.s.n_colors + k] = 0.f;
+    } else {
+        const float4 *vr4 = reinterpret_cast<const float4 *>(p.g.v_splats + (size_t)g * DNS_REC);
+        float vr[DNS_REC];
+        {
+            float4 a = vr4[0], b = vr4[1], c = vr4[2], d = vr4[3];
+            vr[0] = a.x; vr[1] = a.y; vr[2] = a.z; vr[3] = a.w;
+            vr[4] = b.x; vr[5] = b.y; vr[6] = b.z; vr[7] = b.w;
+            vr[8] = c.x; vr[9] = c.y; vr[10] = c.z; vr[11] = c.w;
+            vr[12] = d.x; vr[13] = d.y; vr[14] = d.z; vr[15] = d.w;
+        }
+        float vx2 = vr[REC_X], vy2 = vr[REC_Y];
+        if (p.g.v_means2d) { vx2 = p.g.v_means2d[2 * g]; vy2 = p.g.v_means2d[2 * g + 1]; }
+        float vc[3] = {vr[REC_CA], vr[REC_CB], vr[REC_CC]};
+        if (p.g.v_conics) { vc[0] += p.g.v_conics[3 * g]; vc[1] += p.g.v_conics[3 * g + 1]; vc[2] += p.g.v_conics[3 * g + 2]; }
+        float v_depth = p.g.v_depths ? p.g.v_depths[g] : 0.f;
+        float v_comp = p.g.v_compensations ? p.g.v_compensations[g] : 0.f;
+
+        // ---- opacity (A0 / antialiasing)
+        float opac_in = p.s.opacities[g];
+        float opac_act = p.s.opacities_are_logit ? sigmoidf(opac_in) : opac_in;
+        float v_o = vr[REC_OPAC];
+        if (p.c.antialiased) { v_comp += v_o * opac_act; v_o *= st.compensation; }
+        v_opac = p.s.opacities_are_logit ? v_o * opac_act * (1.f - opac_act) : v_o;
+
+        // ---- feature channels
+        int ch = 0;
+        float v_R[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) v_R[i] = 0.f;
+        if (p.s.sh_degree >= 0) {
+            float dx = mean[0] - cam.pos[0], dy = mean[1] - cam.pos[1], dz = mean[2] - cam.pos[2];
+            float inorm = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+            dx *= inorm; dy *= inorm; dz *= inorm;
+            float bas[16];
+            sh_basis(p.s.sh_degree, dx, dy, dz, bas);
+            const float *c0 = p.s.sh0 + (size_t)g * p.s.sh0_stride;
+            const float *cN = p.s.shN + (size_t)g * p.s.shN_stride;
+            float col[3] = {bas[0] * c0[0], bas[0] * c0[1], bas[0] * c0[2]};
+            for (int k = 1; k < nbK; ++k) {
+                col[0] += bas[k] * cN[3 * (k - 1) + 0];
+                col[1] += bas[k] * cN[3 * (k - 1) + 1];
+                col[2] += bas[k] * cN[3 * (k - 1) + 2];
+            }
+            // clamp_min(c + 0.5, 0): gradient passes where c + 0.5 >= 0
+            float vcol[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) vcol[i] = (col[i] + 0.5f >= 0.f) ? vr[REC_CH0 + i] : 0.f;
+            if (vsh0) { vsh0[0] = bas[0] * vcol[0]; vsh0[1] = bas[0] * vcol[1]; vsh0[2] = bas[0] * vcol[2]; }
+            if (vshN) {
+                for (int k = 1; k < nbK; ++k) {
+                    vshN[3 * (k - 1) + 0] = bas[k] * vcol[0];
+                    vshN[3 * (k - 1) + 1] = bas[k] * vcol[1];
+                    vshN[3 * (k - 1) + 2] = bas[k] * vcol[2];
+                }
+                for (int k = 3 * (nbK - 1); k < 3 * restK; ++k) vshN[k] = 0.f;
+            }
+            if (p.s.sh_degree >= 1) {
+                float bx[16], by[16], bz[16];
+                sh_basis_grad(p.s.sh_degree, dx, dy, dz, bx, by, bz);
+                float vdn[3] = {0.f, 0.f, 0.f};
+                for (int k = 1; k < nbK; ++k) {
+                    float s = cN[3 * (k - 1)] * vcol[0] + cN[3 * (k - 1) + 1] * vcol[1] + cN[3 * (k - 1) + 2] * vcol[2];
+                    vdn[0] += bx[k] * s; vdn[1] += by[k] * s; vdn[2] += bz[k] * s;
+                }
+                float dot = vdn[0] * dx + vdn[1] * dy + vdn[2] * dz;
+                v_mean[0] += (vdn[0] - dot * dx) * inorm;
+                v_mean[1] += (vdn[1] - dot * dy) * inorm;
+                v_mean[2] += (vdn[2] - dot * dz) * inorm;
+            }
+            ch = 3;
+        } else {
+            if (p.g.v_colors)
+                for (int k = 0; k < p.s.n_colors; ++k) p.g.v_colors[(size_t)g * p.s.n_colors + k] = vr[REC_CH0 + k];
+            ch = p.s.n_colors;
+        }
+        if (p.o.with_depth_channel) { v_depth += vr[REC_CH0 + ch]; ch += 1; }
+        if (p.o.with_normal_channels) {
+            // n_cam = Mn * (sgn * col/|col|), col = Rq[:,k]  ->  only the quaternion receives gradient
+            const float *Mn = p.c.normal_frame;
+            float campos[3] = {Mn[9], Mn[10], Mn[11]};
+            float n[3], nrm, sgn; int k;
+            gaussian_normal(st.Rq, sc_raw, mean, campos, n, k, nrm, sgn);
+            float vn[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                vn[i] = sgn * (Mn[0 + i] * vr[REC_CH0 + ch] + Mn[3 + i] * vr[REC_CH0 + ch + 1] + Mn[6 + i] * vr[REC_CH0 + ch + 2]);
+            float u[3] = {n[0] * sgn, n[1] * sgn, n[2] * sgn};
+            float d = u[0] * vn[0] + u[1] * vn[1] + u[2] * vn[2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v_R[3 * i + k] += (vn[i] - u[i] * d) / nrm;
+        }
+
+        // ---- conic -> cov2d (A.8)
+        float a = st.conic[0], b = st.conic[1], c = st.conic[2];
+        float ga = vc[0], gb = 0.5f * vc[1], gc = vc[2];
+        float t00 = a * ga + b * gb, t01 = a * gb + b * gc;
+        float t10 = b * ga + c * gb, t11 = b * gb + c * gc;
+        float G2[4];
+        G2[0] = -(t00 * a + t01 * b);
+        G2[1] = -(t00 * b + t01 * c);
+        G2[2] = -(t10 * a + t11 * b);
+        G2[3] = -(t10 * b + t11 * c);
+        if (v_comp != 0.f && st.compensation > 0.f) {
+            float comp = st.compensation;
+            float inv_db = 1.f / st.det_blur;
+            float kk = v_comp * 0.5f / comp;
+            float one_minus = 1.f - comp * comp;
+            float d00 = (st.cov2d[2] - comp * comp * st.cov2d_blur[2]) * inv_db;
+            float d11 = (st.cov2d[0] - comp * comp * st.cov2d_blur[0]) * inv_db;
+            float d01 = (-2.f * st.cov2d[1] * one_minus) * inv_db;
+            G2[0] += kk * d00; G2[3] += kk * d11;
+            G2[1] += 0.5f * kk * d01; G2[2] += 0.5f * kk * d01;
+        }
+        const float *J = st.J; const float *Cc = st.covar_c;
+        float GJ[6], GtJ[6];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            GJ[j] = G2[0] * J[j] + G2[1] * J[3 + j];
+            GJ[3 + j] = G2[2] * J[j] + G2[3] * J[3 + j];
+            GtJ[j] = G2[0] * J[j] + G2[2] * J[3 + j];
+            GtJ[3 + j] = G2[1] * J[j] + G2[3] * J[3 + j];
+        }
+        float v_Cc[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v_Cc[3 * i + j] = J[i] * GJ[j] + J[3 + i] * GJ[3 + j];
+        float v_J[6];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    s1 += GJ[3 * r + k] * Cc[3 * j + k];
+                    s2 += GtJ[3 * r + k] * Cc[3 * k + j];
+                }
+                v_J[3 * r + j] = s1 + s2;
+            }
+        float fx = cam.fx, fy = cam.fy, rz = st.rz, rz2 = st.rz2, rz3 = st.rz2 * st.rz;
+        float x = st.mean_c[0], y = st.mean_c[1];
+        float v_mc[3];
+        v_mc[0] = fx * rz * vx2;
+        v_mc[1] = fy * rz * vy2;
+        v_mc[2] = -(fx * x * vx2 + fy * y * vy2) * rz2;
+        if (st.x_in) v_mc[0] += -fx * rz2 * v_J[2];
+        else v_mc[2] += -fx * rz3 * v_J[2] * st.tx;
+        if (st.y_in) v_mc[1] += -fy * rz2 * v_J[5];
+        else v_mc[2] += -fy * rz3 * v_J[5] * st.ty;
+        v_mc[2] += -fx * rz2 * v_J[0] - fy * rz2 * v_J[4] + 2.f * fx * st.tx * rz3 * v_J[2] + 2.f * fy * st.ty * rz3 * v_J[5];
+        v_mc[2] += v_depth;
+
+        const float *Rv = cam.Rv;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v_mean[i] += Rv[0 + i] * v_mc[0] + Rv[3 + i] * v_mc[1] + Rv[6 + i] * v_mc[2];
+        float tmp[9], v_cov[9];
+        mm3_atb(Rv, v_Cc, tmp);
+        mm3(tmp, Rv, v_cov);
+        float sym[9], v_M[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) sym[3 * i + j] = v_cov[3 * i + j] + v_cov[3 * j + i];
+        mm3(sym, st.M, v_M);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v_R[3 * i + j] += v_M[3 * i + j] * sc[j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float vs = st.Rq[0 + j] * v_M[0 + j] + st.Rq[3 + j] * v_M[3 + j] + st.Rq[6 + j] * v_M[6 + j];
+            v_scale[j] = p.s.scales_are_log ? vs * sc[j] : vs;
+        }
+        float w = st.qn[0], qx = st.qn[1], qy = st.qn[2], qz = st.qn[3];
+        float vqn[4];
+        vqn[0] = 2.f * (qx * (v_R[7] - v_R[5]) + qy * (v_R[2] - v_R[6]) + qz * (v_R[3] - v_R[1]));
+        vqn[1] = 2.f * (-2.f * qx * (v_R[4] + v_R[8]) + qy * (v_R[3] + v_R[1]) + qz * (v_R[6] + v_R[2]) + w * (v_R[7] - v_R[5]));
+        vqn[2] = 2.f * (qx * (v_R[3] + v_R[1]) - 2.f * qy * (v_R[0] + v_R[8]) + qz * (v_R[7] + v_R[5]) + w * (v_R[2] - v_R[6]));
+        vqn[3] = 2.f * (qx * (v_R[6] + v_R[2]) + qy * (v_R[7] + v_R[5]) - 2.f * qz * (v_R[0] + v_R[4]) + w * (v_R[3] - v_R[1]));
+        float dot = vqn[0] * w + vqn[1] * qx + vqn[2] * qy + vqn[3] * qz;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v_quat[i] = (vqn[i] - dot * st.qn[i]) * st.inv_norm;
+    }
+
+    p.g.v_means[3 * g] = v_mean[0]; p.g.v_means[3 * g + 1] = v_mean[1]; p.g.v_means[3 * g + 2] = v_mean[2];
+    p.g.v_quats[4 * g] = v_quat[0]; p.g.v_quats[4 * g + 1] = v_quat[1]; p.g.v_quats[4 * g + 2] = v_quat[2]; p.g.v_quats[4 * g + 3] = v_quat[3];
+    p.g.v_scales[3 * g] = v_scale[0]; p.g.v_scales[3 * g + 1] = v_scale[1]; p.g.v_scales[3 * g + 2] = v_scale[2];
+    p.g.v_opacities[g] = v_opac;
+}
+
+__global__ __launch_bounds__(256) void pack_splats_kernel(int N, const float *__restrict__ means2d,
+                                                          const float *__restrict__ conics,
+                                                          const float *__restrict__ opacities,
+                                                          const float *__restrict__ colors, int C,
+                                                          float *__restrict__ splats)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    float r[DNS_REC];
+#pragma unroll
+    for (int i = 0; i < DNS_REC; ++i) r[i] = 0.f;
+    r[REC_X] = means2d[2 * g]; r[REC_Y] = means2d[2 * g + 1];
+    r[REC_CA] = conics[3 * g]; r[REC_CB] = conics[3 * g + 1]; r[REC_CC] = conics[3 * g + 2];
+    r[REC_OPAC] = opacities[g];
+    for (int k = 0; k < C; ++k) r[REC_CH0 + k] = colors[(size_t)g * C + k];
+    float4 *rec4 = reinterpret_cast<float4 *>(splats + (size_t)g * DNS_REC);
+    rec4[0] = make_float4(r[0], r[1], r[2], r[3]);
+    rec4[1] = make_float4(r[4], r[5], r[6], r[7]);
+    rec4[2] = make_float4(r[8], r[9], r[10], r[11]);
+    rec4[3] = make_float4(r[12], r[13], r[14], r[15]);
+}
+
+}  // namespace
+
+static int check_scene(const dnsplat_scene *s, const dnsplat_camera *c, const dnsplat_proj_out *o)
+{
+    if (!s || !c || !o) return DNSPLAT_ERR_INVALID_ARG;
+    if (s->N < 0) return DNSPLAT_ERR_INVALID_ARG;
+    if (s->N == 0) return DNSPLAT_OK;
+    if (!s->means || !s->quats || !s->scales || !s->opacities) return DNSPLAT_ERR_INVALID_ARG;
+    if (!c->viewmat || !c->K || c->width <= 0 || c->height <= 0 || c->tile_size <= 0) return DNSPLAT_ERR_INVALID_ARG;
+    if (s->sh_degree > 3) return DNSPLAT_ERR_UNSUPPORTED;
+    int ch;
+    if (s->sh_degree >= 0) {
+        if (!s->sh0 || (s->sh_degree > 0 && !s->shN)) return DNSPLAT_ERR_INVALID_ARG;
+        if (s->sh_K < (s->sh_degree + 1) * (s->sh_degree + 1)) return DNSPLAT_ERR_INVALID_ARG;
+        ch = 3;
+    } else {
+        if (s->n_colors < 0 || (s->n_colors > 0 && !s->colors)) return DNSPLAT_ERR_INVALID_ARG;
+        ch = s->n_colors;
+    }
+    ch += (o->with_depth_channel ? 1 : 0) + (o->with_normal_channels ? 3 : 0);
+    if (ch > DNSPLAT_MAX_CHANNELS) return DNSPLAT_ERR_UNSUPPORTED;
+    if (o->with_normal_channels && !c->normal_frame) return DNSPLAT_ERR_INVALID_ARG;
+    if (!o->radii || !o->means2d || !o->depths || !o->conics || !o->tiles_per_gauss || !o->splats)
+        return DNSPLAT_ERR_INVALID_ARG;
+    return DNSPLAT_OK;
+}
+
+extern "C" int dnsplat_project_fwd(const dnsplat_scene *scene, const dnsplat_camera *cam,
+                                   const dnsplat_proj_out *out, dnsplat_stream_t stream)
+{
+    int rc = check_scene(scene, cam, out);
+    if (rc != DNSPLAT_OK) return rc;
+    if (scene->N == 0) return DNSPLAT_OK;
+    FwdParams p{*scene, *cam, *out};
+    dim3 block(256), grid((scene->N + 255) / 256);
+    hipLaunchKernelGGL(project_fwd_kernel, grid, block, 0, (hipStream_t)stream, p);
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}
+
+extern "C" int dnsplat_project_bwd(const dnsplat_scene *scene, const dnsplat_camera *cam,
+                                   const dnsplat_proj_out *fwd, const dnsplat_proj_grads *grads,
+                                   dnsplat_stream_t stream)
+{
+    if (!scene || !cam || !fwd || !grads) return DNSPLAT_ERR_INVALID_ARG;
+    if (scene->N == 0) return DNSPLAT_OK;
+    if (!grads->radii || !grads->v_splats || !grads->v_means || !grads->v_quats || !grads->v_scales ||
+        !grads->v_opacities)
+        return DNSPLAT_ERR_INVALID_ARG;
+    if (scene->sh_degree > 3) return DNSPLAT_ERR_UNSUPPORTED;
+    if (fwd->with_normal_channels && !cam->normal_frame) return DNSPLAT_ERR_INVALID_ARG;
+    BwdParams p{*scene, *cam, *fwd, *grads};
+    dim3 block(256), grid((scene->N + 255) / 256);
+    hipLaunchKernelGGL(project_bwd_kernel, grid, block, 0, (hipStream_t)stream, p);
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}
+
+extern "C" int dnsplat_pack_splats(int32_t N, const float *means2d, const float *conics, const float *opacities,
+                                   const float *colors, int32_t C, float *splats, dnsplat_stream_t stream)
+{
+    if (N < 0 || C < 0 || C > DNSPLAT_MAX_CHANNELS) return DNSPLAT_ERR_INVALID_ARG;
+    if (N == 0) return DNSPLAT_OK;
+    if (!means2d || !conics || !opacities || !splats || (C > 0 && !colors)) return DNSPLAT_ERR_INVALID_ARG;
+    dim3 block(256), grid((N + 255) / 256);
+    hipLaunchKernelGGL(pack_splats_kernel, grid, block, 0, (hipStream_t)stream, N, means2d, conics, opacities,
+                       colors, C, splats);
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}

@@ -1,0 +1,277 @@
+// raster_bwd.hip — per-tile alpha compositing, backward (stage 4 of include/dnsplat.h).
+//
+// Replaces gsplat 1.0.0 rasterize_to_pixels_bwd and the legacy rasterize_backward /
+// nd_rasterize_backward (call sites dn_splatter/dn_model.py:495, :564; rule set SURVEY.md A.7).
+//
+// The reference design is pixel-parallel: every thread owns a pixel, walks the tile list back to
+// front, and each of the ~15 per-splat partial gradients is warp-reduced and atomically added once
+// per (warp, splat).  On a 64-wide wave that reduction (15 values x 6-7 DPP steps) costs more than
+// the gradient math itself.  This kernel turns the problem by 90 degrees — a wave64 SYSTOLIC pass:
+//
+//   * one wave owns one 16x16 tile; lane l owns ONE SPLAT of the current 64-splat bucket
+//     (lane 0 = back-most), for the whole pass, and keeps that splat's 16 partial gradients in VGPRs;
+//   * the 256 pixels stream through the lanes, back to front: at step s lane l works on pixel s-l.
+//     What travels with a pixel is only its running state (T, S_a, S_b) — three v_mov_dpp
+//     wave_shr:1 per step — where S = sum_k buffer_k * v_k collapses the reference's per-channel
+//     `buffer` into one scalar per gradient group (v_alpha = T*(c.v) - S/(1-alpha));
+//   * per-pixel constants (upstream gradient, last contributing index) sit in a 12 KiB LDS table,
+//     read with conflict-free ds_read_b128 (48-byte stride over consecutive lanes);
+//   * state leaving lane 63 is parked back in the pixel's LDS row and picked up by lane 0 in the
+//     next (nearer) bucket — the arithmetic order per pixel is exactly the reference's
+//     back-to-front replay (T *= 1/(1-alpha); buffer += c*alpha*T);
+//   * a splat's 16 partials are summed over all 256 pixels in registers: NO cross-lane reduction,
+//     and ONE atomic row per (tile, splat).  The flush is transposed through LDS so that each
+//     global_atomic_add_f32 instruction covers whole 64-byte gradient records (16 lanes per record).
+//
+// Channel groups: channels >= xy_split (the normal channels of the fused pass) are rendered by the
+// reference with xys.detach() (dn_model.py:562), so their share of d/d(alpha) must not reach
+// v_xy / |v_xy| while it does reach v_conic and v_opacity.  Hence two S states.
+
+#include "splat_common.h"
+
+namespace {
+
+constexpr int TILE = 16;
+constexpr int NPIX = TILE * TILE;
+constexpr int PIXREC = 12;  // floats per pixel row in LDS
+
+struct BwdArgs {
+    int width, height, tw, n_tiles;
+    const float4 *__restrict__ splats;
+    const int32_t *__restrict__ flatten_ids;
+    const int32_t *__restrict__ tile_offsets;
+    const float *__restrict__ background;
+    int ed_channel;
+    const float *__restrict__ render;
+    const float *__restrict__ alphas;
+    const int32_t *__restrict__ last_ids;
+    const float *__restrict__ v_render;
+    const float *__restrict__ v_alphas;
+    int xy_split;
+    float *__restrict__ v_splats;
+};
+
+__device__ __forceinline__ float dpp_wave_shr1(float from_prev, float lane0_value)
+{
+    // lane l receives `from_prev` of lane l-1; lane 0 (no source) keeps `lane0_value`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0_value), __float_as_int(from_prev),
+                                                      0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+
+template <int D>
+__global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
+{
+    __shared__ float4 pix[NPIX][PIXREC / 4];   // [p][0..1] = v_k, [p][2] = (T, S_a, S_b, bin_final)
+    __shared__ float4 flush[DNS_WAVE][4];      // gradient rows staged for the transposed flush
+
+    const int tile = dns_xcd_remap(blockIdx.x, a.n_tiles);
+    const int lane = threadIdx.x;
+    const int range_start = a.tile_offsets[tile];
+    const int range_end = a.tile_offsets[tile + 1];
+    if (range_end <= range_start) return;
+    const int tile_x0 = (tile % a.tw) * TILE, tile_y0 = (tile / a.tw) * TILE;
+
+    // ---- prologue: per-pixel table --------------------------------------------------------------
+    int hi = -1;
+#pragma unroll
+    for (int j = 0; j < NPIX / DNS_WAVE; ++j) {
+        const int p = lane + DNS_WAVE * j;
+        const int xi = tile_x0 + (p & 15), yi = tile_y0 + (p >> 4);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        float T_final = 1.f, sa = 0.f, sb = 0.f;
+        int bin_final = -1;
+        if (xi < a.width && yi < a.height) {
+            const size_t pid = (size_t)yi * a.width + xi;
+#pragma unroll
+            for (int k = 0; k < D; ++k) v[k] = a.v_render[pid * D + k];
+            const float al = a.alphas[pid];
+            float va = a.v_alphas ? a.v_alphas[pid] : 0.f;
+            T_final = 1.f - al;
+            bin_final = a.last_ids[pid];
+            if (a.ed_channel >= 0) {
+                // out_ed = acc_ed / max(alpha, 1e-10)
+#pragma unroll
+                for (int k = 0; k < D; ++k)
+                    if (k == a.ed_channel) {
+                        const float inv = 1.f / fmaxf(al, (float)DNS_ED_ALPHA_FLOOR);
+                        const float vd = v[k];
+                        v[k] = vd * inv;
+                        if (al >= (float)DNS_ED_ALPHA_FLOOR) va -= a.render[pid * D + k] * vd * inv;
+                    }
+            }
+            float bga = 0.f, bgb = 0.f;
+            if (a.background) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const float t = a.background[k] * v[k];
+                    if (k < a.xy_split) bga += t; else bgb += t;
+                }
+            }
+            // S starts at -(T_final * d/d(alpha_img) share) so that v_alpha = T*cv - ra*S needs no extra term
+            sa = -T_final * (va - bga);
+            sb = T_final * bgb;
+        }
+        pix[p][0] = make_float4(v[0], v[1], v[2], v[3]);
+        pix[p][1] = make_float4(v[4], v[5], v[6], v[7]);
+        pix[p][2] = make_float4(T_final, sa, sb, __int_as_float(bin_final));
+        hi = max(hi, bin_final);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) hi = max(hi, __shfl_xor(hi, off, DNS_WAVE));
+    hi = min(hi, range_end - 1);
+    if (hi < range_start) return;
+    __builtin_amdgcn_wave_barrier();
+
+    const float fx0 = (float)tile_x0 + 0.5f, fy0 = (float)tile_y0 + 0.5f;
+    const int n_pass = (hi - range_start + DNS_WAVE) / DNS_WAVE;
+
+    for (int pass = 0; pass < n_pass; ++pass) {
+        // ---- this lane's splat for the pass ---------------------------------------------------
+        const int my_idx = hi - pass * DNS_WAVE - lane;
+        const bool has = my_idx >= range_start;
+        int gid = 0;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+        if (has) {
+            gid = a.flatten_ids[my_idx];
+            const float4 *rec = a.splats + (size_t)gid * 4;
+            s0 = rec[0]; s1 = rec[1];
+            if (D > 2) s2 = rec[2];
+            if (D > 6) s3 = rec[3];
+        }
+        const float sx = s0.x, sy = s0.y, ca = s0.z, cb = s0.w, cc = s1.x, opac = s1.y;
+        float ch[8] = {s1.z, s1.w, s2.x, s2.y, s2.z, s2.w, s3.x, s3.y};
+
+        float g_x = 0.f, g_y = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_o = 0.f, g_ax = 0.f, g_ay = 0.f;
+        float g_ch[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g_ch[k] = 0.f;
+        bool touched = false;
+
+        float T_out = 0.f, SA_out = 0.f, SB_out = 0.f;
+        for (int s = 0; s < NPIX + DNS_WAVE - 1; ++s) {
+            const int p = s - lane;
+            const bool active = (unsigned)p < (unsigned)NPIX;
+            const int pc = p & (NPIX - 1);
+            const float4 pv0 = pix[pc][0];
+            const float4 pv1 = pix[pc][1];
+            const float4 pst = pix[pc][2];
+            // state arrives from the previous lane; lane 0 takes it from the pixel's LDS row
+            float T = dpp_wave_shr1(T_out, pst.x);
+            float SA = dpp_wave_shr1(SA_out, pst.y);
+            float SB = dpp_wave_shr1(SB_out, pst.z);
+            const int bin_final = __float_as_int(pst.w);
+
+            const float dx = sx - (fx0 + (float)(pc & 15));
+            const float dy = sy - (fy0 + (float)(pc >> 4));
+            const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+            const float vis = __expf(-sigma);
+            const float ov = opac * vis;
+            const float alpha = fminf((float)DNS_ALPHA_MAX, ov);
+            const bool valid = active && has && my_idx <= bin_final && sigma >= 0.f && alpha >= (float)DNS_ALPHA_MIN;
+            if (valid) {
+                touched = true;
+                const float pvv[8] = {pv0.x, pv0.y, pv0.z, pv0.w, pv1.x, pv1.y, pv1.z, pv1.w};
+                const float ra = 1.f / (1.f - alpha);
+                T *= ra;
+                const float fac = alpha * T;
+                float cva = 0.f, cvb = 0.f;
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    g_ch[k] += fac * pvv[k];
+                    if (k < a.xy_split) cva += ch[k] * pvv[k]; else cvb += ch[k] * pvv[k];
+                }
+                const float va_a = T * cva - ra * SA;
+                const float va_b = T * cvb - ra * SB;
+                if (ov <= (float)DNS_ALPHA_MAX) {
+                    const float va = va_a + va_b;
+                    const float vs = -ov * va;
+                    const float vs_a = -ov * va_a;
+                    g_ca += 0.5f * vs * dx * dx;
+                    g_cb += vs * dx * dy;
+                    g_cc += 0.5f * vs * dy * dy;
+                    const float gx = vs_a * (ca * dx + cb * dy);
+                    const float gy = vs_a * (cb * dx + cc * dy);
+                    g_x += gx; g_y += gy;
+                    g_ax += fabsf(gx); g_ay += fabsf(gy);
+                    g_o += vis * va;
+                }
+                SA += fac * cva;
+                SB += fac * cvb;
+            }
+            T_out = T; SA_out = SA; SB_out = SB;
+            // park the state of the pixel leaving the array for the next (nearer) bucket
+            if (lane == DNS_WAVE - 1 && active) {
+                float4 st = pst;
+                st.x = T; st.y = SA; st.z = SB;
+                pix[pc][2] = st;
+            }
+        }
+
+        // ---- flush: transpose through LDS, one atomic row per touched splat ---------------------
+        flush[lane][0] = make_float4(g_x, g_y, g_ca, g_cb);
+        flush[lane][1] = make_float4(g_cc, g_o, g_ch[0], g_ch[1]);
+        flush[lane][2] = make_float4(g_ch[2], g_ch[3], g_ch[4], g_ch[5]);
+        flush[lane][3] = make_float4(g_ch[6], g_ch[7], g_ax, g_ay);
+        const uint64_t tmask = __ballot(touched);
+        __builtin_amdgcn_wave_barrier();
+        const float *fl = reinterpret_cast<const float *>(&flush[0][0]);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int row = j * 4 + (lane >> 4);
+            const int col = lane & 15;
+            const int rgid = __shfl(gid, row, DNS_WAVE);
+            const float val = fl[j * 64 + lane];
+            if ((tmask >> row) & 1) unsafeAtomicAdd(a.v_splats + (size_t)rgid * DNS_REC + col, val);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int D>
+int launch_bwd(const BwdArgs &ba, hipStream_t stream)
+{
+    hipLaunchKernelGGL(raster_bwd_kernel<D>, dim3(ba.n_tiles), dim3(DNS_WAVE), 0, stream, ba);
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}
+
+}  // namespace
+
+extern "C" int dnsplat_raster_bwd(const dnsplat_raster_args *a, dnsplat_stream_t stream_)
+{
+    if (!a) return DNSPLAT_ERR_INVALID_ARG;
+    if (a->tile_size != TILE) return DNSPLAT_ERR_UNSUPPORTED;
+    if (a->D < 1 || a->D > DNSPLAT_MAX_CHANNELS) return DNSPLAT_ERR_UNSUPPORTED;
+    if (a->width <= 0 || a->height <= 0) return DNSPLAT_ERR_INVALID_ARG;
+    if (!a->splats || !a->tile_offsets || !a->alphas || !a->last_ids || !a->v_render || !a->v_splats)
+        return DNSPLAT_ERR_INVALID_ARG;
+    if (a->ed_channel >= a->D || (a->ed_channel >= 0 && !a->render)) return DNSPLAT_ERR_INVALID_ARG;
+    if (a->xy_split < 0 || a->xy_split > a->D) return DNSPLAT_ERR_INVALID_ARG;
+    BwdArgs ba;
+    ba.width = a->width; ba.height = a->height;
+    ba.tw = dns_tiles_w(a->width, TILE);
+    ba.n_tiles = ba.tw * dns_tiles_h(a->height, TILE);
+    ba.splats = reinterpret_cast<const float4 *>(a->splats);
+    ba.flatten_ids = a->flatten_ids;
+    ba.tile_offsets = a->tile_offsets;
+    ba.background = a->background;
+    ba.ed_channel = a->ed_channel;
+    ba.render = a->render; ba.alphas = a->alphas; ba.last_ids = a->last_ids;
+    ba.v_render = a->v_render; ba.v_alphas = a->v_alphas;
+    ba.xy_split = a->xy_split;
+    ba.v_splats = a->v_splats;
+    hipStream_t stream = (hipStream_t)stream_;
+    switch (a->D) {
+        case 1: return launch_bwd<1>(ba, stream);
+        case 2: return launch_bwd<2>(ba, stream);
+        case 3: return launch_bwd<3>(ba, stream);
+        case 4: return launch_bwd<4>(ba, stream);
+        case 5: return launch_bwd<5>(ba, stream);
+        case 6: return launch_bwd<6>(ba, stream);
+        case 7: return launch_bwd<7>(ba, stream);
+        case 8: return launch_bwd<8>(ba, stream);
+    }
+    return DNSPLAT_ERR_UNSUPPORTED;
+}

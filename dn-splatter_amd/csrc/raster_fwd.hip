@@ -1,0 +1,201 @@
+// raster_fwd.hip — per-tile front-to-back alpha compositing, forward (stage 3 of include/dnsplat.h).
+//
+// Replaces gsplat 1.0.0 rasterize_to_pixels_fwd (call site dn_splatter/dn_model.py:495) and the
+// legacy rasterize_forward / nd_rasterize_forward behind gsplat.rasterize_gaussians
+// (dn_model.py:564); rule set in SURVEY.md Appendix A.6.  D feature channels are composited in ONE
+// pass (colour | expected depth | normal), which is what lets dn-splatter's second, "20 % slower"
+// (README.md:60) normal pass disappear.
+//
+// CDNA4 mapping (not a 16x16-threads-per-tile CUDA layout):
+//   * the unit of work is one wave64 = one 16x8 half tile, two pixels per lane (rows r and r+4 of
+//     the half).  Two pixels per lane halve the LDS broadcast traffic per blended sample — with one
+//     pixel per lane the 4 x ds_read_b128 per splat would cost as many LDS cycles as the VALU work.
+//   * waves never synchronise with each other: each wave stages its own 64-splat batches
+//     (coalesced 64-byte record gathers -> its private 4 KiB LDS slice) and leaves as soon as its
+//     own 128 pixels are saturated (wave-level ballot), so there is no __syncthreads in the kernel.
+//   * the gather for batch b+1 is issued before batch b is consumed; the loads stay in flight
+//     behind the LDS/VALU loop (vmcnt is only waited on when the registers are written to LDS).
+//   * workgroup = the two half tiles of one tile (shared L1 lines for the record gather);
+//     blockIdx -> tile goes through the XCD band remap so that tiles sharing splats share an L2.
+
+#include "splat_common.h"
+
+namespace {
+
+constexpr int TILE = 16;
+constexpr int FWD_WAVES = 2;  // waves per workgroup == half tiles per tile
+constexpr int FWD_THREADS = FWD_WAVES * DNS_WAVE;
+
+struct FwdArgs {
+    int width, height, tw, n_tiles;
+    const float4 *__restrict__ splats;
+    const int32_t *__restrict__ flatten_ids;
+    const int32_t *__restrict__ tile_offsets;
+    const float *__restrict__ background;
+    int ed_channel;
+    float *__restrict__ render;
+    float *__restrict__ alphas;
+    int32_t *__restrict__ last_ids;
+};
+
+template <int D>
+__global__ __launch_bounds__(FWD_THREADS) void raster_fwd_kernel(FwdArgs a)
+{
+    // one 64-record slice per wave: [wave][splat][4 x float4]
+    __shared__ float4 lds[FWD_WAVES][DNS_WAVE][4];
+
+    const int tile = dns_xcd_remap(blockIdx.x, a.n_tiles);
+    const int wave = threadIdx.x / DNS_WAVE;
+    const int lane = threadIdx.x & (DNS_WAVE - 1);
+    const int tile_x = tile % a.tw, tile_y = tile / a.tw;
+    const int px_i = tile_x * TILE + (lane & 15);
+    const int py_i0 = tile_y * TILE + wave * 8 + (lane >> 4);
+    const int py_i1 = py_i0 + 4;
+    const float px = (float)px_i + 0.5f;
+    const float py0 = (float)py_i0 + 0.5f, py1 = (float)py_i1 + 0.5f;
+    const bool in0 = px_i < a.width && py_i0 < a.height;
+    const bool in1 = px_i < a.width && py_i1 < a.height;
+
+    const int range_start = a.tile_offsets[tile];
+    const int range_end = a.tile_offsets[tile + 1];
+
+    float T0 = 1.f, T1 = 1.f;
+    float acc0[D], acc1[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
+    int last0 = 0, last1 = 0;
+    bool done0 = !in0, done1 = !in1;
+
+    float4(*my)[4] = lds[wave];
+
+    // prefetch batch 0
+    float4 r0, r1, r2, r3;
+    {
+        const int idx = range_start + lane;
+        if (idx < range_end) {
+            const int g = a.flatten_ids[idx];
+            const float4 *rec = a.splats + (size_t)g * 4;
+            r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
+        }
+    }
+
+    for (int batch_start = range_start; batch_start < range_end; batch_start += DNS_WAVE) {
+        if (!__any(!(done0 && done1))) break;
+        // stage the prefetched records (waits for the gather here), then start the next gather
+        my[lane][0] = r0; my[lane][1] = r1;
+        if (D > 2) my[lane][2] = r2;
+        if (D > 6) my[lane][3] = r3;
+        {
+            const int idx = batch_start + DNS_WAVE + lane;
+            if (idx < range_end) {
+                const int g = a.flatten_ids[idx];
+                const float4 *rec = a.splats + (size_t)g * 4;
+                r0 = rec[0]; r1 = rec[1];
+                if (D > 2) r2 = rec[2];
+                if (D > 6) r3 = rec[3];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int batch_size = min(DNS_WAVE, range_end - batch_start);
+        for (int t = 0; t < batch_size; ++t) {
+            const float4 g0 = my[t][0];  // x y a b
+            const float4 g1 = my[t][1];  // c opac ch0 ch1
+            const float dx = g0.x - px;
+            const float dy0 = g0.y - py0, dy1 = g0.y - py1;
+            const float adx2 = g0.z * dx * dx, bdx = g0.w * dx;
+            const float sigma0 = 0.5f * (adx2 + g1.x * dy0 * dy0) + bdx * dy0;
+            const float sigma1 = 0.5f * (adx2 + g1.x * dy1 * dy1) + bdx * dy1;
+            const float alpha0 = fminf((float)DNS_ALPHA_MAX, g1.y * __expf(-sigma0));
+            const float alpha1 = fminf((float)DNS_ALPHA_MAX, g1.y * __expf(-sigma1));
+            bool c0 = !done0 && sigma0 >= 0.f && alpha0 >= (float)DNS_ALPHA_MIN;
+            bool c1 = !done1 && sigma1 >= 0.f && alpha1 >= (float)DNS_ALPHA_MIN;
+            const float nT0 = T0 * (1.f - alpha0), nT1 = T1 * (1.f - alpha1);
+            if (c0 && nT0 <= (float)DNS_T_MIN) { done0 = true; c0 = false; }
+            if (c1 && nT1 <= (float)DNS_T_MIN) { done1 = true; c1 = false; }
+            if (__any(c0 || c1)) {
+                float ch[8];
+                ch[0] = g1.z; ch[1] = g1.w;
+                if (D > 2) { const float4 g2 = my[t][2]; ch[2] = g2.x; ch[3] = g2.y; ch[4] = g2.z; ch[5] = g2.w; }
+                if (D > 6) { const float4 g3 = my[t][3]; ch[6] = g3.x; ch[7] = g3.y; }
+                const float v0 = c0 ? alpha0 * T0 : 0.f;
+                const float v1 = c1 ? alpha1 * T1 : 0.f;
+#pragma unroll
+                for (int k = 0; k < D; ++k) { acc0[k] += ch[k] * v0; acc1[k] += ch[k] * v1; }
+                if (c0) { T0 = nT0; last0 = batch_start + t; }
+                if (c1) { T1 = nT1; last1 = batch_start + t; }
+            }
+            if (!__any(!(done0 && done1))) break;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // epilogue: background, expected-depth normalisation, stores
+    if (in0) {
+        const size_t pid = (size_t)py_i0 * a.width + px_i;
+        const float al = 1.f - T0;
+        a.alphas[pid] = al;
+        a.last_ids[pid] = last0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            float v = acc0[k];
+            if (a.background) v += T0 * a.background[k];
+            if (k == a.ed_channel) v = v / fmaxf(al, (float)DNS_ED_ALPHA_FLOOR);
+            a.render[pid * D + k] = v;
+        }
+    }
+    if (in1) {
+        const size_t pid = (size_t)py_i1 * a.width + px_i;
+        const float al = 1.f - T1;
+        a.alphas[pid] = al;
+        a.last_ids[pid] = last1;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            float v = acc1[k];
+            if (a.background) v += T1 * a.background[k];
+            if (k == a.ed_channel) v = v / fmaxf(al, (float)DNS_ED_ALPHA_FLOOR);
+            a.render[pid * D + k] = v;
+        }
+    }
+}
+
+template <int D>
+int launch_fwd(const FwdArgs &fa, hipStream_t stream)
+{
+    hipLaunchKernelGGL(raster_fwd_kernel<D>, dim3(fa.n_tiles), dim3(FWD_THREADS), 0, stream, fa);
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}
+
+}  // namespace
+
+extern "C" int dnsplat_raster_fwd(const dnsplat_raster_args *a, dnsplat_stream_t stream_)
+{
+    if (!a) return DNSPLAT_ERR_INVALID_ARG;
+    if (a->tile_size != TILE) return DNSPLAT_ERR_UNSUPPORTED;
+    if (a->D < 1 || a->D > DNSPLAT_MAX_CHANNELS) return DNSPLAT_ERR_UNSUPPORTED;
+    if (a->width <= 0 || a->height <= 0) return DNSPLAT_ERR_INVALID_ARG;
+    if (!a->splats || !a->tile_offsets || !a->render || !a->alphas || !a->last_ids) return DNSPLAT_ERR_INVALID_ARG;
+    if (a->ed_channel >= a->D) return DNSPLAT_ERR_INVALID_ARG;
+    FwdArgs fa;
+    fa.width = a->width; fa.height = a->height;
+    fa.tw = dns_tiles_w(a->width, TILE);
+    fa.n_tiles = fa.tw * dns_tiles_h(a->height, TILE);
+    fa.splats = reinterpret_cast<const float4 *>(a->splats);
+    fa.flatten_ids = a->flatten_ids;
+    fa.tile_offsets = a->tile_offsets;
+    fa.background = a->background;
+    fa.ed_channel = a->ed_channel;
+    fa.render = a->render; fa.alphas = a->alphas; fa.last_ids = a->last_ids;
+    hipStream_t stream = (hipStream_t)stream_;
+    switch (a->D) {
+        case 1: return launch_fwd<1>(fa, stream);
+        case 2: return launch_fwd<2>(fa, stream);
+        case 3: return launch_fwd<3>(fa, stream);
+        case 4: return launch_fwd<4>(fa, stream);
+        case 5: return launch_fwd<5>(fa, stream);
+        case 6: return launch_fwd<6>(fa, stream);
+        case 7: return launch_fwd<7>(fa, stream);
+        case 8: return launch_fwd<8>(fa, stream);
+    }
+    return DNSPLAT_ERR_UNSUPPORTED;
+}

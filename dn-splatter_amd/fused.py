@@ -1,0 +1,92 @@
+"""One-pass colour + expected-depth + normal rendering — the MI355X-native form of the two gsplat
+calls in ``DNSplatterModel.get_outputs`` (``dn_splatter/dn_model.py:495-516`` and ``:564-575``).
+
+The reference renders RGB+ED with ``rasterization`` and then bins, sorts and composites a second
+time (legacy ``rasterize_gaussians``) just to splat the per-Gaussian normals — "about 20% slower"
+(reference README.md:60).  Both passes use the same xys / conics / opacities / tile lists, so their
+transmittance is identical; here the 3 normal channels ride along as channels 4..6 of a single
+7-channel compositing pass, with the two quirks of the second pass kept:
+
+* its background defaults to ones  -> background vector (0,0,0,0,1,1,1);
+* it is fed ``xys.detach()`` (dn_model.py:562) -> ``xy_split=4``: the normal channels contribute to
+  v_conics / v_opacities / v_normals but not to ``means2d.grad`` / ``means2d.absgrad``.
+
+Activations (exp / sigmoid / quaternion normalisation, dn_model.py:497-499), SH evaluation and the
+normal derivation of dn_model.py:543-560 are fused into the projection kernel, and features_dc /
+features_rest are read in place (no ``torch.cat`` of dn_model.py:466-468).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _ops
+from ._ops import ProjCfg
+
+
+def normal_frame_from_c2w(camera_to_world: Tensor) -> Tensor:
+    """[12] = (M row-major, camera centre) with n_cam = M n_world; dn_model.py:560 computes
+    ``normals @ c2w[:3,:3]`` i.e. M = c2w[:3,:3]^T, and dn_model.py:550-552 flips against c2w[:3,3]."""
+    c2w = camera_to_world.reshape(-1, 4)[:3]  # [3,4]
+    return torch.cat([c2w[:, :3].t().reshape(9), c2w[:, 3].reshape(3)]).to(torch.float32).contiguous()
+
+
+def render_dn(
+    means: Tensor,            # [N,3]
+    quats: Tensor,            # [N,4] raw (un-normalised) parameters
+    scales: Tensor,           # [N,3] log-scales
+    opacities: Tensor,        # [N] or [N,1] logits
+    features_dc: Tensor,      # [N,3]
+    features_rest: Tensor,    # [N,K-1,3]
+    viewmat: Tensor,          # [4,4] world->camera (OpenCV), device tensor
+    K: Tensor,                # [3,3]
+    camera_to_world: Tensor,  # [3,4] nerfstudio (OpenGL) c2w used for the normal frame
+    width: int,
+    height: int,
+    sh_degree: int,
+    predict_normals: bool = True,
+    rasterize_mode: str = "classic",
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    eps2d: float = 0.3,
+    absgrad: bool = True,
+    activated: bool = False,
+) -> Tuple[Tensor, Tensor, Optional[Tensor], Dict]:
+    """Returns ``(render[H,W,4] (RGB + expected depth), alpha[H,W,1], normals[H,W,3] | None, info)``.
+
+    ``activated=False`` means scales/opacities are the raw log / logit parameters of
+    ``gauss_params`` (dn_model.py:227-237) and the kernel applies exp / sigmoid itself.
+    """
+    if rasterize_mode == "antialiased" and predict_normals:
+        raise NotImplementedError(
+            "fused normals need the normal pass to share the colour pass' opacities; with "
+            "rasterize_mode='antialiased' the reference's second pass uses un-compensated opacities "
+            "(dn_model.py:571) — use the two-call path (model.DNSplatterRenderer(fused=False))")
+    N = means.shape[0]
+    D = 4 + (3 if predict_normals else 0)
+    cfg = ProjCfg(width=width, height=height, tile_size=16, eps2d=eps2d, near_plane=near_plane, far_plane=far_plane,
+                  antialiased=(rasterize_mode == "antialiased"), scales_are_log=not activated,
+                  opacities_are_logit=not activated, sh_degree=int(sh_degree), with_depth=True,
+                  with_normals=predict_normals, want_normals_world=predict_normals)
+    nf = normal_frame_from_c2w(camera_to_world).to(means.device) if predict_normals else None
+    pr = _ops.project(means, quats, scales, opacities.reshape(N), sh0=features_dc, shN=features_rest,
+                      viewmat=viewmat, K=K, normal_frame=nf, cfg=cfg)
+    bg = None
+    if predict_normals:
+        bg = torch.tensor([0.0, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0], device=means.device)
+    holder: Dict = {}
+    out, alphas = _ops.rasterize(pr["means2d"], pr["splats"], pr["depths"], pr["radii"], pr["tiles_per_gauss"],
+                                 background=bg, width=width, height=height, tile_size=16, D=D, ed_channel=3,
+                                 xy_split=4, absgrad=absgrad, holder=holder)
+    b = holder["binning"]
+    info = {
+        "means2d": pr["means2d"], "radii": pr["radii"][None], "depths": pr["depths"], "conics": pr["conics"],
+        "tiles_per_gauss": pr["tiles_per_gauss"][None], "normals_world": pr["normals_world"],
+        "flatten_ids": b.flatten_ids[: b.n_isects], "isect_offsets": b.tile_offsets[:-1].reshape(1, b.tile_height, b.tile_width),
+        "n_isects": b.n_isects, "tile_width": b.tile_width, "tile_height": b.tile_height,
+        "width": width, "height": height, "tile_size": 16, "n_cameras": 1,
+    }
+    normals = out[..., 4:7] if predict_normals else None
+    return out[..., :4], alphas[..., None], normals, info

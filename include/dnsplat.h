@@ -1,0 +1,207 @@
+/*
+ * dnsplat.h — C ABI of libdnsplat.so, the MI355X (gfx950) renderer that drops in
+ * behind dn-splatter's DNSplatterModel.get_outputs().
+ *
+ * What it replaces.  The reference has no native code; its hot path is two calls
+ * into the third-party CUDA package gsplat==1.0.0 (reference pin pyproject.toml:8):
+ *   - gsplat.rendering.rasterization(...)   dn_splatter/dn_model.py:495-516
+ *   - gsplat.rasterize_gaussians(...)       dn_splatter/dn_model.py:564-575
+ * plus two helpers (dn_model.py:34-35).  The entry points below are the stages of
+ * those two calls, cut where the reference's own
+ * autograd graph is cut so that the Python binding in dn-splatter_amd/ can expose
+ * exactly the tensors dn-splatter reads back (means2d incl. .grad/.absgrad, radii,
+ * depths, conics, tiles_per_gauss — dn_model.py:517-524).
+ *
+ * Conventions.
+ *   - Every pointer is a DEVICE pointer owned by the caller unless its name ends in
+ *     _host.  Structs themselves live in host memory and are read during the call.
+ *   - Kernels are enqueued on `stream`; no entry point allocates, frees or
+ *     synchronises.  Workspaces are sized by the *_workspace_bytes queries.
+ *   - Return value: 0 = ok, <0 = error (dnsplat_strerror).  No exceptions cross the ABI.
+ *   - All floats are fp32, row-major, layouts as in the reference tensors:
+ *     means[N,3], quats[N,4] (wxyz), scales[N,3], opacities[N], SH coefficients
+ *     [N,K,3] (or split band-0 / rest, dn_model.py:466-468), viewmat[4,4] world->camera
+ *     OpenCV, K[3,3].  One camera per call (dn_model.py:421).
+ *   - The library keeps no global mutable state; calls are re-entrant across streams.
+ *
+ * Splat record.  Stage 1 packs what the compositing kernels gather per tile
+ * intersection into one 64-byte record per Gaussian:
+ *     [0]=x [1]=y [2..4]=conic(a,b,c) [5]=opacity [6..13]=up to 8 feature channels [14..15]=0
+ * The gradient record written by dnsplat_raster_bwd mirrors it:
+ *     [0..1]=v_xy [2..4]=v_conic [5]=v_opacity [6..13]=v_channels [14..15]=|v_xy| (absgrad, A11)
+ */
+#ifndef DNSPLAT_H
+#define DNSPLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DNSPLAT_ABI_VERSION 1
+#define DNSPLAT_RECORD_FLOATS 16
+#define DNSPLAT_MAX_CHANNELS 8
+
+/* error codes */
+#define DNSPLAT_OK 0
+#define DNSPLAT_ERR_INVALID_ARG (-1)
+#define DNSPLAT_ERR_WORKSPACE (-2)
+#define DNSPLAT_ERR_LAUNCH (-3)
+#define DNSPLAT_ERR_UNSUPPORTED (-4)
+
+typedef void *dnsplat_stream_t; /* hipStream_t */
+
+const char *dnsplat_strerror(int code);
+int dnsplat_abi_version(void);
+
+/* ------------------------------------------------------------------ stage 1
+ * Fused per-Gaussian front end: activations (A0) + fully-fused projection (A1)
+ * + tile count (A2a) + spherical harmonics (A5) + per-Gaussian normal (A7) +
+ * record packing.  Replaces gsplat fully_fused_projection / spherical_harmonics
+ * and the torch ops at dn_model.py:497-499, 543-560. */
+typedef struct dnsplat_scene {
+    int32_t N;
+    const float *means;     /* [N,3] */
+    const float *quats;     /* [N,4] wxyz, any norm (normalised inside, as gsplat does) */
+    const float *scales;    /* [N,3] */
+    const float *opacities; /* [N] */
+    int32_t scales_are_log;       /* 1: apply exp()      (dn_model.py:498) */
+    int32_t opacities_are_logit;  /* 1: apply sigmoid()  (dn_model.py:499) */
+    /* colour source: SH if sh_degree >= 0, else direct colours */
+    int32_t sh_degree;            /* active degree 0..3, or -1 */
+    int32_t sh_K;                 /* number of SH bases held in storage (16 for degree-3 models); the
+                                     K-1 higher bands live in shN, gradients of inactive bands are 0 */
+    const float *sh0;             /* band 0, element g at sh0 + g*sh0_stride, 3 floats   */
+    int32_t sh0_stride;
+    const float *shN;             /* bands >= 1, element g at shN + g*shN_stride, 3*(K-1) floats */
+    int32_t shN_stride;
+    const float *colors;          /* direct colours [N, n_colors] when sh_degree < 0 */
+    int32_t n_colors;             /* 0..8 */
+} dnsplat_scene;
+
+typedef struct dnsplat_camera {
+    const float *viewmat;      /* device [16] world->camera, row-major, OpenCV axes */
+    const float *K;            /* device [9] */
+    const float *normal_frame; /* device [12] or NULL: rows 0-8 = M with n_cam = M n_world
+                                  (dn_model.py:560 `normals @ c2w[:3,:3]` => M = c2w[:3,:3]^T),
+                                  9-11 = camera centre used for the facing flip (dn_model.py:550-556) */
+    int32_t width, height, tile_size;
+    float eps2d, near_plane, far_plane, radius_clip;
+    int32_t antialiased;       /* rasterize_mode == "antialiased": opacity *= compensation */
+} dnsplat_camera;
+
+typedef struct dnsplat_proj_out {
+    int32_t *radii;            /* [N] */
+    float *means2d;            /* [N,2] */
+    float *depths;             /* [N] */
+    float *conics;             /* [N,3] */
+    float *compensations;      /* [N] or NULL */
+    int32_t *tiles_per_gauss;  /* [N] */
+    float *splats;             /* [N,16] records, channels = colours | depth | normal */
+    float *normals_world;      /* [N,3] or NULL: what dn_model.py:558 stores into gauss_params["normals"] */
+    int32_t with_depth_channel;   /* append camera-space depth as a channel (RGB+D / RGB+ED) */
+    int32_t with_normal_channels; /* append the 3 camera-frame normal channels (needs camera.normal_frame) */
+} dnsplat_proj_out;
+
+int dnsplat_project_fwd(const dnsplat_scene *scene, const dnsplat_camera *cam,
+                        const dnsplat_proj_out *out, dnsplat_stream_t stream);
+
+/* Packs caller-provided 2-D splats into records; the front end of the legacy
+ * gsplat.rasterize_gaussians call (dn_model.py:564-575) whose inputs are already
+ * projected. colors [N,C], C <= 8. */
+int dnsplat_pack_splats(int32_t N, const float *means2d, const float *conics, const float *opacities,
+                        const float *colors, int32_t C, float *splats, dnsplat_stream_t stream);
+
+/* ------------------------------------------------------------------ stage 2
+ * Tile binning.  Replaces gsplat isect_tiles + radix sort + isect_offset_encode
+ * (A2-A4) and, for the legacy call, map_gaussian_to_intersects + torch.sort +
+ * get_tile_bin_edges (A8).  Produces the same ordering — ascending
+ * (tile, depth bits), ties by Gaussian index — by (1) a stable 32-bit radix sort
+ * of the Gaussians on depth, (2) emission of (tile, gaussian) pairs in that order
+ * and (3) a stable radix sort on the tile id only. */
+size_t dnsplat_bin_workspace_bytes(int32_t N, int64_t isect_capacity, int32_t n_tiles);
+
+typedef struct dnsplat_bin_args {
+    int32_t N;
+    int32_t width, height, tile_size;
+    const float *means2d;            /* [N,2] */
+    const int32_t *radii;            /* [N] */
+    const float *depths;             /* [N] */
+    const int32_t *tiles_per_gauss;  /* [N] */
+    int64_t isect_capacity;          /* entries flatten_ids can hold */
+    int32_t *flatten_ids;            /* out [isect_capacity]: Gaussian index per sorted intersection */
+    int32_t *tile_offsets;           /* out [n_tiles+1]: first sorted index per tile; [n_tiles] = n_isects */
+    int64_t *n_isects;               /* out device scalar: true number of intersections (may exceed capacity) */
+    int64_t *n_isects_host;          /* optional pinned host mirror, written by an async D2H copy; NULL to skip */
+    void *workspace;
+    size_t workspace_bytes;
+} dnsplat_bin_args;
+
+/* 2a: depth sort + inclusive offsets + total.  After this (and a stream sync or
+ * a look at n_isects_host) the caller knows how large flatten_ids must be. */
+int dnsplat_bin_prepare(const dnsplat_bin_args *args, dnsplat_stream_t stream);
+/* 2b: emit + tile sort + offsets.  If n_isects > isect_capacity nothing past the
+ * capacity is written and tile_offsets are clamped: the caller must re-run with
+ * a larger capacity (it detects this from n_isects). */
+int dnsplat_bin_emit_sort(const dnsplat_bin_args *args, dnsplat_stream_t stream);
+/* Reconstructs gsplat's 64-bit isect_ids (tile << 32 | depth bits) for the
+ * sorted list — only needed to populate the `isect_ids` entry of the info dict. */
+int dnsplat_bin_isect_ids(int32_t n_tiles, const int32_t *tile_offsets, const int32_t *flatten_ids,
+                          const float *depths, int64_t *isect_ids, int64_t capacity, dnsplat_stream_t stream);
+
+/* ------------------------------------------------------------------ stage 3/4
+ * Per-tile front-to-back alpha compositing of D feature channels (A6 + A8 in one
+ * pass) and its backward. */
+typedef struct dnsplat_raster_args {
+    int32_t width, height, tile_size;   /* tile_size must be 16 */
+    int32_t D;                          /* feature channels, 1..8 */
+    const float *splats;                /* [N,16] */
+    const int32_t *flatten_ids;
+    const int32_t *tile_offsets;        /* [n_tiles+1] */
+    const float *background;            /* device [D] or NULL (gsplat v1: none; legacy normal pass: ones) */
+    int32_t ed_channel;                 /* channel normalised by max(alpha,1e-10) ("ED"), or -1 */
+    float *render;                      /* [H,W,D] */
+    float *alphas;                      /* [H,W] */
+    int32_t *last_ids;                  /* [H,W] sorted index of the last splat applied */
+    /* backward only */
+    const float *v_render;              /* [H,W,D] */
+    const float *v_alphas;              /* [H,W] or NULL */
+    int32_t xy_split;                   /* channels >= xy_split do not feed v_xy/|v_xy|: the reference renders
+                                           them with xys.detach() (dn_model.py:562). Use D for "all feed". */
+    float *v_splats;                    /* [N,16] gradient records, accumulated into (caller zero-fills) */
+} dnsplat_raster_args;
+
+int dnsplat_raster_fwd(const dnsplat_raster_args *args, dnsplat_stream_t stream);
+int dnsplat_raster_bwd(const dnsplat_raster_args *args, dnsplat_stream_t stream);
+
+/* ------------------------------------------------------------------ stage 5
+ * Fused per-Gaussian back end: gradient record -> parameter gradients.
+ * Replaces gsplat fully_fused_projection_bwd (A10), spherical_harmonics bwd (A5),
+ * the autograd of dn_model.py:543-560 (A7) and of the activations (A0). */
+typedef struct dnsplat_proj_grads {
+    const int32_t *radii;        /* [N] from the forward */
+    const float *v_splats;       /* [N,16] gradient records */
+    const float *v_means2d;      /* optional [N,2]: if non-NULL REPLACES record columns 0-1 (the binding
+                                    routes means2d through autograd so callers may add their own terms) */
+    const float *v_depths;       /* optional [N], added */
+    const float *v_conics;       /* optional [N,3], added */
+    const float *v_compensations;/* optional [N] */
+    float *v_means;              /* [N,3] */
+    float *v_quats;              /* [N,4] */
+    float *v_scales;             /* [N,3] w.r.t. the tensor passed in (log-scales if scales_are_log) */
+    float *v_opacities;          /* [N]   w.r.t. the tensor passed in */
+    float *v_sh0; int32_t v_sh0_stride;   /* like scene.sh0 / shN; NULL to skip */
+    float *v_shN; int32_t v_shN_stride;
+    float *v_colors;             /* [N,n_colors] when sh_degree < 0; NULL to skip */
+} dnsplat_proj_grads;
+
+int dnsplat_project_bwd(const dnsplat_scene *scene, const dnsplat_camera *cam,
+                        const dnsplat_proj_out *fwd, const dnsplat_proj_grads *grads,
+                        dnsplat_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DNSPLAT_H */

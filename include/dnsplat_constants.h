@@ -21,6 +21,6 @@
 #define DNS_ED_ALPHA_FLOOR     1e-10    /* A.6: expected depth = sum(w z)/max(alpha,1e-10)         */
 #define DNS_TILE_DEFAULT       16       /* dn_model.py:470-472 BLOCK_WIDTH                         */
 #define DNS_SH_C0              0.2820947917738781
-#define DNS_MAX_CH             10       /* feature channels a splat record can carry (6 + 10 = 16 floats) */
+#define DNS_MAX_CH             8        /* feature channels a splat record carries: 6 geometry floats + 8 channels + 2 spare = 16 floats */
 
 #endif
