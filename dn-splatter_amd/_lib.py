@@ -142,3 +142,42 @@ def lib() -> ctypes.CDLL:
 def check(rc: int, what: str) -> None:
     if rc != 0:
         raise DnsplatError(f"{what} failed: {lib().dnsplat_strerror(rc).decode()} (code {rc})")
+
+
+class StageTimer:
+    """Per-stage GPU time from HIP events recorded on the stream the kernels are enqueued on (torch's current
+    stream — the one every dnsplat_* call receives).  Used by bench.py for the roofline figures; off by default."""
+
+    def __init__(self):
+        self.events = {}
+
+    def add(self, name, e0, e1):
+        self.events.setdefault(name, []).append((e0, e1))
+
+    def summary(self):
+        """name -> (launches, mean ms, total ms); call after a stream/device synchronize."""
+        out = {}
+        for name, evs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = (len(ms), sum(ms) / len(ms), sum(ms))
+        return out
+
+
+TIMER = None  # set to a StageTimer to record
+
+
+def run(name: str, fn, *args) -> None:
+    """Call one C-ABI entry point, raising on a non-zero code; brackets it with HIP events if TIMER is set."""
+    t = TIMER
+    if t is None:
+        check(fn(*args), name)
+        return
+    import torch
+
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    t.add(name, e0, e1)
+    check(rc, name)

@@ -96,6 +96,24 @@ class _Buffers:
 
 BUFFERS = _Buffers()
 
+# Optional flat gradient bucket (dp.GradArena): when set, stage 5 writes parameter gradients straight into
+# it so that data-parallel training all-reduces ONE buffer without flatten copies.
+GRAD_ARENA = None
+
+
+def set_grad_arena(arena) -> None:
+    global GRAD_ARENA
+    GRAD_ARENA = arena
+
+
+def _grad_like(param: Tensor) -> Tensor:
+    a = GRAD_ARENA
+    if a is not None:
+        t = a.take(param)
+        if t is not None:
+            return t.view(param.shape)
+    return torch.empty_like(param)
+
 # "sync": read n_isects back before emitting (one host round-trip per frame, what gsplat does).
 # "capacity": size the intersection buffers from the previous frames (x1.25), enqueue everything,
 #             then verify n_isects <= capacity while the compositing kernel already runs; an overflow
@@ -190,8 +208,7 @@ class _ProjectFn(torch.autograd.Function):
         out.normals_world = _ptr(nworld)
         out.with_depth_channel = int(cfg.with_depth)
         out.with_normal_channels = int(cfg.with_normals)
-        _lib.check(_lib.lib().dnsplat_project_fwd(ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(out), _stream()),
-                   "dnsplat_project_fwd")
+        _lib.run("dnsplat_project_fwd", _lib.lib().dnsplat_project_fwd, ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(out), _stream())
 
         ctx.cfg = cfg
         ctx.sh_K = sh_K
@@ -225,10 +242,10 @@ class _ProjectFn(torch.autograd.Function):
         v_con = v_conics.reshape(N, 3).contiguous() if v_conics is not None else None
         v_cmp = v_comp.reshape(N).contiguous() if (v_comp is not None and cfg.antialiased) else None
 
-        v_means = torch.empty_like(means)
-        v_quats = torch.empty_like(quats)
-        v_scales = torch.empty_like(scales)
-        v_opac = torch.empty_like(opacities)
+        v_means = _grad_like(means)
+        v_quats = _grad_like(quats)
+        v_scales = _grad_like(scales)
+        v_opac = _grad_like(opacities)
         sh_K = ctx.sh_K
         p_sh0 = p_shN = None
         s0 = sN = 0
@@ -242,11 +259,11 @@ class _ProjectFn(torch.autograd.Function):
             g.v_shN, g.v_shN_stride = _ptr(v_coeffs.view(-1)[3:]), 3 * sh_K
         elif ctx.layout == "split":
             p_sh0, s0 = sh0, 3
-            v_sh0 = torch.empty_like(sh0)
+            v_sh0 = _grad_like(sh0)
             g.v_sh0, g.v_sh0_stride = _ptr(v_sh0), 3
             if sh_K > 1:
                 p_shN, sN = shN, 3 * (sh_K - 1)
-                v_shN = torch.empty_like(shN)
+                v_shN = _grad_like(shN)
                 g.v_shN, g.v_shN_stride = _ptr(v_shN), 3 * (sh_K - 1)
         elif colors is not None:
             v_colors = torch.empty_like(colors)
@@ -260,8 +277,8 @@ class _ProjectFn(torch.autograd.Function):
         g.radii, g.v_splats = _ptr(radii), _ptr(v_splats)
         g.v_means2d, g.v_depths, g.v_conics, g.v_compensations = _ptr(v_m2d), _ptr(v_dep), _ptr(v_con), _ptr(v_cmp)
         g.v_means, g.v_quats, g.v_scales, g.v_opacities = _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac)
-        _lib.check(_lib.lib().dnsplat_project_bwd(ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(fwd),
-                                                  ctypes.byref(g), _stream()), "dnsplat_project_bwd")
+        _lib.run("dnsplat_project_bwd", _lib.lib().dnsplat_project_bwd, ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(fwd),
+                                                  ctypes.byref(g), _stream())
         need = ctx.needs_input_grad
         return (v_means if need[0] else None, v_quats if need[1] else None, v_scales if need[2] else None,
                 v_opac if need[3] else None, v_coeffs if need[4] else None, v_sh0 if need[5] else None,
@@ -324,10 +341,10 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
         capacity = hint
         flatten_ids = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
         args, ws0 = make_args(capacity, flatten_ids, tile_offsets)
-        _lib.check(lib.dnsplat_bin_prepare(ctypes.byref(args), _stream()), "dnsplat_bin_prepare")
+        _lib.run("dnsplat_bin_prepare", _lib.lib().dnsplat_bin_prepare, ctypes.byref(args), _stream())
         ev = torch.cuda.Event()
         ev.record()
-        _lib.check(lib.dnsplat_bin_emit_sort(ctypes.byref(args), _stream()), "dnsplat_bin_emit_sort")
+        _lib.run("dnsplat_bin_emit_sort", _lib.lib().dnsplat_bin_emit_sort, ctypes.byref(args), _stream())
         b = Binning(flatten_ids, tile_offsets, -1, tw, th)
         if after_emit is not None:
             after_emit(b)
@@ -342,7 +359,7 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
         # the N-sized front of the workspace has the same layout for every capacity, so the depth sort
         # done here stays valid for the emit below as long as the buffer is not re-allocated
         args, ws0 = make_args(hint, None, tile_offsets)
-        _lib.check(lib.dnsplat_bin_prepare(ctypes.byref(args), _stream()), "dnsplat_bin_prepare")
+        _lib.run("dnsplat_bin_prepare", _lib.lib().dnsplat_bin_prepare, ctypes.byref(args), _stream())
         torch.cuda.current_stream().synchronize()
         n = int(n_host.item())
     capacity = n
@@ -350,8 +367,8 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
     flatten_ids = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
     args, ws1 = make_args(capacity, flatten_ids, tile_offsets)
     if ws1.data_ptr() != ws0.data_ptr():
-        _lib.check(lib.dnsplat_bin_prepare(ctypes.byref(args), _stream()), "dnsplat_bin_prepare")
-    _lib.check(lib.dnsplat_bin_emit_sort(ctypes.byref(args), _stream()), "dnsplat_bin_emit_sort")
+        _lib.run("dnsplat_bin_prepare", _lib.lib().dnsplat_bin_prepare, ctypes.byref(args), _stream())
+    _lib.run("dnsplat_bin_emit_sort", _lib.lib().dnsplat_bin_emit_sort, ctypes.byref(args), _stream())
     b = Binning(flatten_ids, tile_offsets, n, tw, th)
     if after_emit is not None:
         after_emit(b)
@@ -361,9 +378,8 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
 def isect_ids(b: Binning, depths: Tensor) -> Tensor:
     """gsplat's 64-bit sorted keys (tile << 32 | depth bits), rebuilt on demand for the info dict."""
     out = torch.empty(max(b.n_isects, 1), dtype=torch.int64, device=depths.device)
-    _lib.check(_lib.lib().dnsplat_bin_isect_ids(b.tile_width * b.tile_height, _ptr(b.tile_offsets), _ptr(b.flatten_ids),
-                                                _ptr(depths.reshape(-1)), _ptr(out), b.n_isects, _stream()),
-               "dnsplat_bin_isect_ids")
+    _lib.run("dnsplat_bin_isect_ids", _lib.lib().dnsplat_bin_isect_ids, b.tile_width * b.tile_height, _ptr(b.tile_offsets), _ptr(b.flatten_ids),
+                                                _ptr(depths.reshape(-1)), _ptr(out), b.n_isects, _stream())
     return out[: b.n_isects]
 
 
@@ -392,7 +408,7 @@ class _RasterFn(torch.autograd.Function):
             a.background = _ptr(bg)
             a.ed_channel = ed_channel
             a.render, a.alphas, a.last_ids = _ptr(render), _ptr(alphas), _ptr(last_ids)
-            _lib.check(_lib.lib().dnsplat_raster_fwd(ctypes.byref(a), _stream()), "dnsplat_raster_fwd")
+            _lib.run("dnsplat_raster_fwd", _lib.lib().dnsplat_raster_fwd, ctypes.byref(a), _stream())
 
         b = bin_tiles(means2d.detach().reshape(-1, 2), radii, depths.detach().reshape(-1), tiles, width, height,
                       tile_size, after_emit=composite)
@@ -426,7 +442,7 @@ class _RasterFn(torch.autograd.Function):
         a.v_render, a.v_alphas = _ptr(v_render), _ptr(v_alphas)
         a.xy_split = xy_split
         a.v_splats = _ptr(v_splats)
-        _lib.check(_lib.lib().dnsplat_raster_bwd(ctypes.byref(a), _stream()), "dnsplat_raster_bwd")
+        _lib.run("dnsplat_raster_bwd", _lib.lib().dnsplat_raster_bwd, ctypes.byref(a), _stream())
         if absgrad:
             # gsplat contract (dn_model.py:512, consumed by nerfstudio after_train via self.xys.absgrad)
             means2d.absgrad = v_splats[:, 14:16].reshape(means2d.shape)
@@ -453,8 +469,8 @@ class _PackFn(torch.autograd.Function):
         opacity = _f32c(opacity, "opacity"); colors = _f32c(colors, "colors")
         N, C = colors.shape
         splats = torch.empty(N, RECORD_FLOATS, dtype=torch.float32, device=xys.device)
-        _lib.check(_lib.lib().dnsplat_pack_splats(N, _ptr(xys), _ptr(conics), _ptr(opacity.reshape(-1)), _ptr(colors), C,
-                                                  _ptr(splats), _stream()), "dnsplat_pack_splats")
+        _lib.run("dnsplat_pack_splats", _lib.lib().dnsplat_pack_splats, N, _ptr(xys), _ptr(conics), _ptr(opacity.reshape(-1)), _ptr(colors), C,
+                                                  _ptr(splats), _stream())
         ctx.C = C
         ctx.oshape = opacity.shape
         return splats

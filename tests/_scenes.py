@@ -1,0 +1,83 @@
+"""Seeded scenes and comparison helpers shared by the CPU and GPU test files."""
+from __future__ import annotations
+
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# The parity bar BASELINE.json states: "tile/bin indices bit-exact, rendered RGB/depth/normal and grads
+# within 1e-4 rel fp32".  "rel" is taken relative to the tensor's scale (max |reference|): gradients are
+# sums of thousands of signed terms whose fp32 summation order differs between the oracle (pixel-major,
+# omp atomics) and the GPU (splat-major registers + one atomic per tile), so an element-wise relative
+# error is unbounded at cancelling entries while the scale-relative error stays ~1e-6.
+REL_TOL = 1e-4
+
+
+def rel_err(a, b) -> float:
+    a = a.detach().double().cpu().reshape(-1)
+    b = b.detach().double().cpu().reshape(-1)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if b.numel() == 0:
+        return 0.0
+    scale = b.abs().max().item()
+    return (a - b).abs().max().item() / (scale + 1e-30)
+
+
+def assert_close(a, b, what, tol=REL_TOL):
+    a_ = a.detach().cpu()
+    b_ = b.detach().cpu()
+    assert a_.shape == b_.shape, f"{what}: shape {tuple(a_.shape)} vs {tuple(b_.shape)}"
+    assert torch.isfinite(a_.float()).all(), f"{what}: non-finite values"
+    e = rel_err(a_, b_)
+    assert e <= tol, f"{what}: scale-relative error {e:.3e} > {tol:.1e}"
+
+
+def assert_equal_int(a, b, what):
+    a_ = a.detach().cpu()
+    b_ = b.detach().cpu()
+    assert a_.shape == b_.shape, f"{what}: shape {tuple(a_.shape)} vs {tuple(b_.shape)}"
+    if not torch.equal(a_, b_):
+        bad = (a_ != b_).nonzero()
+        raise AssertionError(f"{what}: {bad.shape[0]} of {a_.numel()} integers differ, first at {bad[0].tolist()}: "
+                             f"{a_[tuple(bad[0])].item()} vs {b_[tuple(bad[0])].item()}")
+
+
+def gsplat_inputs(N, W, H, focal, seed=0, sh_rest_std=0.1, view=0, anisotropic=False):
+    """Activated inputs in the form dn_model.py:496-504 hands to gsplat.rasterization (CPU tensors)."""
+    import dn_splatter_amd as dns
+    from dn_splatter_amd import synthetic
+
+    gp = synthetic.make_gauss_params(N, sh_rest_std=sh_rest_std, seed=seed)
+    cam = synthetic.orbit_camera(view, width=W, height=H, focal=focal)
+    g = torch.Generator().manual_seed(seed + 1000)
+    scales_log = gp["scales"].detach().clone()
+    if anisotropic:
+        scales_log = scales_log + torch.randn(N, 3, generator=g) * 0.6
+    opac_logit = gp["opacities"].detach().clone()
+    if anisotropic:
+        opac_logit = opac_logit + torch.randn(N, 1, generator=g) * 2.0
+    quats = gp["quats"].detach()
+    inp = dict(
+        means=gp["means"].detach().clone(),
+        quats=(quats / quats.norm(dim=-1, keepdim=True)).clone(),
+        scales=torch.exp(scales_log),
+        opacities=torch.sigmoid(opac_logit).squeeze(-1),
+        colors=torch.cat([gp["features_dc"].detach()[:, None], gp["features_rest"].detach()], 1).clone(),
+    )
+    viewmat = dns.get_viewmat(cam.camera_to_worlds)
+    K = cam.get_intrinsics_matrices()
+    return inp, viewmat, K, cam
+
+
+def to_leaf(inp, device):
+    return {k: v.detach().to(device).clone().requires_grad_(True) for k, v in inp.items()}
+
+
+def cotangents(shapes, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.rand(s, generator=g) * 2 - 1 for s in shapes]
