@@ -5,17 +5,18 @@
 //
 // The reference design is pixel-parallel: every thread owns a pixel, walks the tile list back to
 // front, and each of the ~15 per-splat partial gradients is warp-reduced and atomically added once
-// per (warp, splat).  On a 64-wide wave that reduction (15 values x 6-7 DPP steps) costs more than
+// per (warp, splat).  On a 64-wide wave that reduction (15 values x 6 DPP steps) costs more than
 // the gradient math itself.  This kernel turns the problem by 90 degrees — a wave64 SYSTOLIC pass:
 //
-//   * one wave owns one 16x16 tile; lane l owns ONE SPLAT of the current 64-splat bucket
-//     (lane 0 = back-most), for the whole pass, and keeps that splat's 16 partial gradients in VGPRs;
+//   * one wave owns one 16x16 tile; lane l owns ONE SPLAT of the current bucket of 64 (lane 0 =
+//     back-most) for the whole pass and keeps that splat's 16 partial gradients in VGPRs;
 //   * the 256 pixels stream through the lanes, back to front: at step s lane l works on pixel s-l.
 //     What travels with a pixel is only its running state (T, S_a, S_b) — three v_mov_dpp
 //     wave_shr:1 per step — where S = sum_k buffer_k * v_k collapses the reference's per-channel
 //     `buffer` into one scalar per gradient group (v_alpha = T*(c.v) - S/(1-alpha));
 //   * per-pixel constants (upstream gradient, last contributing index) sit in a 12 KiB LDS table,
-//     read with conflict-free ds_read_b128 (48-byte stride over consecutive lanes);
+//     read with conflict-free ds_read_b128 (48-byte stride over consecutive lanes) one step AHEAD of
+//     their use, so the LDS latency hides behind the previous step's arithmetic;
 //   * state leaving lane 63 is parked back in the pixel's LDS row and picked up by lane 0 in the
 //     next (nearer) bucket — the arithmetic order per pixel is exactly the reference's
 //     back-to-front replay (T *= 1/(1-alpha); buffer += c*alpha*T);
@@ -23,9 +24,19 @@
 //     and ONE atomic row per (tile, splat).  The flush is transposed through LDS so that each
 //     global_atomic_add_f32 instruction covers whole 64-byte gradient records (16 lanes per record).
 //
-// Channel groups: channels >= xy_split (the normal channels of the fused pass) are rendered by the
+// Bucket compaction.  A tile list holds every splat whose 3-sigma bounding box touches the tile; on
+// the benchmark scenes about half of those cannot reach alpha >= 1/255 at any pixel centre of the
+// tile.  Before a bucket is formed the wave tests 64 list entries at once against the tile rectangle
+// (dns_cull_rect: exact minimum of the quadratic over the rectangle, one lane per entry) and
+// ballot-compacts the survivors into an LDS queue, so lanes only ever hold splats that can
+// contribute.  Culled entries are exactly those the per-pixel test would skip for all 256 pixels:
+// results are unchanged, the systolic array just runs ~2x fewer steps.
+//
+// Channel groups: channels >= SPLIT (the normal channels of the fused pass) are rendered by the
 // reference with xys.detach() (dn_model.py:562), so their share of d/d(alpha) must not reach
-// v_xy / |v_xy| while it does reach v_conic and v_opacity.  Hence two S states.
+// v_xy / |v_xy| while it does reach v_conic and v_opacity.  Hence two S states.  SPLIT is a
+// compile-time constant for the two shapes that occur (SPLIT == D: everything feeds xy; D == 7,
+// SPLIT == 4: the fused colour+depth | normal pass); other splits take the generic instantiation.
 
 #include "splat_common.h"
 
@@ -33,7 +44,7 @@ namespace {
 
 constexpr int TILE = 16;
 constexpr int NPIX = TILE * TILE;
-constexpr int PIXREC = 12;  // floats per pixel row in LDS
+constexpr int QCAP = 2 * DNS_WAVE;
 
 struct BwdArgs {
     int width, height, tw, n_tiles;
@@ -58,11 +69,13 @@ __device__ __forceinline__ float dpp_wave_shr1(float from_prev, float lane0_valu
                                                       0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
 
-template <int D>
+// SPLIT >= 0: compile-time split; SPLIT < 0: run-time a.xy_split
+template <int D, int SPLIT>
 __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
 {
-    __shared__ float4 pix[NPIX][PIXREC / 4];   // [p][0..1] = v_k, [p][2] = (T, S_a, S_b, bin_final)
+    __shared__ float4 pix[NPIX][3];            // [p][0..1] = v_k, [p][2] = (T, S_a, S_b, bin_final)
     __shared__ float4 flush[DNS_WAVE][4];      // gradient rows staged for the transposed flush
+    __shared__ int32_t queue[QCAP];            // compacted list indices waiting for a bucket
 
     const int tile = dns_xcd_remap(blockIdx.x, a.n_tiles);
     const int lane = threadIdx.x;
@@ -70,6 +83,7 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
     const int range_end = a.tile_offsets[tile + 1];
     if (range_end <= range_start) return;
     const int tile_x0 = (tile % a.tw) * TILE, tile_y0 = (tile / a.tw) * TILE;
+    const int split = SPLIT >= 0 ? SPLIT : a.xy_split;
 
     // ---- prologue: per-pixel table --------------------------------------------------------------
     int hi = -1;
@@ -106,12 +120,14 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
                     const float t = a.background[k] * v[k];
-                    if (k < a.xy_split) bga += t; else bgb += t;
+                    if (k < split) bga += t; else bgb += t;
                 }
             }
             // S starts at -(T_final * d/d(alpha_img) share) so that v_alpha = T*cv - ra*S needs no extra term
             sa = -T_final * (va - bga);
             sb = T_final * bgb;
+            // a pixel nothing was blended into walks no list entry at all
+            if (al <= 0.f) bin_final = -1;
         }
         pix[p][0] = make_float4(v[0], v[1], v[2], v[3]);
         pix[p][1] = make_float4(v[4], v[5], v[6], v[7]);
@@ -125,12 +141,39 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
     __builtin_amdgcn_wave_barrier();
 
     const float fx0 = (float)tile_x0 + 0.5f, fy0 = (float)tile_y0 + 0.5f;
-    const int n_pass = (hi - range_start + DNS_WAVE) / DNS_WAVE;
+    const float rxh = fx0 + 15.f, ryh = fy0 + 15.f;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    for (int pass = 0; pass < n_pass; ++pass) {
+    int cursor = hi;  // next (highest) list index not yet examined
+    int qn = 0;       // entries waiting in the queue (wave-uniform)
+
+    for (;;) {
+        // ---- fill the queue with contributing entries until a full bucket is available ----------
+        while (qn < DNS_WAVE && cursor >= range_start) {
+            const int idx = cursor - lane;
+            bool keep = false;
+            if (idx >= range_start) {
+                const int g = a.flatten_ids[idx];
+                const float4 r0 = a.splats[(size_t)g * 4], r1 = a.splats[(size_t)g * 4 + 1];
+                keep = !dns_cull_rect(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, fx0, rxh, fy0, ryh);
+            }
+            const uint64_t m = __ballot(keep);
+            if (keep) queue[qn + __popcll(m & lt_mask)] = idx;
+            qn += __popcll(m);
+            cursor -= DNS_WAVE;
+        }
+        if (qn == 0) break;
+        __builtin_amdgcn_wave_barrier();
+        const int take = min(qn, DNS_WAVE);
+        const int my_idx = lane < take ? queue[lane] : -1;
+        const int rest = qn - take;
+        const int moved = lane < rest ? queue[DNS_WAVE + lane] : 0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rest) queue[lane] = moved;
+        qn = rest;
+
         // ---- this lane's splat for the pass ---------------------------------------------------
-        const int my_idx = hi - pass * DNS_WAVE - lane;
-        const bool has = my_idx >= range_start;
+        const bool has = my_idx >= 0;
         int gid = 0;
         float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
         if (has) {
@@ -141,7 +184,10 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
             if (D > 6) s3 = rec[3];
         }
         const float sx = s0.x, sy = s0.y, ca = s0.z, cb = s0.w, cc = s1.x, opac = s1.y;
-        float ch[8] = {s1.z, s1.w, s2.x, s2.y, s2.z, s2.w, s3.x, s3.y};
+        const DnsConicE qe = dns_conic_e(ca, cb, cc);
+        const float ch[8] = {s1.z, s1.w, s2.x, s2.y, s2.z, s2.w, s3.x, s3.y};
+        // lanes without a splat can never be valid: give them an index above every bin_final
+        const int cmp_idx = has ? my_idx : 0x7fffffff;
 
         float g_x = 0.f, g_y = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_o = 0.f, g_ax = 0.f, g_ay = 0.f;
         float g_ch[8];
@@ -150,63 +196,65 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
         bool touched = false;
 
         float T_out = 0.f, SA_out = 0.f, SB_out = 0.f;
+        // software pipeline: the pixel row of step s+1 is fetched while step s computes
+        int pc = (0 - lane) & (NPIX - 1);
+        float4 pv0 = pix[pc][0], pv1 = pix[pc][1], pst = pix[pc][2];
         for (int s = 0; s < NPIX + DNS_WAVE - 1; ++s) {
             const int p = s - lane;
             const bool active = (unsigned)p < (unsigned)NPIX;
-            const int pc = p & (NPIX - 1);
-            const float4 pv0 = pix[pc][0];
-            const float4 pv1 = pix[pc][1];
-            const float4 pst = pix[pc][2];
-            // state arrives from the previous lane; lane 0 takes it from the pixel's LDS row
-            float T = dpp_wave_shr1(T_out, pst.x);
-            float SA = dpp_wave_shr1(SA_out, pst.y);
-            float SB = dpp_wave_shr1(SB_out, pst.z);
-            const int bin_final = __float_as_int(pst.w);
+            const int pcur = pc;
+            const float4 c0 = pv0, c1 = pv1, cst = pst;
+            pc = (pc + 1) & (NPIX - 1);
+            pv0 = pix[pc][0]; pv1 = pix[pc][1]; pst = pix[pc][2];
 
-            const float dx = sx - (fx0 + (float)(pc & 15));
-            const float dy = sy - (fy0 + (float)(pc >> 4));
-            const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
-            const float vis = __expf(-sigma);
+            // state arrives from the previous lane; lane 0 takes it from the pixel's LDS row
+            float T = dpp_wave_shr1(T_out, cst.x);
+            float SA = dpp_wave_shr1(SA_out, cst.y);
+            float SB = dpp_wave_shr1(SB_out, cst.z);
+            const int bin_final = __float_as_int(cst.w);
+
+            const float dx = sx - (fx0 + (float)(pcur & 15));
+            const float dy = sy - (fy0 + (float)(pcur >> 4));
+            const float e = dns_exponent(qe, dx, dy);
+            const float vis = dns_exp2(e);
             const float ov = opac * vis;
             const float alpha = fminf((float)DNS_ALPHA_MAX, ov);
-            const bool valid = active && has && my_idx <= bin_final && sigma >= 0.f && alpha >= (float)DNS_ALPHA_MIN;
+            const bool valid = active && cmp_idx <= bin_final && e <= 0.f && alpha >= (float)DNS_ALPHA_MIN;
             if (valid) {
                 touched = true;
-                const float pvv[8] = {pv0.x, pv0.y, pv0.z, pv0.w, pv1.x, pv1.y, pv1.z, pv1.w};
-                const float ra = 1.f / (1.f - alpha);
+                const float pvv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
                 T *= ra;
                 const float fac = alpha * T;
                 float cva = 0.f, cvb = 0.f;
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
-                    g_ch[k] += fac * pvv[k];
-                    if (k < a.xy_split) cva += ch[k] * pvv[k]; else cvb += ch[k] * pvv[k];
+                    g_ch[k] = __builtin_fmaf(fac, pvv[k], g_ch[k]);
+                    if (k < split) cva = __builtin_fmaf(ch[k], pvv[k], cva);
+                    else cvb = __builtin_fmaf(ch[k], pvv[k], cvb);
                 }
                 const float va_a = T * cva - ra * SA;
-                const float va_b = T * cvb - ra * SB;
+                const float va_b = (SPLIT == D) ? 0.f : T * cvb - ra * SB;
                 if (ov <= (float)DNS_ALPHA_MAX) {
                     const float va = va_a + va_b;
                     const float vs = -ov * va;
                     const float vs_a = -ov * va_a;
-                    g_ca += 0.5f * vs * dx * dx;
-                    g_cb += vs * dx * dy;
-                    g_cc += 0.5f * vs * dy * dy;
+                    const float hx = vs * dx, hy = vs * dy;
+                    g_ca = __builtin_fmaf(0.5f * hx, dx, g_ca);
+                    g_cb = __builtin_fmaf(hx, dy, g_cb);
+                    g_cc = __builtin_fmaf(0.5f * hy, dy, g_cc);
                     const float gx = vs_a * (ca * dx + cb * dy);
                     const float gy = vs_a * (cb * dx + cc * dy);
                     g_x += gx; g_y += gy;
                     g_ax += fabsf(gx); g_ay += fabsf(gy);
-                    g_o += vis * va;
+                    g_o = __builtin_fmaf(vis, va, g_o);
                 }
-                SA += fac * cva;
-                SB += fac * cvb;
+                SA = __builtin_fmaf(fac, cva, SA);
+                if (SPLIT != D) SB = __builtin_fmaf(fac, cvb, SB);
             }
             T_out = T; SA_out = SA; SB_out = SB;
             // park the state of the pixel leaving the array for the next (nearer) bucket
-            if (lane == DNS_WAVE - 1 && active) {
-                float4 st = pst;
-                st.x = T; st.y = SA; st.z = SB;
-                pix[pc][2] = st;
-            }
+            if (lane == DNS_WAVE - 1 && active) pix[pcur][2] = make_float4(T, SA, SB, cst.w);
         }
 
         // ---- flush: transpose through LDS, one atomic row per touched splat ---------------------
@@ -217,24 +265,33 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
         const uint64_t tmask = __ballot(touched);
         __builtin_amdgcn_wave_barrier();
         const float *fl = reinterpret_cast<const float *>(&flush[0][0]);
+        const int col = lane & 15;
+        const bool col_used = col < REC_CH0 + D || col >= REC_ABSX;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int row = j * 4 + (lane >> 4);
-            const int col = lane & 15;
             const int rgid = __shfl(gid, row, DNS_WAVE);
             const float val = fl[j * 64 + lane];
-            if ((tmask >> row) & 1) unsafeAtomicAdd(a.v_splats + (size_t)rgid * DNS_REC + col, val);
+            if (((tmask >> row) & 1) && col_used) unsafeAtomicAdd(a.v_splats + (size_t)rgid * DNS_REC + col, val);
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-template <int D>
+template <int D, int SPLIT>
 int launch_bwd(const BwdArgs &ba, hipStream_t stream)
 {
-    hipLaunchKernelGGL(raster_bwd_kernel<D>, dim3(ba.n_tiles), dim3(DNS_WAVE), 0, stream, ba);
+    hipLaunchKernelGGL((raster_bwd_kernel<D, SPLIT>), dim3(ba.n_tiles), dim3(DNS_WAVE), 0, stream, ba);
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;
+}
+
+template <int D>
+int dispatch_split(const BwdArgs &ba, hipStream_t stream)
+{
+    if (ba.xy_split == D) return launch_bwd<D, D>(ba, stream);
+    if (D == 7 && ba.xy_split == 4) return launch_bwd<D, (D == 7 ? 4 : D)>(ba, stream);
+    return launch_bwd<D, -1>(ba, stream);
 }
 
 }  // namespace
@@ -245,8 +302,8 @@ extern "C" int dnsplat_raster_bwd(const dnsplat_raster_args *a, dnsplat_stream_t
     if (a->tile_size != TILE) return DNSPLAT_ERR_UNSUPPORTED;
     if (a->D < 1 || a->D > DNSPLAT_MAX_CHANNELS) return DNSPLAT_ERR_UNSUPPORTED;
     if (a->width <= 0 || a->height <= 0) return DNSPLAT_ERR_INVALID_ARG;
-    if (!a->splats || !a->tile_offsets || !a->alphas || !a->last_ids || !a->v_render || !a->v_splats)
-        return DNSPLAT_ERR_INVALID_ARG;
+    // splats / flatten_ids / v_splats are only touched for list entries: NULL is fine when every list is empty (N == 0)
+    if (!a->tile_offsets || !a->alphas || !a->last_ids || !a->v_render) return DNSPLAT_ERR_INVALID_ARG;
     if (a->ed_channel >= a->D || (a->ed_channel >= 0 && !a->render)) return DNSPLAT_ERR_INVALID_ARG;
     if (a->xy_split < 0 || a->xy_split > a->D) return DNSPLAT_ERR_INVALID_ARG;
     BwdArgs ba;
@@ -264,14 +321,14 @@ extern "C" int dnsplat_raster_bwd(const dnsplat_raster_args *a, dnsplat_stream_t
     ba.v_splats = a->v_splats;
     hipStream_t stream = (hipStream_t)stream_;
     switch (a->D) {
-        case 1: return launch_bwd<1>(ba, stream);
-        case 2: return launch_bwd<2>(ba, stream);
-        case 3: return launch_bwd<3>(ba, stream);
-        case 4: return launch_bwd<4>(ba, stream);
-        case 5: return launch_bwd<5>(ba, stream);
-        case 6: return launch_bwd<6>(ba, stream);
-        case 7: return launch_bwd<7>(ba, stream);
-        case 8: return launch_bwd<8>(ba, stream);
+        case 1: return dispatch_split<1>(ba, stream);
+        case 2: return dispatch_split<2>(ba, stream);
+        case 3: return dispatch_split<3>(ba, stream);
+        case 4: return dispatch_split<4>(ba, stream);
+        case 5: return dispatch_split<5>(ba, stream);
+        case 6: return dispatch_split<6>(ba, stream);
+        case 7: return dispatch_split<7>(ba, stream);
+        case 8: return dispatch_split<8>(ba, stream);
     }
     return DNSPLAT_ERR_UNSUPPORTED;
 }

@@ -67,6 +67,9 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_fwd_kernel(FwdArgs a)
     bool done0 = !in0, done1 = !in1;
 
     float4(*my)[4] = lds[wave];
+    // pixel-centre rectangle of this wave's 16x8 half tile, for the per-splat cull test
+    const float rxl = (float)(tile_x * TILE) + 0.5f, rxh = rxl + 15.f;
+    const float ryl = (float)(tile_y * TILE + wave * 8) + 0.5f, ryh = ryl + 7.f;
 
     // prefetch batch 0
     float4 r0, r1, r2, r3;
@@ -75,16 +78,28 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_fwd_kernel(FwdArgs a)
         if (idx < range_end) {
             const int g = a.flatten_ids[idx];
             const float4 *rec = a.splats + (size_t)g * 4;
-            r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
+            r0 = rec[0]; r1 = rec[1];
+            if (D > 2) r2 = rec[2];
+            if (D > 6) r3 = rec[3];
         }
     }
 
     for (int batch_start = range_start; batch_start < range_end; batch_start += DNS_WAVE) {
         if (!__any(!(done0 && done1))) break;
-        // stage the prefetched records (waits for the gather here), then start the next gather
-        my[lane][0] = r0; my[lane][1] = r1;
-        if (D > 2) my[lane][2] = r2;
-        if (D > 6) my[lane][3] = r3;
+        // Splats that cannot reach alpha >= 1/255 anywhere in the half tile are dropped here, once per
+        // (wave, splat), instead of being rejected 128 times by the per-pixel test.
+        const bool keep = (batch_start + lane < range_end) &&
+                          !dns_cull_rect(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rxl, rxh, ryl, ryh);
+        uint64_t todo = __ballot(keep);
+        // stage the prefetched records (waits for the gather here) with the conic pre-scaled for exp2,
+        // then start the next gather
+        {
+            const DnsConicE q = dns_conic_e(r0.z, r0.w, r1.x);
+            my[lane][0] = make_float4(r0.x, r0.y, q.na, q.nb);
+            my[lane][1] = make_float4(q.nc, r1.y, r1.z, r1.w);
+            if (D > 2) my[lane][2] = r2;
+            if (D > 6) my[lane][3] = r3;
+        }
         {
             const int idx = batch_start + DNS_WAVE + lane;
             if (idx < range_end) {
@@ -96,19 +111,21 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_fwd_kernel(FwdArgs a)
             }
         }
         __builtin_amdgcn_wave_barrier();
-        const int batch_size = min(DNS_WAVE, range_end - batch_start);
-        for (int t = 0; t < batch_size; ++t) {
-            const float4 g0 = my[t][0];  // x y a b
-            const float4 g1 = my[t][1];  // c opac ch0 ch1
+        while (todo) {
+            const int t = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const float4 g0 = my[t][0];  // x y na nb
+            const float4 g1 = my[t][1];  // nc opac ch0 ch1
+            DnsConicE q;
+            q.na = g0.z; q.nb = g0.w; q.nc = g1.x;
             const float dx = g0.x - px;
             const float dy0 = g0.y - py0, dy1 = g0.y - py1;
-            const float adx2 = g0.z * dx * dx, bdx = g0.w * dx;
-            const float sigma0 = 0.5f * (adx2 + g1.x * dy0 * dy0) + bdx * dy0;
-            const float sigma1 = 0.5f * (adx2 + g1.x * dy1 * dy1) + bdx * dy1;
-            const float alpha0 = fminf((float)DNS_ALPHA_MAX, g1.y * __expf(-sigma0));
-            const float alpha1 = fminf((float)DNS_ALPHA_MAX, g1.y * __expf(-sigma1));
-            bool c0 = !done0 && sigma0 >= 0.f && alpha0 >= (float)DNS_ALPHA_MIN;
-            bool c1 = !done1 && sigma1 >= 0.f && alpha1 >= (float)DNS_ALPHA_MIN;
+            const float e0 = dns_exponent(q, dx, dy0);
+            const float e1 = dns_exponent(q, dx, dy1);
+            const float alpha0 = fminf((float)DNS_ALPHA_MAX, g1.y * dns_exp2(e0));
+            const float alpha1 = fminf((float)DNS_ALPHA_MAX, g1.y * dns_exp2(e1));
+            bool c0 = !done0 && e0 <= 0.f && alpha0 >= (float)DNS_ALPHA_MIN;
+            bool c1 = !done1 && e1 <= 0.f && alpha1 >= (float)DNS_ALPHA_MIN;
             const float nT0 = T0 * (1.f - alpha0), nT1 = T1 * (1.f - alpha1);
             if (c0 && nT0 <= (float)DNS_T_MIN) { done0 = true; c0 = false; }
             if (c1 && nT1 <= (float)DNS_T_MIN) { done1 = true; c1 = false; }
@@ -174,7 +191,8 @@ extern "C" int dnsplat_raster_fwd(const dnsplat_raster_args *a, dnsplat_stream_t
     if (a->tile_size != TILE) return DNSPLAT_ERR_UNSUPPORTED;
     if (a->D < 1 || a->D > DNSPLAT_MAX_CHANNELS) return DNSPLAT_ERR_UNSUPPORTED;
     if (a->width <= 0 || a->height <= 0) return DNSPLAT_ERR_INVALID_ARG;
-    if (!a->splats || !a->tile_offsets || !a->render || !a->alphas || !a->last_ids) return DNSPLAT_ERR_INVALID_ARG;
+    // splats / flatten_ids are only dereferenced for list entries: both may be NULL when every tile list is empty (N == 0)
+    if (!a->tile_offsets || !a->render || !a->alphas || !a->last_ids) return DNSPLAT_ERR_INVALID_ARG;
     if (a->ed_channel >= a->D) return DNSPLAT_ERR_INVALID_ARG;
     FwdArgs fa;
     fa.width = a->width; fa.height = a->height;

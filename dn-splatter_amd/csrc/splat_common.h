@@ -60,3 +60,66 @@ __device__ __forceinline__ int dns_xcd_remap(int b, int n)
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + k;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Compositing math shared by the forward and backward kernels, so that both take bit-identical
+// decisions on (pixel, splat) pairs:
+//     sigma = 1/2 (a dx^2 + c dy^2) + b dx dy,  vis = exp(-sigma),  alpha = min(0.999, o vis),
+//     pair skipped if sigma < 0 or alpha < 1/255.
+// The exponent is evaluated as exp2 of a pre-scaled quadratic form: e = -log2(e) * sigma with the
+// scaling folded into the three conic coefficients once per splat (3 multiplies per splat instead of
+// one per pair).  The fused-multiply-add sequence is spelled out so that compiler contraction
+// cannot make the two kernels round differently.
+#define DNS_LOG2E 1.4426950408889634f
+
+struct DnsConicE {
+    float na, nb, nc;  // -log2e/2 * a, -log2e * b, -log2e/2 * c
+};
+
+__device__ __forceinline__ DnsConicE dns_conic_e(float ca, float cb, float cc)
+{
+    DnsConicE q;
+    q.na = (-0.5f * DNS_LOG2E) * ca;
+    q.nb = (-DNS_LOG2E) * cb;
+    q.nc = (-0.5f * DNS_LOG2E) * cc;
+    return q;
+}
+
+// e = -log2e * sigma  (<= 0 for a valid pair)
+__device__ __forceinline__ float dns_exponent(const DnsConicE &q, float dx, float dy)
+{
+    const float u = __builtin_fmaf(q.na, dx, q.nb * dy);
+    return __builtin_fmaf(dx, u, (q.nc * dy) * dy);
+}
+
+__device__ __forceinline__ float dns_exp2(float e) { return __builtin_amdgcn_exp2f(e); }
+
+// Conservative test "no pixel centre of the rectangle [xl,xh] x [yl,yh] can pass alpha >= 1/255 for this
+// splat".  The exact minimum of the quadratic form over the rectangle (it lies on the edge(s) nearest to
+// the mean when the mean is outside) is compared with ln(255 o) plus a safety margin that dominates the
+// fp32 rounding of the per-pixel evaluation, so a culled splat is one the per-pixel test would have
+// skipped for every pixel: skipping it changes no result bit.  NaNs compare false => keep.
+__device__ __forceinline__ bool dns_cull_rect(float sx, float sy, float ca, float cb, float cc, float opac,
+                                              float xl, float xh, float yl, float yh)
+{
+    const float dxl = sx - xh, dxh = sx - xl, dyl = sy - yh, dyh = sy - yl;
+    const float X = fminf(fmaxf(0.f, dxl), dxh);  // point of [dxl,dxh] nearest to 0
+    const float Y = fminf(fmaxf(0.f, dyl), dyh);
+    float smin = 0.f, pos = 0.f;
+    if (X != 0.f || Y != 0.f) {
+        float sxe = 3.0e38f, sye = 3.0e38f, pxe = 0.f, pye = 0.f;
+        if (X != 0.f) {
+            const float dy = fminf(fmaxf(-cb * X / cc, dyl), dyh);
+            pxe = 0.5f * (ca * X * X + cc * dy * dy);
+            sxe = pxe + cb * X * dy;
+        }
+        if (Y != 0.f) {
+            const float dx = fminf(fmaxf(-cb * Y / ca, dxl), dxh);
+            pye = 0.5f * (ca * dx * dx + cc * Y * Y);
+            sye = pye + cb * dx * Y;
+        }
+        if (sxe < sye) { smin = sxe; pos = pxe; } else { smin = sye; pos = pye; }
+    }
+    const float tau = __logf(255.f * opac);
+    return smin > tau + 0.02f + 1e-5f * pos;
+}

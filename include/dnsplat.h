@@ -157,7 +157,7 @@ int dnsplat_bin_isect_ids(int32_t n_tiles, const int32_t *tile_offsets, const in
 typedef struct dnsplat_raster_args {
     int32_t width, height, tile_size;   /* tile_size must be 16 */
     int32_t D;                          /* feature channels, 1..8 */
-    const float *splats;                /* [N,16] */
+    const float *splats;                /* [N,16]; splats, flatten_ids and v_splats may be NULL iff every tile list is empty */
     const int32_t *flatten_ids;
     const int32_t *tile_offsets;        /* [n_tiles+1] */
     const float *background;            /* device [D] or NULL (gsplat v1: none; legacy normal pass: ones) */

@@ -28,13 +28,35 @@ def rel_err(a, b) -> float:
     return (a - b).abs().max().item() / (scale + 1e-30)
 
 
-def assert_close(a, b, what, tol=REL_TOL):
+# The compositing rule has two hard cut-offs (skip a pair if alpha < 1/255; stop a pixel when T(1-alpha) <=
+# 1e-4).  Two fp32 implementations whose exp() differ in the last ulp (libm expf in the oracle,
+# v_exp_f32 on the GPU, ex2.approx in gsplat's CUDA) take the other side of a cut-off for a handful of
+# (pixel, splat) pairs per frame; each flip moves one pixel's contribution (up to ~1e-3 of the tensor scale
+# for faint, wide Gaussians).  Scenes with scattered opacities therefore allow a FLIP_FRACTION of entries to
+# exceed REL_TOL, bounded by FLIP_TOL; the BASELINE scenes (opacity 0.1 everywhere) are held to REL_TOL strictly.
+FLIP_FRACTION = 1e-3
+FLIP_TOL = 5e-3
+
+
+def assert_close(a, b, what, tol=REL_TOL, atol=0.0, flips=0.0):
+    """max|a-b| <= tol * max|b| + atol for all entries (all but a fraction ``flips``, themselves <= FLIP_TOL).
+    ``atol`` is only for tensors that are mathematically zero (e.g. the quaternion gradient of isotropic
+    Gaussians), where both sides hold nothing but fp32 rounding noise."""
     a_ = a.detach().cpu()
     b_ = b.detach().cpu()
     assert a_.shape == b_.shape, f"{what}: shape {tuple(a_.shape)} vs {tuple(b_.shape)}"
     assert torch.isfinite(a_.float()).all(), f"{what}: non-finite values"
-    e = rel_err(a_, b_)
-    assert e <= tol, f"{what}: scale-relative error {e:.3e} > {tol:.1e}"
+    if b_.numel() == 0:
+        return
+    scale = b_.double().abs().max().item()
+    d = (a_.double() - b_.double()).abs().reshape(-1)
+    err = d.max().item()
+    if flips > 0.0:
+        n_bad = int((d > tol * scale + atol).sum())
+        assert n_bad <= max(1, int(flips * d.numel())), f"{what}: {n_bad} of {d.numel()} entries beyond {tol:.1e} * {scale:.3e}"
+        assert err <= FLIP_TOL * scale + atol, f"{what}: max abs error {err:.3e} > {FLIP_TOL:.1e} * scale {scale:.3e}"
+        return
+    assert err <= tol * scale + atol, f"{what}: max abs error {err:.3e} > {tol:.1e} * scale {scale:.3e} + {atol:.1e}"
 
 
 def assert_equal_int(a, b, what):
