@@ -62,6 +62,26 @@ struct BwdArgs {
     float *__restrict__ v_splats;
 };
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// One pixel row (48 bytes) of the LDS table as three ds_read_b128.  Left to itself hipcc scalarises the
+// row (its fields are carried across the loop back-edge one by one) and re-merges it into
+// ds_read_b32 / ds_read2_b32, which at a 48-byte lane stride are 4-way bank conflicted (measured: 63 % of
+// all LDS cycles of this kernel were conflict cycles).  ds_read_b128 at that stride is conflict-free
+// (MI355X_MICROARCH.md, LDS lane groups).  The loads are issued here and waited for in row_wait(), which
+// ties the destination registers to the s_waitcnt so that no use can be scheduled above it.
+__device__ __forceinline__ void row_issue(uint32_t byte_addr, v4f &r0, v4f &r1, v4f &r2)
+{
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+                 : "v"(byte_addr)
+                 : "memory");
+}
+__device__ __forceinline__ void row_wait(v4f &r0, v4f &r1, v4f &r2)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2) : : "memory");
+}
+
 __device__ __forceinline__ float dpp_wave_shr1(float from_prev, float lane0_value)
 {
     // lane l receives `from_prev` of lane l-1; lane 0 (no source) keeps `lane0_value`
@@ -196,27 +216,27 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
         bool touched = false;
 
         float T_out = 0.f, SA_out = 0.f, SB_out = 0.f;
-        // software pipeline: the pixel row of step s+1 is fetched while step s computes
-        int pc = (0 - lane) & (NPIX - 1);
-        float4 pv0 = pix[pc][0], pv1 = pix[pc][1], pst = pix[pc][2];
+        // The pixel row of the step is requested first and waited for only after the row-independent part
+        // (pixel coordinates, exponent, exp2) has been issued, which covers the LDS latency.
+        const uint32_t pix_base = (uint32_t)(uintptr_t)&pix[0][0];   // LDS byte address of the table
         for (int s = 0; s < NPIX + DNS_WAVE - 1; ++s) {
             const int p = s - lane;
             const bool active = (unsigned)p < (unsigned)NPIX;
-            const int pcur = pc;
-            const float4 c0 = pv0, c1 = pv1, cst = pst;
-            pc = (pc + 1) & (NPIX - 1);
-            pv0 = pix[pc][0]; pv1 = pix[pc][1]; pst = pix[pc][2];
-
-            // state arrives from the previous lane; lane 0 takes it from the pixel's LDS row
-            float T = dpp_wave_shr1(T_out, cst.x);
-            float SA = dpp_wave_shr1(SA_out, cst.y);
-            float SB = dpp_wave_shr1(SB_out, cst.z);
-            const int bin_final = __float_as_int(cst.w);
+            const int pcur = p & (NPIX - 1);
+            v4f c0, c1, cst;
+            row_issue(pix_base + pcur * 48, c0, c1, cst);
 
             const float dx = sx - (fx0 + (float)(pcur & 15));
             const float dy = sy - (fy0 + (float)(pcur >> 4));
             const float e = dns_exponent(qe, dx, dy);
             const float vis = dns_exp2(e);
+
+            row_wait(c0, c1, cst);
+            // state arrives from the previous lane; lane 0 takes it from the pixel's LDS row
+            float T = dpp_wave_shr1(T_out, cst.x);
+            float SA = dpp_wave_shr1(SA_out, cst.y);
+            float SB = dpp_wave_shr1(SB_out, cst.z);
+            const int bin_final = __float_as_int(cst.w);
             const float ov = opac * vis;
             const float alpha = fminf((float)DNS_ALPHA_MAX, ov);
             const bool valid = active && cmp_idx <= bin_final && e <= 0.f && alpha >= (float)DNS_ALPHA_MIN;

@@ -113,3 +113,12 @@ def test_product_refuses_cpu_tensors_and_never_imports_the_oracle(dns):
             assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), fn
     code = "import sys; sys.path.insert(0, %r); import dn_splatter_amd; assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'" % ROOT
     subprocess.run([sys.executable, "-c", code], check=True)
+
+
+def test_hand_placed_lds_loads_are_not_touched_before_their_wait():
+    """raster_bwd.hip issues ds_read_b128 by hand and waits later (see row_issue/row_wait): the generated ISA
+    must not read or copy the destination registers in between."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_asm_hazards
+
+    assert check_asm_hazards.check() == 0

@@ -1,0 +1,19 @@
+"""Summarise rocprofv3 --pmc CSVs (gpurun_out/pmc/*/p_counter_collection.csv) per kernel, averaged per launch."""
+import collections, csv, glob, json, re, sys
+root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
+names = ["raster_bwd_kernel", "raster_fwd_kernel", "project_bwd_kernel", "project_fwd_kernel", "radix_scatter_kernel",
+         "radix_hist_kernel", "emit_kernel", "radix_scan_kernel", "tile_offsets_kernel", "postops"]
+out = {}
+for f in sorted(glob.glob(root + "/*/p_counter_collection.csv")):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); ids = collections.defaultdict(set)
+    meta = {}
+    for row in csv.DictReader(open(f)):
+        k = next((n for n in names if n in row["Kernel_Name"]), None)
+        if k is None: continue
+        acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); ids[k].add(row["Dispatch_Id"])
+        meta[k] = dict(VGPR=row["VGPR_Count"], SGPR=row["SGPR_Count"], LDS=row["LDS_Block_Size"], grid=row["Grid_Size"], wg=row["Workgroup_Size"])
+    for k in acc:
+        n = len(ids[k])
+        out.setdefault(k, {}).update({c: v / n for c, v in acc[k].items()})
+        out[k]["launches_seen"] = n; out[k].update(meta[k])
+print(json.dumps(out, indent=1))
