@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bin-policy", default="capacity", choices=["sync", "capacity"])
     ap.add_argument("--two-call", action="store_true", help="reference's two-pass sequence instead of the fused pass")
+    ap.add_argument("--torch-postops", action="store_true", help="keep dn_model.py:526-603 in torch instead of the HIP epilogue")
     args = ap.parse_args()
 
     import dn_splatter_amd as dns
@@ -122,7 +123,7 @@ def main():
     # identical parameters on every rank (seed 0), one camera per rank (8-view orbit)
     gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=0, device=dev)
     cam = synthetic.orbit_camera(rank % 8, n_views=8, width=W, height=H, focal=focal).to(dev)
-    renderer = dns.DNSplatterRenderer(gp, fused=not args.two_call)
+    renderer = dns.DNSplatterRenderer(gp, fused=not args.two_call, fused_postops=not args.torch_postops)
     dns.set_bin_policy(args.bin_policy)
     arena = dp.GradArena(gp)
     dns.set_grad_arena(arena)
@@ -134,8 +135,8 @@ def main():
         for k in dp.GRAD_KEYS:
             gp[k].grad = None
         out = renderer.get_outputs(cam)
-        loss = sum((out[k] * cot[k]).sum() for k in OUT_KEYS)
-        loss.backward()
+        # the losses stay in PyTorch (north star); their result is a dense cotangent per output image
+        torch.autograd.backward([out[k] for k in OUT_KEYS], [cot[k] for k in OUT_KEYS])
         return dp.allreduce_gradients(gp, arena)
 
     for _ in range(args.warmup):
@@ -201,7 +202,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {N} random-init Gaussians, 1 camera/GPU {W}x{H}, SH degree 3 + "
                                    f"expected depth + per-Gaussian normals ({D_CH} channels, "
-                                   f"{'two-call' if args.two_call else 'fused one-pass'}), fx=fy={focal}, orbit r=8, "
+                                   f"{'two-call' if args.two_call else 'fused one-pass'}, post-ops in {'torch' if (args.torch_postops or args.two_call) else 'HIP'}), fx=fy={focal}, orbit r=8, "
                                    f"closed-form 3-NN scale init",
                        "N": N, "Nv": Nv, "n_isects": I, "mean_isects_per_rank": i_all / world,
                        "mean_tile_list_len": round(I / T, 1), "pixels": P, "bin_policy": args.bin_policy,

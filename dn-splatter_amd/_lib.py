@@ -15,7 +15,7 @@ _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "libdnsplat.so"
 CSRC_DIR = _PKG_DIR / "csrc"
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 RECORD_FLOATS = 16
 MAX_CHANNELS = 8
 
@@ -65,6 +65,14 @@ class BinArgs(ctypes.Structure):
     ]
 
 
+class DnPost(ctypes.Structure):
+    _fields_ = [
+        ("background_rgb", c_void_p), ("rgb", c_void_p), ("depth", c_void_p), ("normal", c_void_p),
+        ("depth_max", c_void_p),
+        ("v_rgb", c_void_p), ("v_depth", c_void_p), ("v_normal", c_void_p), ("v_accumulation", c_void_p),
+    ]
+
+
 class RasterArgs(ctypes.Structure):
     _fields_ = [
         ("width", c_int32), ("height", c_int32), ("tile_size", c_int32), ("D", c_int32),
@@ -74,6 +82,7 @@ class RasterArgs(ctypes.Structure):
         ("v_render", c_void_p), ("v_alphas", c_void_p),
         ("xy_split", c_int32),
         ("v_splats", c_void_p),
+        ("dn", ctypes.POINTER(DnPost)),
     ]
 
 
@@ -94,6 +103,7 @@ EXPORTS = [
     "dnsplat_project_fwd", "dnsplat_pack_splats",
     "dnsplat_bin_workspace_bytes", "dnsplat_bin_prepare", "dnsplat_bin_emit_sort", "dnsplat_bin_isect_ids",
     "dnsplat_raster_fwd", "dnsplat_raster_bwd",
+    "dnsplat_dn_depth_normals", "dnsplat_camera_prepare",
     "dnsplat_project_bwd",
 ]
 
@@ -133,6 +143,10 @@ def lib() -> ctypes.CDLL:
         L.dnsplat_bin_isect_ids.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
         L.dnsplat_raster_fwd.argtypes = [ctypes.POINTER(RasterArgs), c_void_p]
         L.dnsplat_raster_bwd.argtypes = [ctypes.POINTER(RasterArgs), c_void_p]
+        L.dnsplat_dn_depth_normals.argtypes = [c_int32, c_int32, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p]
+        L.dnsplat_camera_prepare.argtypes = [c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                             c_void_p]
         if L.dnsplat_abi_version() != ABI_VERSION:
             raise DnsplatError(f"libdnsplat ABI {L.dnsplat_abi_version()} != binding {ABI_VERSION}; rebuild")
         _lib = L

@@ -19,7 +19,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import BinArgs, Camera, ProjGrads, ProjOut, RasterArgs, Scene, RECORD_FLOATS
+from ._lib import BinArgs, Camera, DnPost, ProjGrads, ProjOut, RasterArgs, Scene, RECORD_FLOATS
 
 
 def _ptr(t: Optional[Tensor]):
@@ -458,6 +458,117 @@ def rasterize(means2d, splats, depths, radii, tiles, *, background=None, width, 
     render, alphas = _RasterFn.apply(means2d, splats, depths, radii, tiles, background, width, height, tile_size, D,
                                      ed_channel, xy_split, absgrad, holder)
     return render, alphas
+
+
+_BG7: Dict[torch.device, Tensor] = {}
+
+
+def _bg7(device) -> Tensor:
+    """Kernel-level background of the fused pass: none for rgb | depth, ones for the normal channels (the
+    legacy gsplat.rasterize_gaussians default, dn_model.py:564-575 passes no background)."""
+    t = _BG7.get(device)
+    if t is None:
+        t = torch.tensor([0.0, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0], device=device)
+        _BG7[device] = t
+    return t
+
+
+class _RasterDnFn(torch.autograd.Function):
+    """Bins, composites the 7 fused channels AND applies dn-splatter's per-pixel post-ops in the same
+    kernels (``dnsplat_dn_post``): returns the images ``get_outputs`` hands out — rgb, depth (filled),
+    normal, accumulation, surface_normal — instead of the raw composite."""
+
+    @staticmethod
+    def forward(ctx, means2d, splats, depths, radii, tiles, bg_rgb, width, height, intr, absgrad, holder):
+        dev = splats.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        render = torch.empty(height, width, 7, **f32)
+        alphas = torch.empty(height, width, **f32)
+        last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
+        rgb = torch.empty(height, width, 3, **f32)
+        depth_raw = torch.empty(height, width, **f32)
+        normal = torch.empty(height, width, 3, **f32)
+        depth_max = torch.zeros(1, **f32)
+        depth_out = torch.empty(height, width, 1, **f32)
+        surface_normal = torch.empty(height, width, 3, **f32)
+        bg_rgb = _f32c(bg_rgb, "background")
+        bg7 = _bg7(dev)
+        dn = DnPost()
+        dn.background_rgb, dn.rgb, dn.depth, dn.normal = _ptr(bg_rgb), _ptr(rgb), _ptr(depth_raw), _ptr(normal)
+        dn.depth_max = _ptr(depth_max)
+
+        def composite(b: Binning):
+            depth_max.zero_()
+            a = RasterArgs()
+            a.width, a.height, a.tile_size, a.D = width, height, 16, 7
+            a.splats, a.flatten_ids, a.tile_offsets = _ptr(splats), _ptr(b.flatten_ids), _ptr(b.tile_offsets)
+            a.background = _ptr(bg7)
+            a.ed_channel = 3
+            a.render, a.alphas, a.last_ids = _ptr(render), _ptr(alphas), _ptr(last_ids)
+            a.dn = ctypes.pointer(dn)
+            _lib.run("dnsplat_raster_fwd", _lib.lib().dnsplat_raster_fwd, ctypes.byref(a), _stream())
+
+        b = bin_tiles(means2d.detach().reshape(-1, 2), radii, depths.detach().reshape(-1), tiles, width, height, 16,
+                      after_emit=composite)
+        fx, fy, cx, cy = intr
+        _lib.run("dnsplat_dn_depth_normals", _lib.lib().dnsplat_dn_depth_normals, width, height, fx, fy, cx, cy,
+                 _ptr(depth_raw), _ptr(alphas), _ptr(depth_max), _ptr(depth_out), _ptr(surface_normal), _stream())
+        if holder is not None:
+            holder["binning"] = b
+        ctx.save_for_backward(means2d, splats, b.flatten_ids, b.tile_offsets, render, alphas, last_ids, bg_rgb)
+        ctx.cfg = (width, height, absgrad)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(surface_normal)
+        return rgb, depth_out, normal, alphas.unsqueeze(-1), surface_normal
+
+    @staticmethod
+    def backward(ctx, v_rgb, v_depth, v_normal, v_acc, _v_sn):
+        means2d, splats, flatten_ids, tile_offsets, render, alphas, last_ids, bg_rgb = ctx.saved_tensors
+        width, height, absgrad = ctx.cfg
+        N = splats.shape[0]
+        dev = splats.device
+        v_splats = torch.zeros(N, RECORD_FLOATS, dtype=torch.float32, device=dev)
+        none = (None,) * 9
+        if v_rgb is None and v_depth is None and v_normal is None and v_acc is None:
+            return (v_splats[:, 0:2].view(means2d.shape), v_splats) + none
+        z = lambda t, c: torch.zeros(height, width, c, dtype=torch.float32, device=dev) if t is None else t.contiguous()  # noqa: E731
+        v_rgb, v_depth, v_normal = z(v_rgb, 3), z(v_depth, 1), z(v_normal, 3)
+        v_acc = v_acc.contiguous() if v_acc is not None else None
+        dn = DnPost()
+        dn.background_rgb = _ptr(bg_rgb)
+        dn.v_rgb, dn.v_depth, dn.v_normal, dn.v_accumulation = _ptr(v_rgb), _ptr(v_depth), _ptr(v_normal), _ptr(v_acc)
+        a = RasterArgs()
+        a.width, a.height, a.tile_size, a.D = width, height, 16, 7
+        a.splats, a.flatten_ids, a.tile_offsets = _ptr(splats), _ptr(flatten_ids), _ptr(tile_offsets)
+        a.background = _ptr(_bg7(dev))
+        a.ed_channel = 3
+        a.render, a.alphas, a.last_ids = _ptr(render), _ptr(alphas), _ptr(last_ids)
+        a.xy_split = 4
+        a.v_splats = _ptr(v_splats)
+        a.dn = ctypes.pointer(dn)
+        _lib.run("dnsplat_raster_bwd", _lib.lib().dnsplat_raster_bwd, ctypes.byref(a), _stream())
+        if absgrad:
+            means2d.absgrad = v_splats[:, 14:16].reshape(means2d.shape)
+        return (v_splats[:, 0:2].view(means2d.shape), v_splats) + none
+
+
+def rasterize_dn(means2d, splats, depths, radii, tiles, *, background_rgb, width, height, intrinsics, absgrad=True,
+                 holder=None):
+    """-> rgb[H,W,3], depth[H,W,1], normal[H,W,3], accumulation[H,W,1], surface_normal[H,W,3]"""
+    return _RasterDnFn.apply(means2d, splats, depths, radii, tiles, background_rgb, width, height, intrinsics, absgrad,
+                             holder)
+
+
+def camera_prepare(c2w: Tensor, fx: float, fy: float, cx: float, cy: float, with_normal_frame: bool = True):
+    """One-launch replacement of get_viewmat + intrinsics + normal frame (dn_model.py:475-479, 550-560).
+    ``c2w`` [3,4] (or [1,3,4]) on the GPU -> viewmat[4,4], K[3,3], normal_frame[12] | None."""
+    c2w = _f32c(c2w.reshape(-1)[:12], "camera_to_worlds")
+    dev = c2w.device
+    out = torch.empty(16 + 9 + 12, dtype=torch.float32, device=dev)
+    viewmat, K, nf = out[:16], out[16:25], out[25:37]
+    _lib.run("dnsplat_camera_prepare", _lib.lib().dnsplat_camera_prepare, _ptr(c2w), fx, fy, cx, cy, _ptr(viewmat), _ptr(K),
+             _ptr(nf) if with_normal_frame else None, _stream())
+    return viewmat.view(4, 4), K.view(3, 3), (nf if with_normal_frame else None)
 
 
 class _PackFn(torch.autograd.Function):

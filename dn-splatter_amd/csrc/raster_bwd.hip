@@ -60,6 +60,12 @@ struct BwdArgs {
     const float *__restrict__ v_alphas;
     int xy_split;
     float *__restrict__ v_splats;
+    // fused dn-splatter epilogue (DN instantiation only): cotangents of rgb / filled depth / normal / accumulation
+    const float *__restrict__ bg_rgb;
+    const float *__restrict__ dn_v_rgb;
+    const float *__restrict__ dn_v_depth;
+    const float *__restrict__ dn_v_normal;
+    const float *__restrict__ dn_v_acc;
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -90,7 +96,7 @@ __device__ __forceinline__ float dpp_wave_shr1(float from_prev, float lane0_valu
 }
 
 // SPLIT >= 0: compile-time split; SPLIT < 0: run-time a.xy_split
-template <int D, int SPLIT>
+template <int D, int SPLIT, bool DN>
 __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
 {
     __shared__ float4 pix[NPIX][3];            // [p][0..1] = v_k, [p][2] = (T, S_a, S_b, bin_final)
@@ -116,7 +122,45 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
         for (int k = 0; k < 8; ++k) v[k] = 0.f;
         float T_final = 1.f, sa = 0.f, sb = 0.f;
         int bin_final = -1;
-        if (xi < a.width && yi < a.height) {
+        if (DN && xi < a.width && yi < a.height) {
+            // cotangents of the dn-splatter images -> cotangents of the raw composite (backward of
+            // dn_model.py:526-537, 577-578; forward twin: dn_epilogue in raster_fwd.hip)
+            const size_t pid = (size_t)yi * a.width + xi;
+            const float al = a.alphas[pid];
+            T_final = 1.f - al;
+            bin_final = a.last_ids[pid];
+            float raw[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) raw[k] = a.render[pid * 7 + k];
+            float va = a.dn_v_acc ? a.dn_v_acc[pid] : 0.f;
+            const float one_minus = 1.f - al;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float bg = a.bg_rgb[c];
+                const float pre = raw[c] + one_minus * bg;
+                const float g = (pre >= 0.f && pre <= 1.f) ? a.dn_v_rgb[pid * 3 + c] : 0.f;   // clamp(0,1)
+                v[c] = g;
+                va -= bg * g;                                                                 // (1 - alpha) * background
+            }
+            {
+                const float vd = al > 0.f ? a.dn_v_depth[pid] : 0.f;                          // where(alpha > 0, depth, max)
+                const float inv = 1.f / fmaxf(al, (float)DNS_ED_ALPHA_FLOOR);
+                v[3] = vd * inv;
+                if (al >= (float)DNS_ED_ALPHA_FLOOR) va -= raw[3] * vd * inv;
+            }
+            {
+                const float nx = raw[4], ny = raw[5], nz = raw[6];
+                const float inrm = 1.f / sqrtf(nx * nx + ny * ny + nz * nz);
+                const float hx = nx * inrm, hy = ny * inrm, hz = nz * inrm;
+                const float gx = 0.5f * a.dn_v_normal[pid * 3], gy = 0.5f * a.dn_v_normal[pid * 3 + 1],
+                            gz = 0.5f * a.dn_v_normal[pid * 3 + 2];                            // (n_hat + 1) / 2
+                const float dot = hx * gx + hy * gy + hz * gz;
+                v[4] = (gx - hx * dot) * inrm; v[5] = (gy - hy * dot) * inrm; v[6] = (gz - hz * dot) * inrm;
+            }
+            sa = -T_final * va;                       // rgb/depth carry no kernel-level background
+            sb = T_final * (v[4] + v[5] + v[6]);      // the legacy normal pass composites over ones
+            if (al <= 0.f) bin_final = -1;
+        } else if (xi < a.width && yi < a.height) {
             const size_t pid = (size_t)yi * a.width + xi;
 #pragma unroll
             for (int k = 0; k < D; ++k) v[k] = a.v_render[pid * D + k];
@@ -298,10 +342,10 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
     }
 }
 
-template <int D, int SPLIT>
+template <int D, int SPLIT, bool DN = false>
 int launch_bwd(const BwdArgs &ba, hipStream_t stream)
 {
-    hipLaunchKernelGGL((raster_bwd_kernel<D, SPLIT>), dim3(ba.n_tiles), dim3(DNS_WAVE), 0, stream, ba);
+    hipLaunchKernelGGL((raster_bwd_kernel<D, SPLIT, DN>), dim3(ba.n_tiles), dim3(DNS_WAVE), 0, stream, ba);
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;
 }
@@ -323,7 +367,7 @@ extern "C" int dnsplat_raster_bwd(const dnsplat_raster_args *a, dnsplat_stream_t
     if (a->D < 1 || a->D > DNSPLAT_MAX_CHANNELS) return DNSPLAT_ERR_UNSUPPORTED;
     if (a->width <= 0 || a->height <= 0) return DNSPLAT_ERR_INVALID_ARG;
     // splats / flatten_ids / v_splats are only touched for list entries: NULL is fine when every list is empty (N == 0)
-    if (!a->tile_offsets || !a->alphas || !a->last_ids || !a->v_render) return DNSPLAT_ERR_INVALID_ARG;
+    if (!a->tile_offsets || !a->alphas || !a->last_ids || (!a->v_render && !a->dn)) return DNSPLAT_ERR_INVALID_ARG;
     if (a->ed_channel >= a->D || (a->ed_channel >= 0 && !a->render)) return DNSPLAT_ERR_INVALID_ARG;
     if (a->xy_split < 0 || a->xy_split > a->D) return DNSPLAT_ERR_INVALID_ARG;
     BwdArgs ba;
@@ -339,7 +383,16 @@ extern "C" int dnsplat_raster_bwd(const dnsplat_raster_args *a, dnsplat_stream_t
     ba.v_render = a->v_render; ba.v_alphas = a->v_alphas;
     ba.xy_split = a->xy_split;
     ba.v_splats = a->v_splats;
+    ba.bg_rgb = ba.dn_v_rgb = ba.dn_v_depth = ba.dn_v_normal = ba.dn_v_acc = nullptr;
     hipStream_t stream = (hipStream_t)stream_;
+    if (a->dn) {
+        const dnsplat_dn_post *dn = a->dn;
+        if (a->D != 7 || a->ed_channel != 3 || a->xy_split != 4 || !a->background) return DNSPLAT_ERR_UNSUPPORTED;
+        if (!dn->background_rgb || !dn->v_rgb || !dn->v_depth || !dn->v_normal || !a->render) return DNSPLAT_ERR_INVALID_ARG;
+        ba.bg_rgb = dn->background_rgb; ba.dn_v_rgb = dn->v_rgb; ba.dn_v_depth = dn->v_depth;
+        ba.dn_v_normal = dn->v_normal; ba.dn_v_acc = dn->v_accumulation;
+        return launch_bwd<7, 4, true>(ba, stream);
+    }
     switch (a->D) {
         case 1: return dispatch_split<1>(ba, stream);
         case 2: return dispatch_split<2>(ba, stream);

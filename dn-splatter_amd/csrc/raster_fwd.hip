@@ -36,9 +36,31 @@ struct FwdArgs {
     float *__restrict__ render;
     float *__restrict__ alphas;
     int32_t *__restrict__ last_ids;
+    // fused dn-splatter epilogue (DN instantiation only)
+    const float *__restrict__ bg_rgb;
+    float *__restrict__ dn_rgb;
+    float *__restrict__ dn_depth;
+    float *__restrict__ dn_normal;
+    float *__restrict__ dn_depth_max;
 };
 
-template <int D>
+// The dn-splatter per-pixel post-ops (dn_model.py:526-528, 577-578) applied to one finished pixel.
+__device__ __forceinline__ float dn_epilogue(const FwdArgs &a, size_t pid, const float *raw, float al)
+{
+    const float one_minus = 1.f - al;   // the reference computes (1 - alpha) from the rounded alpha image
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        a.dn_rgb[pid * 3 + c] = fminf(fmaxf(raw[c] + one_minus * a.bg_rgb[c], 0.f), 1.f);
+    const float nx = raw[4], ny = raw[5], nz = raw[6];
+    const float nrm = sqrtf(nx * nx + ny * ny + nz * nz);
+    a.dn_normal[pid * 3 + 0] = (nx / nrm + 1.f) / 2.f;
+    a.dn_normal[pid * 3 + 1] = (ny / nrm + 1.f) / 2.f;
+    a.dn_normal[pid * 3 + 2] = (nz / nrm + 1.f) / 2.f;
+    a.dn_depth[pid] = raw[3];
+    return raw[3];
+}
+
+template <int D, bool DN>
 __global__ __launch_bounds__(FWD_THREADS) void raster_fwd_kernel(FwdArgs a)
 {
     // one 64-record slice per wave: [wave][splat][4 x float4]
@@ -147,38 +169,52 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_fwd_kernel(FwdArgs a)
     }
 
     // epilogue: background, expected-depth normalisation, stores
+    float dmax = 0.f;
     if (in0) {
         const size_t pid = (size_t)py_i0 * a.width + px_i;
         const float al = 1.f - T0;
         a.alphas[pid] = al;
         a.last_ids[pid] = last0;
+        float raw[8];
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             float v = acc0[k];
             if (a.background) v += T0 * a.background[k];
             if (k == a.ed_channel) v = v / fmaxf(al, (float)DNS_ED_ALPHA_FLOOR);
             a.render[pid * D + k] = v;
+            raw[k] = v;
         }
+        if (DN) dmax = fmaxf(dmax, dn_epilogue(a, pid, raw, al));
     }
     if (in1) {
         const size_t pid = (size_t)py_i1 * a.width + px_i;
         const float al = 1.f - T1;
         a.alphas[pid] = al;
         a.last_ids[pid] = last1;
+        float raw[8];
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             float v = acc1[k];
             if (a.background) v += T1 * a.background[k];
             if (k == a.ed_channel) v = v / fmaxf(al, (float)DNS_ED_ALPHA_FLOOR);
             a.render[pid * D + k] = v;
+            raw[k] = v;
         }
+        if (DN) dmax = fmaxf(dmax, dn_epilogue(a, pid, raw, al));
+    }
+    if (DN) {
+        // image-wide max of the expected depth (dn_model.py:535 `depth_im.detach().max()`): depths are >= 0,
+        // so their bit patterns order like the floats and one integer atomicMax per wave suffices
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, DNS_WAVE));
+        if (lane == 0 && dmax > 0.f) atomicMax(reinterpret_cast<int *>(a.dn_depth_max), __float_as_int(dmax));
     }
 }
 
-template <int D>
+template <int D, bool DN = false>
 int launch_fwd(const FwdArgs &fa, hipStream_t stream)
 {
-    hipLaunchKernelGGL(raster_fwd_kernel<D>, dim3(fa.n_tiles), dim3(FWD_THREADS), 0, stream, fa);
+    hipLaunchKernelGGL((raster_fwd_kernel<D, DN>), dim3(fa.n_tiles), dim3(FWD_THREADS), 0, stream, fa);
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;
 }
@@ -204,7 +240,16 @@ extern "C" int dnsplat_raster_fwd(const dnsplat_raster_args *a, dnsplat_stream_t
     fa.background = a->background;
     fa.ed_channel = a->ed_channel;
     fa.render = a->render; fa.alphas = a->alphas; fa.last_ids = a->last_ids;
+    fa.bg_rgb = nullptr; fa.dn_rgb = fa.dn_depth = fa.dn_normal = fa.dn_depth_max = nullptr;
     hipStream_t stream = (hipStream_t)stream_;
+    if (a->dn) {
+        const dnsplat_dn_post *dn = a->dn;
+        if (a->D != 7 || a->ed_channel != 3 || !a->background) return DNSPLAT_ERR_UNSUPPORTED;
+        if (!dn->background_rgb || !dn->rgb || !dn->depth || !dn->normal || !dn->depth_max) return DNSPLAT_ERR_INVALID_ARG;
+        fa.bg_rgb = dn->background_rgb; fa.dn_rgb = dn->rgb; fa.dn_depth = dn->depth; fa.dn_normal = dn->normal;
+        fa.dn_depth_max = dn->depth_max;
+        return launch_fwd<7, true>(fa, stream);
+    }
     switch (a->D) {
         case 1: return launch_fwd<1>(fa, stream);
         case 2: return launch_fwd<2>(fa, stream);

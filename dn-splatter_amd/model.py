@@ -110,10 +110,13 @@ class DNSplatterRenderer:
     opacities[, normals]) — dn_model.py:227-237."""
 
     def __init__(self, gauss_params: Dict[str, Tensor], config: Optional[RendererConfig] = None, fused: bool = True,
-                 rasterization_fn: Optional[Callable] = None, rasterize_gaussians_fn: Optional[Callable] = None):
+                 rasterization_fn: Optional[Callable] = None, rasterize_gaussians_fn: Optional[Callable] = None,
+                 fused_postops: bool = True):
         self.gauss_params = gauss_params
         self.config = config or RendererConfig()
         self.fused = fused
+        self.fused_postops = fused_postops   # also run dn_model.py:526-537,577-603 inside the HIP kernels
+        self._bg_cache: Dict = {}
         self.step = 10 ** 9  # all SH bands active unless the trainer says otherwise (dn_model.py:488-490)
         self._rasterization = rasterization_fn or rasterization
         self._rasterize_gaussians = rasterize_gaussians_fn or rasterize_gaussians
@@ -131,14 +134,36 @@ class DNSplatterRenderer:
         if cfg.rasterize_mode not in ["antialiased", "classic"]:
             raise ValueError("Unknown rasterize_mode: %s", cfg.rasterize_mode)
         c2w = camera.camera_to_worlds
-        viewmat = get_viewmat(c2w)                       # dn_model.py:475
-        K = camera.get_intrinsics_matrices().to(c2w.device)   # dn_model.py:476
         W, H = int(camera.width), int(camera.height)
-        background = torch.tensor(cfg.background_color, dtype=torch.float32, device=c2w.device)
+        background = self._bg_cache.get(c2w.device)
+        if background is None:
+            background = torch.tensor(cfg.background_color, dtype=torch.float32, device=c2w.device)
+            self._bg_cache[c2w.device] = background
 
         means, scales, quats = gp["means"], gp["scales"], gp["quats"]
         features_dc, features_rest, opacities = gp["features_dc"], gp["features_rest"], gp["opacities"]
 
+        if (self.fused and self.fused_postops and cfg.sh_degree > 0 and cfg.predict_normals
+                and cfg.rasterize_mode == "classic"):
+            # everything between the parameters and the output dict in HIP
+            out, info = _fused.render_dn_outputs(
+                means, quats, scales, opacities, features_dc, features_rest, c2w[0], float(camera.fx), float(camera.fy),
+                float(camera.cx), float(camera.cy), W, H, sh_degree=self._sh_degree_to_use(), background_rgb=background,
+                absgrad=True)
+            gp["normals"] = info["normals_world"]          # dn_model.py:558
+            if self.training and info["means2d"].requires_grad:
+                info["means2d"].retain_grad()              # dn_model.py:517-518
+            self.xys = info["means2d"]
+            self.radii = info["radii"][0]
+            self.depths = info["depths"]
+            self.conics = info["conics"]
+            self.num_tiles_hit = info["tiles_per_gauss"]
+            self.last_info = info
+            out["background"] = background
+            return out
+
+        viewmat = get_viewmat(c2w)                       # dn_model.py:475
+        K = camera.get_intrinsics_matrices().to(c2w.device)   # dn_model.py:476
         if self.fused and cfg.sh_degree > 0 and not (cfg.rasterize_mode == "antialiased" and cfg.predict_normals):
             render, alpha, normals_im, info = _fused.render_dn(
                 means, quats, scales, opacities, features_dc, features_rest, viewmat[0], K[0], c2w[0], W, H,

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DNSPLAT_ABI_VERSION 1
+#define DNSPLAT_ABI_VERSION 2
 #define DNSPLAT_RECORD_FLOATS 16
 #define DNSPLAT_MAX_CHANNELS 8
 
@@ -154,6 +154,28 @@ int dnsplat_bin_isect_ids(int32_t n_tiles, const int32_t *tile_offsets, const in
 /* ------------------------------------------------------------------ stage 3/4
  * Per-tile front-to-back alpha compositing of D feature channels (A6 + A8 in one
  * pass) and its backward. */
+/* Optional dn-splatter epilogue fused into the compositing kernels: the per-pixel
+ * post-ops DNSplatterModel.get_outputs applies to the two gsplat results (dn_model.py:526-537, 577-578).
+ * Only for the fused 7-channel layout rgb | expected depth | normal (D == 7, ed_channel == 3,
+ * xy_split == 4, background == {0,0,0,0,1,1,1}).  Forward additionally writes
+ *     rgb    = clamp(render_rgb + (1 - alpha) * background_rgb, 0, 1)          dn_model.py:526-528
+ *     depth  = expected depth as composited (the alpha == 0 fill needs the image-wide maximum, which
+ *              the forward reduces into *depth_max; dnsplat_dn_depth_normals applies it)  :533-537
+ *     normal = (n / |n| + 1) / 2 with n the composited normal incl. its ones-background  :577-578
+ * and backward takes the cotangents of those images (and of accumulation = alpha) instead of
+ * v_render / v_alphas. */
+typedef struct dnsplat_dn_post {
+    const float *background_rgb; /* device [3] */
+    float *rgb;                  /* out [H,W,3] */
+    float *depth;                /* out [H,W] expected depth, unfilled */
+    float *normal;               /* out [H,W,3] */
+    float *depth_max;            /* device scalar, caller zero-fills; receives max over the image of `depth` */
+    const float *v_rgb;          /* backward: [H,W,3] */
+    const float *v_depth;        /* backward: [H,W] cotangent of the FILLED depth image (masked by alpha > 0 inside) */
+    const float *v_normal;       /* backward: [H,W,3] */
+    const float *v_accumulation; /* backward: [H,W] or NULL */
+} dnsplat_dn_post;
+
 typedef struct dnsplat_raster_args {
     int32_t width, height, tile_size;   /* tile_size must be 16 */
     int32_t D;                          /* feature channels, 1..8 */
@@ -171,10 +193,28 @@ typedef struct dnsplat_raster_args {
     int32_t xy_split;                   /* channels >= xy_split do not feed v_xy/|v_xy|: the reference renders
                                            them with xys.detach() (dn_model.py:562). Use D for "all feed". */
     float *v_splats;                    /* [N,16] gradient records, accumulated into (caller zero-fills) */
+    const dnsplat_dn_post *dn;          /* NULL, or the fused dn-splatter epilogue (then v_render / v_alphas are unused) */
 } dnsplat_raster_args;
 
 int dnsplat_raster_fwd(const dnsplat_raster_args *args, dnsplat_stream_t stream);
 int dnsplat_raster_bwd(const dnsplat_raster_args *args, dnsplat_stream_t stream);
+
+/* Depth fill + depth->normal stencil of get_outputs (dn_model.py:533-537 and 589-603 with
+ * utils/normal_utils.py:9-48, utils/camera_utils.py:92-144, called with c2w = identity):
+ *     depth_out      = alpha > 0 ? depth : *depth_max
+ *     surface_normal = (1 + diag(1,-1,-1) * normalize(cross(right - left, top - bottom))) / 2 of the
+ *                      back-projected (pixel centre + 0.5) depth_out; 0.5 on the one-pixel border.
+ * No gradient flows through it in the reference (depth.detach(), dn_model.py:590). */
+int dnsplat_dn_depth_normals(int32_t width, int32_t height, float fx, float fy, float cx, float cy,
+                             const float *depth, const float *alphas, const float *depth_max,
+                             float *depth_out /* [H,W] */, float *surface_normal /* [H,W,3] */,
+                             dnsplat_stream_t stream);
+
+/* nerfstudio get_viewmat + intrinsics + normal frame in one launch: from the camera-to-world matrix
+ * c2w [3,4] (OpenGL axes, device) writes viewmat[16] (world->camera, OpenCV), K[9] and
+ * normal_frame[12] (see dnsplat_camera).  Replaces ~20 tiny torch kernels per frame (dn_model.py:475-479). */
+int dnsplat_camera_prepare(const float *c2w, float fx, float fy, float cx, float cy,
+                           float *viewmat, float *K, float *normal_frame, dnsplat_stream_t stream);
 
 /* ------------------------------------------------------------------ stage 5
  * Fused per-Gaussian back end: gradient record -> parameter gradients.

@@ -232,8 +232,12 @@ def test_rasterize_gaussians_legacy_dropin(dns, orc):
         assert_close(cg[k].grad, co[k].grad, "legacy grad " + k, flips=FLIP_FRACTION)
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_get_outputs_mirror_matches_reference_sequence(dns, orc, fused):
+MODES = {"fused_hip_postops": dict(fused=True, fused_postops=True), "fused_torch_postops": dict(fused=True, fused_postops=False),
+         "two_call": dict(fused=False)}
+
+
+@pytest.mark.parametrize("mode", sorted(MODES))
+def test_get_outputs_mirror_matches_reference_sequence(dns, orc, mode):
     """DNSplatterModel.get_outputs (dn_model.py:404-612): our fused one-pass renderer and our two-call
     drop-ins against the reference's own op sequence run on the oracle."""
     from dn_splatter_amd import synthetic
@@ -255,7 +259,7 @@ def test_get_outputs_mirror_matches_reference_sequence(dns, orc, fused):
         loss.backward()
         return out, params, m
 
-    out_g, p_g, m_g = run(DEV, fused=fused)
+    out_g, p_g, m_g = run(DEV, **MODES[mode])
     out_o, p_o, m_o = run("cpu", fused=False, rasterization_fn=orc.rasterization,
                           rasterize_gaussians_fn=orc.rasterize_gaussians)
     torch.cuda.synchronize()
@@ -265,8 +269,13 @@ def test_get_outputs_mirror_matches_reference_sequence(dns, orc, fused):
     for k in ("rgb", "depth", "normal", "accumulation"):
         assert out_g[k].shape == out_o[k].shape
         assert_close(out_g[k], out_o[k], k, flips=FLIP_FRACTION)
-    # surface_normal is a finite-difference stencil of the depth image: 1e-4 depth noise is amplified
-    assert rel_err(out_g["surface_normal"], out_o["surface_normal"]) < 5e-2
+    # surface_normal is a finite-difference stencil of the depth image: depth noise is amplified by ~fx/d, so it
+    # is compared on the 99.9 % quantile of the error; the border must be exactly the reference's 0.5
+    d_sn = (out_g["surface_normal"].detach().cpu() - out_o["surface_normal"].detach()).abs().reshape(-1)
+    assert float(torch.quantile(d_sn[::7], 0.999)) < 5e-3, float(torch.quantile(d_sn[::7], 0.999))
+    assert float(d_sn.max()) < 0.5
+    sn = out_g["surface_normal"].detach().cpu()
+    assert torch.equal(sn[0], torch.full_like(sn[0], 0.5)) and torch.equal(sn[:, -1], torch.full_like(sn[:, -1], 0.5))
     assert_close(p_g["normals"], p_o["normals"], "gauss_params['normals'] (dn_model.py:558)", 1e-5)
     for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities"):
         assert_close(p_g[k].grad, p_o[k].grad, "grad " + k, flips=FLIP_FRACTION)
