@@ -1,0 +1,122 @@
+"""Host-side logic that needs no GPU: the get_outputs mirror's torch post-ops, camera helpers, synthetic inputs,
+bench accounting.  (The mirror is exercised with the oracle plugged in for the two gsplat calls.)"""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+from _scenes import assert_close
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_get_viewmat_inverts_the_camera(dns):
+    from dn_splatter_amd import synthetic
+
+    cam = synthetic.orbit_camera(3, width=64, height=48, focal=50.0)
+    vm = dns.get_viewmat(cam.camera_to_worlds)[0]
+    c2w = cam.camera_to_worlds[0]
+    # OpenGL -> OpenCV: flip y, z of the camera axes; viewmat @ [cam centre, 1] = 0
+    centre = torch.cat([c2w[:, 3], torch.ones(1)])
+    assert torch.allclose(vm @ centre, torch.tensor([0.0, 0.0, 0.0, 1.0]), atol=1e-5)
+    R = vm[:3, :3]
+    assert torch.allclose(R @ R.T, torch.eye(3), atol=1e-5)
+    # the camera looks at the origin: the origin lies on the +z (forward) axis in OpenCV coordinates
+    o = vm @ torch.tensor([0.0, 0.0, 0.0, 1.0])
+    assert abs(float(o[0])) < 1e-4 and abs(float(o[1])) < 1e-4 and abs(float(o[2]) - 8.0) < 1e-4
+
+
+def test_normal_from_depth_image_of_a_plane():
+    """A fronto-parallel plane z = 2 gives the normal (0,0,+-1); a tilted plane gives its analytic normal."""
+    sys.path.insert(0, ROOT)
+    from dn_splatter_amd.model import normal_from_depth_image
+
+    W, H, f = 40, 30, 35.0
+    d = torch.full((H, W, 1), 2.0)
+    n = normal_from_depth_image(d, f, f, W / 2, H / 2, (W, H), torch.eye(4))
+    inner = n[1:-1, 1:-1]
+    assert torch.allclose(inner.abs(), torch.tensor([0.0, 0.0, 1.0]).expand_as(inner), atol=1e-5)
+    assert float(n[0].abs().max()) == 0.0 and float(n[:, 0].abs().max()) == 0.0   # zero-padded border
+    # plane n.X = c with n = (a, 0, 1)/|.|: z = c / (a x/z + 1) ... sample depth analytically along pixel rays
+    a, c = 0.3, 2.0
+    xs = (torch.arange(W) + 0.5 - W / 2) / f
+    z = c / (a * xs + 1.0)
+    d2 = z[None, :, None].expand(H, W, 1).contiguous()
+    n2 = normal_from_depth_image(d2, f, f, W / 2, H / 2, (W, H), torch.eye(4))[1:-1, 1:-1]
+    expect = torch.tensor([a, 0.0, 1.0]) / math.sqrt(a * a + 1)
+    assert torch.allclose(n2.abs(), expect.abs().expand_as(n2), atol=2e-3)
+
+
+def test_synthetic_inputs_follow_the_reference_init(dns):
+    from dn_splatter_amd import synthetic
+
+    gp = synthetic.make_gauss_params(5000, sh_degree=3, seed=0)
+    assert gp["means"].shape == (5000, 3) and float(gp["means"].abs().max()) <= 5.0          # (rand-0.5)*10
+    assert gp["features_rest"].shape == (5000, 15, 3) and gp["features_dc"].shape == (5000, 3)
+    assert torch.allclose(torch.sigmoid(gp["opacities"]), torch.full((5000, 1), 0.1), atol=1e-6)   # logit(0.1)
+    assert torch.allclose(gp["scales"][:, 0], gp["scales"][:, 1])                                  # isotropic
+    assert torch.allclose(gp["quats"].norm(dim=-1), torch.ones(5000), atol=1e-5)
+    # closed-form 3-NN distance tracks the kNN value the reference computes with sklearn
+    knn = torch.exp(gp["scales"][:, 0]).mean().item()
+    cf = synthetic.mean_3nn_distance_closed_form(5000)
+    assert abs(knn - cf) / cf < 0.08
+    # determinism
+    gp2 = synthetic.make_gauss_params(5000, sh_degree=3, seed=0)
+    assert torch.equal(gp["means"], gp2["means"]) and torch.equal(gp["quats"], gp2["quats"])
+
+
+def test_bench_stage_bytes_sum_to_the_survey_formula():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    N, Nv, I, P, T = 1_000_000, 716_866, 21_243_626, 1920 * 1080, 8160
+    sb = bench.stage_bytes(N, Nv, I, P, T)
+    assert sum(sb.values()) == 84 * N + 796 * Nv + 216 * I + 76 * P + 12 * T
+    assert set(bench.WORKLOADS) == {"c1", "c2", "c3"} and bench.WORKLOADS["c2"][:3] == (1_000_000, 1920, 1080)
+
+
+def test_mirror_output_contract_and_sh_schedule(dns, orc):
+    from dn_splatter_amd import synthetic
+
+    gp = synthetic.make_gauss_params(400, sh_rest_std=0.2, seed=2)
+    cam = synthetic.orbit_camera(0, width=48, height=32, focal=30.0)
+    params = {k: v.detach().clone().requires_grad_(k != "normals") for k, v in gp.items()}
+    m = dns.DNSplatterRenderer(params, fused=False, rasterization_fn=orc.rasterization,
+                               rasterize_gaussians_fn=orc.rasterize_gaussians)
+    m.step = 0            # dn_model.py:487-490: degree = min(step // interval, sh_degree)
+    assert m._sh_degree_to_use() == 0
+    out0 = m.get_outputs(cam)
+    m.step = 2500
+    assert m._sh_degree_to_use() == 2
+    m.step = 10 ** 9
+    out3 = m.get_outputs(cam)
+    assert not torch.allclose(out0["rgb"], out3["rgb"])      # higher bands change the colour
+    assert torch.allclose(out0["depth"], out3["depth"])      # ... but not the geometry
+    for k, c in (("rgb", 3), ("depth", 1), ("normal", 3), ("surface_normal", 3), ("accumulation", 1)):
+        assert out3[k].shape == (32, 48, c), k
+    assert out3["background"].shape == (3,)
+    assert float(out3["rgb"].min()) >= 0 and float(out3["rgb"].max()) <= 1
+    assert m.xys.shape == (1, 400, 2) and m.radii.shape == (400,) and m.radii.dtype == torch.int32
+    with pytest.raises(ValueError):
+        dns.DNSplatterRenderer(params, config=dns.RendererConfig(rasterize_mode="bogus")).get_outputs(cam)
+
+
+def test_torch_postops_equal_their_closed_forms(dns, orc):
+    """Background blend, depth fill and normal normalisation of the mirror (dn_model.py:526-537, 577-578)."""
+    from dn_splatter_amd import synthetic
+
+    gp = synthetic.make_gauss_params(300, sh_rest_std=0.0, seed=4)
+    cam = synthetic.orbit_camera(2, width=40, height=24, focal=25.0)
+    params = {k: v.detach().clone() for k, v in gp.items()}
+    m = dns.DNSplatterRenderer(params, fused=False, rasterization_fn=orc.rasterization,
+                               rasterize_gaussians_fn=orc.rasterize_gaussians)
+    out = m.get_outputs(cam)
+    n = out["normal"] * 2 - 1
+    assert torch.allclose(n.norm(dim=-1), torch.ones(24, 40), atol=1e-5)
+    acc = out["accumulation"]
+    empty = acc[..., 0] == 0
+    if bool(empty.any()):
+        assert torch.allclose(out["rgb"][empty], out["background"].expand(int(empty.sum()), 3), atol=1e-6)
+        assert torch.allclose(out["depth"][empty], out["depth"].max().expand(int(empty.sum()), 1))
