@@ -44,7 +44,8 @@ namespace {
 
 constexpr int TILE = 16;
 constexpr int NPIX = TILE * TILE;
-constexpr int QCAP = 2 * DNS_WAVE;
+constexpr int BUCKET = 2 * DNS_WAVE;   // splats per systolic pass: two per lane, processed as packed fp32 pairs
+constexpr int QCAP = 4 * DNS_WAVE;
 
 struct BwdArgs {
     int width, height, tw, n_tiles;
@@ -68,7 +69,10 @@ struct BwdArgs {
     const float *__restrict__ dn_v_acc;
 };
 
+
+
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 // One pixel row (48 bytes) of the LDS table as three ds_read_b128.  Left to itself hipcc scalarises the
 // row (its fields are carried across the loop back-edge one by one) and re-merges it into
@@ -76,16 +80,21 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // all LDS cycles of this kernel were conflict cycles).  ds_read_b128 at that stride is conflict-free
 // (MI355X_MICROARCH.md, LDS lane groups).  The loads are issued here and waited for in row_wait(), which
 // ties the destination registers to the s_waitcnt so that no use can be scheduled above it.
-__device__ __forceinline__ void row_issue(uint32_t byte_addr, v4f &r0, v4f &r1, v4f &r2)
+// `token` is any value the row-independent arithmetic of the step is derived from: passing it through the asm
+// pins that arithmetic BEHIND the loads in program order (otherwise hipcc hoists it above them and the wait
+// follows the loads immediately).
+__device__ __forceinline__ void row_issue(uint32_t byte_addr, v4f &r0, v4f &r1, v4f &r2, int &token)
 {
-    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32"
-                 : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "+v"(token)
                  : "v"(byte_addr)
                  : "memory");
 }
-__device__ __forceinline__ void row_wait(v4f &r0, v4f &r1, v4f &r2)
+// `done` is the last value of the row-independent arithmetic: routing it through the asm keeps that arithmetic
+// AHEAD of the wait (hipcc is otherwise free to sink it below).
+__device__ __forceinline__ void row_wait(v4f &r0, v4f &r1, v4f &r2, f2 &done)
 {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2) : : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(done) : : "memory");
 }
 
 __device__ __forceinline__ float dpp_wave_shr1(float from_prev, float lane0_value)
@@ -210,10 +219,11 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
 
     int cursor = hi;  // next (highest) list index not yet examined
     int qn = 0;       // entries waiting in the queue (wave-uniform)
+    const uint32_t pix_base = (uint32_t)(uintptr_t)&pix[0][0];   // LDS byte address of the table
 
     for (;;) {
-        // ---- fill the queue with contributing entries until a full bucket is available ----------
-        while (qn < DNS_WAVE && cursor >= range_start) {
+        // ---- fill the queue with contributing entries until a full bucket (2 per lane) is available ----
+        while (qn < BUCKET && cursor >= range_start) {
             const int idx = cursor - lane;
             bool keep = false;
             if (idx >= range_start) {
@@ -228,117 +238,149 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
         }
         if (qn == 0) break;
         __builtin_amdgcn_wave_barrier();
-        const int take = min(qn, DNS_WAVE);
-        const int my_idx = lane < take ? queue[lane] : -1;
+        const int take = min(qn, BUCKET);
+        // lane l owns entries 2l (A, farther) and 2l+1 (B, nearer): a pixel meets them in list order
+        const int idx_a = 2 * lane < take ? queue[2 * lane] : -1;
+        const int idx_b = 2 * lane + 1 < take ? queue[2 * lane + 1] : -1;
         const int rest = qn - take;
-        const int moved = lane < rest ? queue[DNS_WAVE + lane] : 0;
+        const int moved = lane < rest ? queue[BUCKET + lane] : 0;
         __builtin_amdgcn_wave_barrier();
         if (lane < rest) queue[lane] = moved;
         qn = rest;
 
-        // ---- this lane's splat for the pass ---------------------------------------------------
-        const bool has = my_idx >= 0;
-        int gid = 0;
-        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
-        if (has) {
-            gid = a.flatten_ids[my_idx];
-            const float4 *rec = a.splats + (size_t)gid * 4;
-            s0 = rec[0]; s1 = rec[1];
-            if (D > 2) s2 = rec[2];
-            if (D > 6) s3 = rec[3];
+        // ---- this lane's two splats for the pass, as packed pairs (x = A, y = B) ------------------
+        int gid_a = 0, gid_b = 0;
+        float4 ra0 = make_float4(0.f, 0.f, 0.f, 0.f), ra1 = ra0, ra2 = ra0, ra3 = ra0;
+        float4 rb0 = ra0, rb1 = ra0, rb2 = ra0, rb3 = ra0;
+        if (idx_a >= 0) {
+            gid_a = a.flatten_ids[idx_a];
+            const float4 *rec = a.splats + (size_t)gid_a * 4;
+            ra0 = rec[0]; ra1 = rec[1];
+            if (D > 2) ra2 = rec[2];
+            if (D > 6) ra3 = rec[3];
         }
-        const float sx = s0.x, sy = s0.y, ca = s0.z, cb = s0.w, cc = s1.x, opac = s1.y;
-        const DnsConicE qe = dns_conic_e(ca, cb, cc);
-        const float ch[8] = {s1.z, s1.w, s2.x, s2.y, s2.z, s2.w, s3.x, s3.y};
+        if (idx_b >= 0) {
+            gid_b = a.flatten_ids[idx_b];
+            const float4 *rec = a.splats + (size_t)gid_b * 4;
+            rb0 = rec[0]; rb1 = rec[1];
+            if (D > 2) rb2 = rec[2];
+            if (D > 6) rb3 = rec[3];
+        }
+        const f2 sx = {ra0.x, rb0.x}, sy = {ra0.y, rb0.y};
+        const f2 ca = {ra0.z, rb0.z}, cb = {ra0.w, rb0.w}, cc = {ra1.x, rb1.x}, opac = {ra1.y, rb1.y};
+        const DnsConicE qa = dns_conic_e(ra0.z, ra0.w, ra1.x), qb = dns_conic_e(rb0.z, rb0.w, rb1.x);
+        const f2 na = {qa.na, qb.na}, nb = {qa.nb, qb.nb}, nc = {qa.nc, qb.nc};
+        const f2 ch[8] = {{ra1.z, rb1.z}, {ra1.w, rb1.w}, {ra2.x, rb2.x}, {ra2.y, rb2.y},
+                          {ra2.z, rb2.z}, {ra2.w, rb2.w}, {ra3.x, rb3.x}, {ra3.y, rb3.y}};
         // lanes without a splat can never be valid: give them an index above every bin_final
-        const int cmp_idx = has ? my_idx : 0x7fffffff;
+        const int cmp_a = idx_a >= 0 ? idx_a : 0x7fffffff;
+        const int cmp_b = idx_b >= 0 ? idx_b : 0x7fffffff;
 
-        float g_x = 0.f, g_y = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_o = 0.f, g_ax = 0.f, g_ay = 0.f;
-        float g_ch[8];
+        const f2 zero2 = {0.f, 0.f};
+        f2 g_x = zero2, g_y = zero2, g_ca = zero2, g_cb = zero2, g_cc = zero2, g_o = zero2, g_ax = zero2, g_ay = zero2;
+        f2 g_ch[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) g_ch[k] = 0.f;
-        bool touched = false;
+        for (int k = 0; k < 8; ++k) g_ch[k] = zero2;
+        bool touched_a = false, touched_b = false;
 
         float T_out = 0.f, SA_out = 0.f, SB_out = 0.f;
         // The pixel row of the step is requested first and waited for only after the row-independent part
-        // (pixel coordinates, exponent, exp2) has been issued, which covers the LDS latency.
-        const uint32_t pix_base = (uint32_t)(uintptr_t)&pix[0][0];   // LDS byte address of the table
+        // (pixel coordinates, exponents, exp2) has been issued, which covers the LDS latency.
         for (int s = 0; s < NPIX + DNS_WAVE - 1; ++s) {
             const int p = s - lane;
             const bool active = (unsigned)p < (unsigned)NPIX;
-            const int pcur = p & (NPIX - 1);
+            int pcur = p & (NPIX - 1);
             v4f c0, c1, cst;
-            row_issue(pix_base + pcur * 48, c0, c1, cst);
+            row_issue(pix_base + pcur * 48, c0, c1, cst, pcur);
 
-            const float dx = sx - (fx0 + (float)(pcur & 15));
-            const float dy = sy - (fy0 + (float)(pcur >> 4));
-            const float e = dns_exponent(qe, dx, dy);
-            const float vis = dns_exp2(e);
-
-            row_wait(c0, c1, cst);
+            const float px = fx0 + (float)(pcur & 15), py = fy0 + (float)(pcur >> 4);
+            const f2 dx = sx - px, dy = sy - py;
+            // same fused-multiply-add sequence as dns_exponent(), two splats at a time (v_pk_*_f32)
+            const f2 e = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(na, dx, nb * dy), (nc * dy) * dy);
+            f2 vis = {dns_exp2(e.x), dns_exp2(e.y)};
+            row_wait(c0, c1, cst, vis);
+            const f2 ov = opac * vis;
+            const float al_a = fminf((float)DNS_ALPHA_MAX, ov.x), al_b = fminf((float)DNS_ALPHA_MAX, ov.y);
             // state arrives from the previous lane; lane 0 takes it from the pixel's LDS row
             float T = dpp_wave_shr1(T_out, cst.x);
             float SA = dpp_wave_shr1(SA_out, cst.y);
             float SB = dpp_wave_shr1(SB_out, cst.z);
             const int bin_final = __float_as_int(cst.w);
-            const float ov = opac * vis;
-            const float alpha = fminf((float)DNS_ALPHA_MAX, ov);
-            const bool valid = active && cmp_idx <= bin_final && e <= 0.f && alpha >= (float)DNS_ALPHA_MIN;
-            if (valid) {
-                touched = true;
+            const bool valid_a = active && cmp_a <= bin_final && e.x <= 0.f && al_a >= (float)DNS_ALPHA_MIN;
+            const bool valid_b = active && cmp_b <= bin_final && e.y <= 0.f && al_b >= (float)DNS_ALPHA_MIN;
+            {   // straight-line: an idle step costs the same as a busy one, but no phi copies at a join
+                touched_a |= valid_a; touched_b |= valid_b;
+                // an invalid pair takes alpha = 0 (=> 1/(1-alpha) = 1, weight 0: state and sums unchanged) and m = 0
+                const f2 alpha = {valid_a ? al_a : 0.f, valid_b ? al_b : 0.f};
+                const f2 m = {(valid_a && ov.x <= (float)DNS_ALPHA_MAX) ? 1.f : 0.f,
+                              (valid_b && ov.y <= (float)DNS_ALPHA_MAX) ? 1.f : 0.f};
+                const f2 om = 1.f - alpha;
+                const f2 ra = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                const float T1 = T * ra.x, T2 = T1 * ra.y;          // the pixel meets A, then B
+                const f2 Tv = {T1, T2};
+                const f2 fac = alpha * Tv;
                 const float pvv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-                const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
-                T *= ra;
-                const float fac = alpha * T;
-                float cva = 0.f, cvb = 0.f;
+                f2 cva = zero2, cvb = zero2;
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
-                    g_ch[k] = __builtin_fmaf(fac, pvv[k], g_ch[k]);
-                    if (k < split) cva = __builtin_fmaf(ch[k], pvv[k], cva);
-                    else cvb = __builtin_fmaf(ch[k], pvv[k], cvb);
+                    const f2 vk = {pvv[k], pvv[k]};
+                    g_ch[k] = __builtin_elementwise_fma(fac, vk, g_ch[k]);
+                    if (k < split) cva = __builtin_elementwise_fma(ch[k], vk, cva);
+                    else cvb = __builtin_elementwise_fma(ch[k], vk, cvb);
                 }
-                const float va_a = T * cva - ra * SA;
-                const float va_b = (SPLIT == D) ? 0.f : T * cvb - ra * SB;
-                if (ov <= (float)DNS_ALPHA_MAX) {
-                    const float va = va_a + va_b;
-                    const float vs = -ov * va;
-                    const float vs_a = -ov * va_a;
-                    const float hx = vs * dx, hy = vs * dy;
-                    g_ca = __builtin_fmaf(0.5f * hx, dx, g_ca);
-                    g_cb = __builtin_fmaf(hx, dy, g_cb);
-                    g_cc = __builtin_fmaf(0.5f * hy, dy, g_cc);
-                    const float gx = vs_a * (ca * dx + cb * dy);
-                    const float gy = vs_a * (cb * dx + cc * dy);
-                    g_x += gx; g_y += gy;
-                    g_ax += fabsf(gx); g_ay += fabsf(gy);
-                    g_o = __builtin_fmaf(vis, va, g_o);
+                const float SA1 = __builtin_fmaf(fac.x, cva.x, SA);
+                const f2 SAv = {SA, SA1};
+                const f2 va_a = Tv * cva - ra * SAv;
+                SA = __builtin_fmaf(fac.y, cva.y, SA1);
+                f2 va = va_a;
+                if (SPLIT != D) {
+                    const float SB1 = __builtin_fmaf(fac.x, cvb.x, SB);
+                    const f2 SBv = {SB, SB1};
+                    va += Tv * cvb - ra * SBv;
+                    SB = __builtin_fmaf(fac.y, cvb.y, SB1);
                 }
-                SA = __builtin_fmaf(fac, cva, SA);
-                if (SPLIT != D) SB = __builtin_fmaf(fac, cvb, SB);
+                const f2 nov = -(ov * m);
+                const f2 vs = nov * va, vs_a = nov * va_a;
+                const f2 hx = vs * dx, hy = vs * dy;
+                g_ca = __builtin_elementwise_fma(hx, dx, g_ca);      // x 1/2 at the flush
+                g_cb = __builtin_elementwise_fma(hx, dy, g_cb);
+                g_cc = __builtin_elementwise_fma(hy, dy, g_cc);
+                const f2 gx = vs_a * (ca * dx + cb * dy);
+                const f2 gy = vs_a * (cb * dx + cc * dy);
+                g_x += gx; g_y += gy;
+                g_ax += __builtin_elementwise_abs(gx); g_ay += __builtin_elementwise_abs(gy);
+                g_o = __builtin_elementwise_fma(vis * m, va, g_o);
+                T = T2;
             }
             T_out = T; SA_out = SA; SB_out = SB;
             // park the state of the pixel leaving the array for the next (nearer) bucket
             if (lane == DNS_WAVE - 1 && active) pix[pcur][2] = make_float4(T, SA, SB, cst.w);
         }
 
-        // ---- flush: transpose through LDS, one atomic row per touched splat ---------------------
-        flush[lane][0] = make_float4(g_x, g_y, g_ca, g_cb);
-        flush[lane][1] = make_float4(g_cc, g_o, g_ch[0], g_ch[1]);
-        flush[lane][2] = make_float4(g_ch[2], g_ch[3], g_ch[4], g_ch[5]);
-        flush[lane][3] = make_float4(g_ch[6], g_ch[7], g_ax, g_ay);
-        const uint64_t tmask = __ballot(touched);
-        __builtin_amdgcn_wave_barrier();
-        const float *fl = reinterpret_cast<const float *>(&flush[0][0]);
+        // ---- flush: transpose through LDS, one atomic row per touched splat (A rows, then B rows) ----
         const int col = lane & 15;
         const bool col_used = col < REC_CH0 + D || col >= REC_ABSX;
+        const float *fl = reinterpret_cast<const float *>(&flush[0][0]);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int row = j * 4 + (lane >> 4);
-            const int rgid = __shfl(gid, row, DNS_WAVE);
-            const float val = fl[j * 64 + lane];
-            if (((tmask >> row) & 1) && col_used) unsafeAtomicAdd(a.v_splats + (size_t)rgid * DNS_REC + col, val);
+        for (int half = 0; half < 2; ++half) {
+            const int gid = half ? gid_b : gid_a;
+#define SEL(v) (half ? (v).y : (v).x)
+            flush[lane][0] = make_float4(SEL(g_x), SEL(g_y), 0.5f * SEL(g_ca), SEL(g_cb));
+            flush[lane][1] = make_float4(0.5f * SEL(g_cc), SEL(g_o), SEL(g_ch[0]), SEL(g_ch[1]));
+            flush[lane][2] = make_float4(SEL(g_ch[2]), SEL(g_ch[3]), SEL(g_ch[4]), SEL(g_ch[5]));
+            flush[lane][3] = make_float4(SEL(g_ch[6]), SEL(g_ch[7]), SEL(g_ax), SEL(g_ay));
+#undef SEL
+            const uint64_t tmask = __ballot(half ? touched_b : touched_a);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int row = j * 4 + (lane >> 4);
+                const int rgid = __shfl(gid, row, DNS_WAVE);
+                const float val = fl[j * 64 + lane];
+                if (((tmask >> row) & 1) && col_used) unsafeAtomicAdd(a.v_splats + (size_t)rgid * DNS_REC + col, val);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
