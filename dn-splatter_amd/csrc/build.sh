@@ -1,6 +1,8 @@
 #!/usr/bin/env bash
 # Builds libdnsplat.so for gfx950 (MI355X) in-tree.  project.hip is compiled without FMA contraction
 # (bit-exact radii / tile counts against the oracle); the compositing kernels keep contraction on.
+# raster_bwd.hip: SLP vectorisation off — its packed-fp32 pairs are written out by hand, and the SLP pass
+# re-packs the remaining scalar chains at the price of extra v_mov (measured +5 % cycles per step).
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
@@ -10,7 +12,7 @@ pids=()
 $HIPCC $COMMON -ffp-contract=off -c project.hip    -o _obj/project.o & pids+=($!)
 $HIPCC $COMMON                   -c binning.hip    -o _obj/binning.o & pids+=($!)
 $HIPCC $COMMON                   -c raster_fwd.hip -o _obj/raster_fwd.o & pids+=($!)
-$HIPCC $COMMON                   -c raster_bwd.hip -o _obj/raster_bwd.o & pids+=($!)
+$HIPCC $COMMON -fno-slp-vectorize -c raster_bwd.hip -o _obj/raster_bwd.o & pids+=($!)
 $HIPCC $COMMON                   -c c_api.hip      -o _obj/c_api.o & pids+=($!)
 $HIPCC $COMMON -ffp-contract=off -c postops.hip    -o _obj/postops.o & pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done

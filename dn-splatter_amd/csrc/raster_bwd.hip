@@ -286,7 +286,11 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
         float T_out = 0.f, SA_out = 0.f, SB_out = 0.f;
         // The pixel row of the step is requested first and waited for only after the row-independent part
         // (pixel coordinates, exponents, exp2) has been issued, which covers the LDS latency.
+#ifdef DNS_BWD_SKIP_LOOP
+        for (int s = 0; s < 0; ++s) {
+#else
         for (int s = 0; s < NPIX + DNS_WAVE - 1; ++s) {
+#endif
             const int p = s - lane;
             const bool active = (unsigned)p < (unsigned)NPIX;
             int pcur = p & (NPIX - 1);
@@ -319,12 +323,18 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
                 const float T1 = T * ra.x, T2 = T1 * ra.y;          // the pixel meets A, then B
                 const f2 Tv = {T1, T2};
                 const f2 fac = alpha * Tv;
-                const float pvv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                // the pixel's cotangents as aligned register pairs; a channel is broadcast to both splats by
+                // selecting one half of its pair (op_sel), not by copying it
+                const f2 pp[4] = {__builtin_shufflevector(c0, c0, 0, 1), __builtin_shufflevector(c0, c0, 2, 3),
+                                  __builtin_shufflevector(c1, c1, 0, 1), __builtin_shufflevector(c1, c1, 2, 3)};
                 f2 cva = zero2, cvb = zero2;
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
-                    const f2 vk = {pvv[k], pvv[k]};
-                    g_ch[k] = __builtin_elementwise_fma(fac, vk, g_ch[k]);
+                    const f2 vk = (k & 1) ? __builtin_shufflevector(pp[k >> 1], pp[k >> 1], 1, 1)
+                                          : __builtin_shufflevector(pp[k >> 1], pp[k >> 1], 0, 0);
+                    // two plain v_fmac: hipcc would materialise the broadcast pair for a packed FMA here
+                    g_ch[k].x = __builtin_fmaf(fac.x, vk.x, g_ch[k].x);
+                    g_ch[k].y = __builtin_fmaf(fac.y, vk.y, g_ch[k].y);
                     if (k < split) cva = __builtin_elementwise_fma(ch[k], vk, cva);
                     else cvb = __builtin_elementwise_fma(ch[k], vk, cvb);
                 }

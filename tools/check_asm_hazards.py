@@ -27,7 +27,7 @@ def regs_of(line):
 
 def check() -> int:
     with tempfile.TemporaryDirectory() as tmp:
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-save-temps", "-c", SRC,
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-save-temps", "-c", SRC,
                         "-o", os.path.join(tmp, "rb.o")], cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         asm = open(os.path.join(tmp, "raster_bwd-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     kernels = re.findall(r"^(_ZN\S*raster_bwd_kernel\S*):", asm, re.M)
