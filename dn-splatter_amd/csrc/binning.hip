@@ -127,12 +127,21 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ n_ptr, uint32_t n_cap, int shift,
     const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nb)
 {
+    // The chunk is first sorted by digit INSIDE LDS (stable), then written out run by run: consecutive lanes
+    // store to consecutive addresses of one digit's run, so the stores coalesce.  A direct scatter from the
+    // ranking registers sends the 64 lanes of one store instruction to up to 64 different cache lines and
+    // ran at a quarter of this version's rate on the 21 M-entry tile passes.
     __shared__ uint32_t wave_cnt[RS_WAVES][RS_DIGITS];
-    __shared__ uint32_t wave_base[RS_WAVES][RS_DIGITS];
+    __shared__ uint32_t wave_loc[RS_WAVES][RS_DIGITS];   // chunk-local position of a (wave, digit) run
+    __shared__ uint32_t dstart[RS_DIGITS];               // chunk-local start of a digit's run
+    __shared__ uint32_t gbase[RS_DIGITS];                // global start of this chunk's run of a digit
+    __shared__ uint32_t keys_s[RS_CHUNK];
+    __shared__ uint32_t vals_s[RS_CHUNK];
     __shared__ uint32_t lds_wave[4];
     const uint32_t n = min(*n_ptr, n_cap);
     const uint32_t base = blockIdx.x * RS_CHUNK;
     if (base >= n) return;
+    const uint32_t n_valid = min((uint32_t)RS_CHUNK, n - base);
     const int w = threadIdx.x / DNS_WAVE;
     const uint32_t lane = lane_id();
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -165,16 +174,22 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     }
     __syncthreads();
     {
-        // digit d = threadIdx.x: global base = (#keys with smaller digit) + (#same digit in earlier blocks)
-        const uint32_t tot = totals[threadIdx.x];
+        // digit d = threadIdx.x
+        const uint32_t c0 = wave_cnt[0][threadIdx.x], c1 = wave_cnt[1][threadIdx.x], c2 = wave_cnt[2][threadIdx.x],
+                       c3 = wave_cnt[3][threadIdx.x];
+        const uint32_t cnt = c0 + c1 + c2 + c3;
         uint32_t t2;
-        const uint32_t inc = block_incl_scan_256(tot, lds_wave, t2);
-        uint32_t run = (inc - tot) + table[(size_t)threadIdx.x * nb + blockIdx.x];
-#pragma unroll
-        for (int i = 0; i < RS_WAVES; ++i) {
-            wave_base[i][threadIdx.x] = run;
-            run += wave_cnt[i][threadIdx.x];
-        }
+        const uint32_t linc = block_incl_scan_256(cnt, lds_wave, t2);     // chunk-local exclusive start
+        const uint32_t ls = linc - cnt;
+        dstart[threadIdx.x] = ls;
+        wave_loc[0][threadIdx.x] = ls;
+        wave_loc[1][threadIdx.x] = ls + c0;
+        wave_loc[2][threadIdx.x] = ls + c0 + c1;
+        wave_loc[3][threadIdx.x] = ls + c0 + c1 + c2;
+        // global base = (#keys with smaller digit) + (#same digit in earlier chunks)
+        const uint32_t tot = totals[threadIdx.x];
+        const uint32_t ginc = block_incl_scan_256(tot, lds_wave, t2);
+        gbase[threadIdx.x] = (ginc - tot) + table[(size_t)threadIdx.x * nb + blockIdx.x];
     }
     __syncthreads();
 #pragma unroll
@@ -182,9 +197,21 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         const uint32_t idx = wave_start + r * DNS_WAVE + lane;
         if (idx < n) {
             const uint32_t d = (key[r] >> shift) & 0xff;
-            const uint32_t dst = wave_base[w][d] + rnk[r];
-            if (WRITE_KEYS) keys_out[dst] = key[r];
-            vals_out[dst] = val[r];
+            const uint32_t lpos = wave_loc[w][d] + rnk[r];
+            keys_s[lpos] = key[r];
+            vals_s[lpos] = val[r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const uint32_t i = r * RS_THREADS + threadIdx.x;
+        if (i < n_valid) {
+            const uint32_t k = keys_s[i];
+            const uint32_t d = (k >> shift) & 0xff;
+            const uint32_t dst = gbase[d] + (i - dstart[d]);
+            if (WRITE_KEYS) keys_out[dst] = k;
+            vals_out[dst] = vals_s[i];
         }
     }
 }
