@@ -206,6 +206,8 @@ def main():
                                    f"closed-form 3-NN scale init",
                        "N": N, "Nv": Nv, "n_isects": I, "mean_isects_per_rank": i_all / world,
                        "mean_tile_list_len": round(I / T, 1), "pixels": P, "bin_policy": args.bin_policy,
+                       "allreduce_bytes_per_step": wire,
+                       "grads_in_flat_bucket": bool(all(arena.holds(gp[k].grad) for k in dp.GRAD_KEYS)),
                        "parallelism": f"dp{world} (camera per GPU, RCCL all-reduce of {wire} B/step)" if world > 1 else "single GPU"},
             "roofline": roofline,
             "frame_roofline": frame_roofline,
@@ -221,7 +223,7 @@ def main():
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(res))
     dp.barrier()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

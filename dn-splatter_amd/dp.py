@@ -80,7 +80,8 @@ def init_from_env(device_type: Optional[str] = None):
         device = torch.device("cuda", local)
     else:
         device = torch.device("cpu")
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("DNSPLAT_FORCE_DIST", "0") == "1"   # exercise the collective path with a single rank
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         backend = "nccl" if device_type == "cuda" else "gloo"
@@ -93,10 +94,17 @@ def world_size(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def _collectives_on(group=None) -> bool:
+    """True when a process group exists and either has > 1 rank or was forced on for testing."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("DNSPLAT_FORCE_DIST", "0") == "1"
+
+
 def allreduce_mean_(t: Tensor, group=None, async_op: bool = False):
     """In-place mean over ranks.  RCCL has a native AVG; gloo sums and we scale."""
     w = world_size(group)
-    if w == 1:
+    if not _collectives_on(group):
         return None
     if t.is_cuda:
         return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
@@ -110,7 +118,7 @@ def allreduce_gradients(params: Dict[str, Tensor], arena: Optional[GradArena] = 
 
     Fast path: every grad is a slice of ``arena`` -> one in-place collective over the bucket.
     Otherwise the grads are packed into a temporary bucket, reduced and copied back."""
-    if world_size(group) == 1:
+    if not _collectives_on(group):
         return 0
     grads = [params[k].grad for k in GRAD_KEYS]
     if arena is not None and all(arena.holds(g) for g in grads):
@@ -129,12 +137,12 @@ def allreduce_gradients(params: Dict[str, Tensor], arena: Optional[GradArena] = 
 
 
 def barrier(group=None) -> None:
-    if world_size(group) > 1:
+    if _collectives_on(group):
         dist.barrier(group)
 
 
 def max_over_ranks(value: float, device, group=None) -> float:
-    if world_size(group) == 1:
+    if not _collectives_on(group):
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
@@ -143,6 +151,6 @@ def max_over_ranks(value: float, device, group=None) -> float:
 
 def sum_over_ranks(values: Iterable[float], device, group=None):
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
-    if world_size(group) > 1:
+    if _collectives_on(group):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t.tolist()
