@@ -109,7 +109,8 @@ template <int D, int SPLIT, bool DN>
 __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
 {
     __shared__ float4 pix[NPIX][3];            // [p][0..1] = v_k, [p][2] = (T, S_a, S_b, bin_final)
-    __shared__ float4 flush[DNS_WAVE][4];      // gradient rows staged for the transposed flush
+    __shared__ float4 flush[16][4];            // 16 gradient rows at a time staged for the transposed flush (1 KiB:
+                                               // LDS per wave decides how many tiles a CU works on at once)
     __shared__ int32_t queue[QCAP];            // compacted list indices waiting for a bucket
 
     const int tile = dns_xcd_remap(blockIdx.x, a.n_tiles);
@@ -368,28 +369,38 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
         }
 
         // ---- flush: transpose through LDS, one atomic row per touched splat (A rows, then B rows) ----
+        // Sixteen lanes at a time park their 16 partial sums; then the whole wave adds those 16 records to
+        // global memory with 4 atomic instructions, each covering 4 complete 64-byte records.
         const int col = lane & 15;
         const bool col_used = col < REC_CH0 + D || col >= REC_ABSX;
         const float *fl = reinterpret_cast<const float *>(&flush[0][0]);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int gid = half ? gid_b : gid_a;
-#define SEL(v) (half ? (v).y : (v).x)
-            flush[lane][0] = make_float4(SEL(g_x), SEL(g_y), 0.5f * SEL(g_ca), SEL(g_cb));
-            flush[lane][1] = make_float4(0.5f * SEL(g_cc), SEL(g_o), SEL(g_ch[0]), SEL(g_ch[1]));
-            flush[lane][2] = make_float4(SEL(g_ch[2]), SEL(g_ch[3]), SEL(g_ch[4]), SEL(g_ch[5]));
-            flush[lane][3] = make_float4(SEL(g_ch[6]), SEL(g_ch[7]), SEL(g_ax), SEL(g_ay));
-#undef SEL
             const uint64_t tmask = __ballot(half ? touched_b : touched_a);
-            __builtin_amdgcn_wave_barrier();
+#define SEL(v) (half ? (v).y : (v).x)
+            const float4 f0 = make_float4(SEL(g_x), SEL(g_y), 0.5f * SEL(g_ca), SEL(g_cb));
+            const float4 f1 = make_float4(0.5f * SEL(g_cc), SEL(g_o), SEL(g_ch[0]), SEL(g_ch[1]));
+            const float4 f2v = make_float4(SEL(g_ch[2]), SEL(g_ch[3]), SEL(g_ch[4]), SEL(g_ch[5]));
+            const float4 f3 = make_float4(SEL(g_ch[6]), SEL(g_ch[7]), SEL(g_ax), SEL(g_ay));
+#undef SEL
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int row = j * 4 + (lane >> 4);
-                const int rgid = __shfl(gid, row, DNS_WAVE);
-                const float val = fl[j * 64 + lane];
-                if (((tmask >> row) & 1) && col_used) unsafeAtomicAdd(a.v_splats + (size_t)rgid * DNS_REC + col, val);
+            for (int q = 0; q < 4; ++q) {
+                if (((tmask >> (16 * q)) & 0xffffull) == 0) continue;     // wave-uniform: none of these 16 splats touched
+                if ((lane >> 4) == q) {
+                    flush[lane & 15][0] = f0; flush[lane & 15][1] = f1; flush[lane & 15][2] = f2v; flush[lane & 15][3] = f3;
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = j * 4 + (lane >> 4);          // 0..15 within this group of lanes
+                    const int src = 16 * q + row;                 // the lane that owns that splat
+                    const int rgid = __shfl(gid, src, DNS_WAVE);
+                    const float val = fl[j * 64 + lane];
+                    if (((tmask >> src) & 1) && col_used) unsafeAtomicAdd(a.v_splats + (size_t)rgid * DNS_REC + col, val);
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
         }
     }
 }
