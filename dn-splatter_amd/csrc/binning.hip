@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void depth_keys_kernel(int N, const int32_t *_
 // 2. one LSD radix pass = histogram, per-digit scan, stable scatter
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t *__restrict__ keys,
                                                                 const uint32_t *__restrict__ n_ptr, uint32_t n_cap,
-                                                                int shift, uint32_t *__restrict__ table, int nb)
+                                                                int shift, uint32_t mask, uint32_t *__restrict__ table,
+                                                                int nb)
 {
     __shared__ uint32_t hist[RS_DIGITS];
     const uint32_t n = min(*n_ptr, n_cap);
@@ -96,11 +97,11 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t *
 #pragma unroll
         for (int i = 0; i < RS_ITEMS; ++i) {
             uint32_t idx = base + i * RS_THREADS + threadIdx.x;
-            if (idx < n) atomicAdd(&hist[(keys[idx] >> shift) & 0xff], 1u);
+            if (idx < n) atomicAdd(&hist[(keys[idx] >> shift) & mask], 1u);
         }
     }
     __syncthreads();
-    table[(size_t)threadIdx.x * nb + blockIdx.x] = hist[threadIdx.x];
+    if (threadIdx.x <= mask) table[(size_t)threadIdx.x * nb + blockIdx.x] = hist[threadIdx.x];
 }
 
 // one workgroup per digit: exclusive scan of table[d][0..nb) in place, totals[d] = row sum
@@ -121,7 +122,9 @@ __global__ __launch_bounds__(SC_THREADS) void radix_scan_kernel(uint32_t *__rest
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-template <bool WRITE_KEYS>
+// DBITS = digit width of this pass (<= 8): the tile passes split their 13 bits 7 + 6 instead of 8 + 8 — fewer
+// ballots per key and longer per-digit runs for the coalesced run stores.
+template <bool WRITE_KEYS, int DBITS>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ n_ptr, uint32_t n_cap, int shift,
@@ -138,6 +141,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     __shared__ uint32_t keys_s[RS_CHUNK];
     __shared__ uint32_t vals_s[RS_CHUNK];
     __shared__ uint32_t lds_wave[4];
+    constexpr uint32_t DMASK = (1u << DBITS) - 1u;
     const uint32_t n = min(*n_ptr, n_cap);
     const uint32_t base = blockIdx.x * RS_CHUNK;
     if (base >= n) return;
@@ -158,11 +162,11 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         const bool valid = idx < n;
         key[r] = valid ? keys_in[idx] : 0u;
         val[r] = valid ? vals_in[idx] : 0u;
-        const uint32_t d = (key[r] >> shift) & 0xff;
-        // match-any by digit: 8 ballots partition the wave into equal-digit lane sets
+        const uint32_t d = (key[r] >> shift) & DMASK;
+        // match-any by digit: DBITS ballots partition the wave into equal-digit lane sets
         uint64_t m = __ballot(valid);
 #pragma unroll
-        for (int bit = 0; bit < 8; ++bit) {
+        for (int bit = 0; bit < DBITS; ++bit) {
             const bool b = (d >> bit) & 1;
             const uint64_t bal = __ballot(b);
             m &= b ? bal : ~bal;
@@ -187,16 +191,17 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         wave_loc[2][threadIdx.x] = ls + c0 + c1;
         wave_loc[3][threadIdx.x] = ls + c0 + c1 + c2;
         // global base = (#keys with smaller digit) + (#same digit in earlier chunks)
-        const uint32_t tot = totals[threadIdx.x];
+        const bool is_digit = threadIdx.x <= DMASK;
+        const uint32_t tot = is_digit ? totals[threadIdx.x] : 0u;
         const uint32_t ginc = block_incl_scan_256(tot, lds_wave, t2);
-        gbase[threadIdx.x] = (ginc - tot) + table[(size_t)threadIdx.x * nb + blockIdx.x];
+        gbase[threadIdx.x] = is_digit ? (ginc - tot) + table[(size_t)threadIdx.x * nb + blockIdx.x] : 0u;
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         const uint32_t idx = wave_start + r * DNS_WAVE + lane;
         if (idx < n) {
-            const uint32_t d = (key[r] >> shift) & 0xff;
+            const uint32_t d = (key[r] >> shift) & DMASK;
             const uint32_t lpos = wave_loc[w][d] + rnk[r];
             keys_s[lpos] = key[r];
             vals_s[lpos] = val[r];
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         const uint32_t i = r * RS_THREADS + threadIdx.x;
         if (i < n_valid) {
             const uint32_t k = keys_s[i];
-            const uint32_t d = (k >> shift) & 0xff;
+            const uint32_t d = (k >> shift) & DMASK;
             const uint32_t dst = gbase[d] + (i - dstart[d]);
             if (WRITE_KEYS) keys_out[dst] = k;
             vals_out[dst] = vals_s[i];
@@ -403,6 +408,28 @@ BinWs carve(void *ws, int N, int64_t cap)
     return b;
 }
 
+// one LSD pass over `dbits` bits at `shift`
+void radix_pass(hipStream_t stream, const uint32_t *ka, const uint32_t *va, uint32_t *kb, uint32_t *vb, const uint32_t *n_ptr,
+                uint32_t n_cap, int shift, int dbits, uint32_t *table, uint32_t *totals, int nb)
+{
+    const uint32_t mask = (1u << dbits) - 1u;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(RS_THREADS), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(1 << dbits), dim3(SC_THREADS), 0, stream, table, nb, totals);
+#define DNS_SCATTER(B) hipLaunchKernelGGL((radix_scatter_kernel<true, B>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb, \
+                                          n_ptr, n_cap, shift, table, totals, nb)
+    switch (dbits) {
+        case 1: DNS_SCATTER(1); break;
+        case 2: DNS_SCATTER(2); break;
+        case 3: DNS_SCATTER(3); break;
+        case 4: DNS_SCATTER(4); break;
+        case 5: DNS_SCATTER(5); break;
+        case 6: DNS_SCATTER(6); break;
+        case 7: DNS_SCATTER(7); break;
+        default: DNS_SCATTER(8); break;
+    }
+#undef DNS_SCATTER
+}
+
 int tile_bits(int n_tiles)
 {
     int bits = 1;
@@ -448,11 +475,7 @@ extern "C" int dnsplat_bin_prepare(const dnsplat_bin_args *a, dnsplat_stream_t s
         uint32_t *ka = w.key_a, *kb = w.key_b, *va = w.val_a, *vb = w.val_b;
         for (int pass = 0; pass < 4; ++pass) {
             const int shift = 8 * pass;
-            hipLaunchKernelGGL(radix_hist_kernel, dim3(w.nb_n), dim3(RS_THREADS), 0, stream, ka, w.n_gauss, n_u32, shift,
-                               w.tab_n, w.nb_n);
-            hipLaunchKernelGGL(radix_scan_kernel, dim3(RS_DIGITS), dim3(SC_THREADS), 0, stream, w.tab_n, w.nb_n, w.totals);
-            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(w.nb_n), dim3(RS_THREADS), 0, stream, ka, va, kb, vb,
-                               w.n_gauss, n_u32, shift, w.tab_n, w.totals, w.nb_n);
+            radix_pass(stream, ka, va, kb, vb, w.n_gauss, n_u32, shift, 8, w.tab_n, w.totals, w.nb_n);
             uint32_t *t = ka; ka = kb; kb = t;
             t = va; va = vb; vb = t;
         }
@@ -491,15 +514,13 @@ extern "C" int dnsplat_bin_emit_sort(const dnsplat_bin_args *a, dnsplat_stream_t
     const int bits = tile_bits(n_tiles);
     const int passes = (bits + 7) / 8;
     uint32_t *ka = w.tkey_a, *kb = w.tkey_b, *va = w.tval_a, *vb = w.tval_b;
+    int shift = 0;
     for (int pass = 0; pass < passes; ++pass) {
-        const int shift = 8 * pass;
+        const int dbits = (bits - shift + (passes - pass) - 1) / (passes - pass);   // 13 bits -> 7 + 6
         const bool last = pass == passes - 1;
         uint32_t *vout = last ? (uint32_t *)a->flatten_ids : vb;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(w.nb_i), dim3(RS_THREADS), 0, stream, ka, w.total, cap, shift, w.tab_i,
-                           w.nb_i);
-        hipLaunchKernelGGL(radix_scan_kernel, dim3(RS_DIGITS), dim3(SC_THREADS), 0, stream, w.tab_i, w.nb_i, w.totals);
-        hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(w.nb_i), dim3(RS_THREADS), 0, stream, ka, va, kb, vout, w.total,
-                           cap, shift, w.tab_i, w.totals, w.nb_i);
+        radix_pass(stream, ka, va, kb, vout, w.total, cap, shift, dbits, w.tab_i, w.totals, w.nb_i);
+        shift += dbits;
         uint32_t *t = ka; ka = kb; kb = t;
         t = va; va = vb; vb = t;
     }
