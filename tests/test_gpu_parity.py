@@ -69,8 +69,10 @@ def test_c1_rasterization_matches_oracle(dns, orc):
     fp32 noise there and that gradient is compared with an absolute tolerance."""
     inp, viewmat, K, _ = gsplat_inputs(10_000, 256, 256, focal=160.0, seed=0)
     o, g = _call_both(dns, orc, inp, viewmat, K, 256, 256, sh_degree=3, render_mode="RGB+ED", absgrad=True)
-    _check_forward(o, g)
-    _check_backward(o, g, quat_atol=1e-4)
+    # observed on this scene: every tensor within 2e-5 of its scale; the cut-off flip allowance (see _scenes.py)
+    # only guards against a single (pixel, splat) threshold decision landing differently
+    _check_forward(o, g, flips=FLIP_FRACTION)
+    _check_backward(o, g, quat_atol=1e-4, flips=FLIP_FRACTION)
 
 
 def test_c1_anisotropic_rasterization_matches_oracle(dns, orc):
