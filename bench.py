@@ -58,7 +58,7 @@ def stage_bytes(N, Nv, I, P, T):
     }
 
 
-def cpu_baseline(workload, crop=256):
+def cpu_baseline(workload, crop=512):
     """Times the CPU oracle — the reference's own two-call sequence (rasterization + legacy
     rasterize_gaussians, dn_model.py:495-575) through the same host mirror — on a centre crop of the same
     scene and scales by the pixel ratio.  Test infrastructure used as the checker/baseline only."""
