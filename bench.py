@@ -39,6 +39,7 @@ WORKLOADS = {
     "c1": (10_000, 256, 256, 160.0),
     "c2": (1_000_000, 1920, 1080, 1200.0),
     "c3": (3_000_000, 1600, 1200, 1200.0),
+    "c5": (5_000_000, 1600, 1200, 1200.0),   # configs[4]: per GPU of the 8-GPU run, normally with --losses
 }
 
 OUT_KEYS = ("rgb", "depth", "normal", "accumulation")
@@ -108,6 +109,9 @@ def main():
     ap.add_argument("--bin-policy", default="capacity", choices=["sync", "capacity"])
     ap.add_argument("--two-call", action="store_true", help="reference's two-pass sequence instead of the fused pass")
     ap.add_argument("--torch-postops", action="store_true", help="keep dn_model.py:526-603 in torch instead of the HIP epilogue")
+    ap.add_argument("--losses", action="store_true",
+                    help="time dn-splatter's PyTorch loss stack (L1+SSIM, EdgeAwareLogL1 depth, normal L1+TV, scale) instead of "
+                         "feeding random cotangents (BASELINE config C5)")
     args = ap.parse_args()
 
     import dn_splatter_amd as dns
@@ -132,12 +136,20 @@ def main():
     shapes = {"rgb": (H, W, 3), "depth": (H, W, 1), "normal": (H, W, 3), "accumulation": (H, W, 1)}
     cot = {k: torch.rand(shapes[k], device=dev, generator=gen) * 2 - 1 for k in OUT_KEYS}
 
+    batch = None
+    if args.losses:
+        from dn_splatter_amd import torch_losses
+        batch = torch_losses.synthetic_batch(W, H, dev, seed=rank)
+
     def step():
         for k in dp.GRAD_KEYS:
             gp[k].grad = None
         out = renderer.get_outputs(cam)
-        # the losses stay in PyTorch (north star); their result is a dense cotangent per output image
-        torch.autograd.backward([out[k] for k in OUT_KEYS], [cot[k] for k in OUT_KEYS])
+        if batch is not None:
+            torch_losses.dn_loss(out, batch, gp["scales"]).backward()
+        else:
+            # the losses stay in PyTorch (north star); their result is a dense cotangent per output image
+            torch.autograd.backward([out[k] for k in OUT_KEYS], [cot[k] for k in OUT_KEYS])
         return dp.allreduce_gradients(gp, arena)
 
     for _ in range(args.warmup):
@@ -204,7 +216,7 @@ def main():
             "config": {"workload": f"{args.workload}: {N} random-init Gaussians, 1 camera/GPU {W}x{H}, SH degree 3 + "
                                    f"expected depth + per-Gaussian normals ({D_CH} channels, "
                                    f"{'two-call' if args.two_call else 'fused one-pass'}, post-ops in {'torch' if (args.torch_postops or args.two_call) else 'HIP'}), fx=fy={focal}, orbit r=8, "
-                                   f"closed-form 3-NN scale init",
+                                   f"closed-form 3-NN scale init, {'dn-splatter PyTorch loss stack' if args.losses else 'random dense cotangents'}",
                        "N": N, "Nv": Nv, "n_isects": I, "mean_isects_per_rank": i_all / world,
                        "mean_tile_list_len": round(I / T, 1), "pixels": P, "bin_policy": args.bin_policy,
                        "allreduce_bytes_per_step": wire,

@@ -103,7 +103,7 @@ EXPORTS = [
     "dnsplat_project_fwd", "dnsplat_pack_splats",
     "dnsplat_bin_workspace_bytes", "dnsplat_bin_prepare", "dnsplat_bin_emit_sort", "dnsplat_bin_isect_ids",
     "dnsplat_raster_fwd", "dnsplat_raster_bwd",
-    "dnsplat_dn_depth_normals", "dnsplat_camera_prepare",
+    "dnsplat_dn_depth_normals", "dnsplat_camera_prepare", "dnsplat_densify_stats",
     "dnsplat_project_bwd",
 ]
 
@@ -145,6 +145,7 @@ def lib() -> ctypes.CDLL:
         L.dnsplat_raster_bwd.argtypes = [ctypes.POINTER(RasterArgs), c_void_p]
         L.dnsplat_dn_depth_normals.argtypes = [c_int32, c_int32, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p]
+        L.dnsplat_densify_stats.argtypes = [c_int32, c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]
         L.dnsplat_camera_prepare.argtypes = [c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                              c_void_p]
         if L.dnsplat_abi_version() != ABI_VERSION:

@@ -83,7 +83,36 @@ __global__ void camera_prepare_kernel(const float *__restrict__ c2w, float fx, f
     }
 }
 
+__global__ __launch_bounds__(256) void densify_stats_kernel(int N, const int32_t *__restrict__ radii,
+                                                            const float *__restrict__ xy_grads, int stride, float inv_max_size,
+                                                            float *__restrict__ grad_norm, float *__restrict__ vis,
+                                                            float *__restrict__ max2d)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    const int r = radii[g];
+    if (r <= 0) return;
+    const float gx = xy_grads[(size_t)g * stride], gy = xy_grads[(size_t)g * stride + 1];
+    grad_norm[g] += sqrtf(gx * gx + gy * gy);
+    vis[g] += 1.f;
+    // torch divides a tensor by a python scalar as a multiply by its fp32 reciprocal; do the same
+    max2d[g] = fmaxf(max2d[g], (float)r * inv_max_size);
+}
+
 }  // namespace
+
+extern "C" int dnsplat_densify_stats(int32_t N, const int32_t *radii, const float *xy_grads, int32_t grad_stride,
+                                     float inv_max_size, float *xys_grad_norm, float *vis_counts, float *max_2Dsize,
+                                     dnsplat_stream_t stream)
+{
+    if (N < 0 || grad_stride < 2) return DNSPLAT_ERR_INVALID_ARG;
+    if (N == 0) return DNSPLAT_OK;
+    if (!radii || !xy_grads || !xys_grad_norm || !vis_counts || !max_2Dsize) return DNSPLAT_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(densify_stats_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, radii, xy_grads,
+                       grad_stride, inv_max_size, xys_grad_norm, vis_counts, max_2Dsize);
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}
 
 extern "C" int dnsplat_dn_depth_normals(int32_t width, int32_t height, float fx, float fy, float cx, float cy,
                                         const float *depth, const float *alphas, const float *depth_max,

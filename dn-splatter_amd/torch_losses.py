@@ -1,0 +1,101 @@
+"""The per-pixel losses of dn-splatter, kept in PyTorch-ROCm (BASELINE.json north star: "the per-pixel
+depth/normal losses ... in dn_splatter/losses.py stay in PyTorch-ROCm").
+
+This is the host-side restatement that BASELINE config C5 ("depth + mono-normal loss enabled") times together
+with the renderer; nothing here is a kernel of ours.  It follows
+
+* ``DNSplatterModel.get_loss_dict``                      dn_splatter/dn_model.py:614-729
+* ``DNRegularization.get_loss`` / depth / normal / scale dn_splatter/regularization_strategy.py:146-199
+* ``EdgeAwareLogL1``, ``LogL1``, ``L1``, ``TVLoss``      dn_splatter/losses.py:154-224, 279-295
+* the inherited RGB term of nerfstudio's ``SplatfactoModel.get_loss_dict``: ``(1 - l) * L1 + l * (1 - SSIM)`` with
+  ``l = ssim_lambda = 0.2`` and pytorch_msssim's SSIM (11x11 Gaussian window, sigma 1.5, valid padding,
+  data_range 1) — neither nerfstudio nor pytorch_msssim is vendored in the reference, so that term is restated
+  from their published definitions.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+
+def _gaussian_window(size: int = 11, sigma: float = 1.5, device=None) -> Tensor:
+    x = torch.arange(size, dtype=torch.float32, device=device) - size // 2
+    g = torch.exp(-(x ** 2) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+def ssim(pred: Tensor, gt: Tensor, data_range: float = 1.0) -> Tensor:
+    """Mean SSIM of two [H,W,3] images (separable 11-tap Gaussian, valid padding)."""
+    x = pred.permute(2, 0, 1)[None]
+    y = gt.permute(2, 0, 1)[None]
+    C = x.shape[1]
+    w = _gaussian_window(device=x.device)
+    wh = w.view(1, 1, -1, 1).repeat(C, 1, 1, 1)
+    ww = w.view(1, 1, 1, -1).repeat(C, 1, 1, 1)
+
+    def blur(t):
+        return F.conv2d(F.conv2d(t, wh, groups=C), ww, groups=C)
+
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    mu_x, mu_y = blur(x), blur(y)
+    sxx = blur(x * x) - mu_x * mu_x
+    syy = blur(y * y) - mu_y * mu_y
+    sxy = blur(x * y) - mu_x * mu_y
+    cs = (2 * sxy + c2) / (sxx + syy + c2)
+    s = ((2 * mu_x * mu_y + c1) / (mu_x * mu_x + mu_y * mu_y + c1)) * cs
+    return s.mean()
+
+
+def edge_aware_log_l1(pred: Tensor, gt: Tensor, rgb: Tensor, mask: Optional[Tensor]) -> Tensor:
+    """losses.py:187-224, implementation="scalar"."""
+    logl1 = torch.log(1 + torch.abs(pred - gt))
+    grad_img_x = torch.mean(torch.abs(rgb[..., :, :-1, :] - rgb[..., :, 1:, :]), -1, keepdim=True)
+    grad_img_y = torch.mean(torch.abs(rgb[..., :-1, :, :] - rgb[..., 1:, :, :]), -1, keepdim=True)
+    loss_x = torch.exp(-grad_img_x) * logl1[..., :, :-1, :]
+    loss_y = torch.exp(-grad_img_y) * logl1[..., :-1, :, :]
+    if mask is not None:
+        loss_x = loss_x[mask[..., :, :-1, :]]
+        loss_y = loss_y[mask[..., :-1, :, :]]
+    return loss_x.mean() + loss_y.mean()
+
+
+def tv_loss(pred: Tensor) -> Tensor:
+    """losses.py:279-295."""
+    h_diff = pred[..., :, :-1, :] - pred[..., :, 1:, :]
+    w_diff = pred[..., :-1, :, :] - pred[..., 1:, :, :]
+    return torch.mean(torch.abs(h_diff)) + torch.mean(torch.abs(w_diff))
+
+
+def dn_loss(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], scales: Tensor, ssim_lambda: float = 0.2,
+            depth_lambda: float = 0.2, depth_tolerance: float = 0.1, use_depth_loss: bool = True,
+            use_normal_loss: bool = True) -> Tensor:
+    """main_loss of ``DNSplatterModel.get_loss_dict`` for regularization_strategy == "dn-splatter" with mono depth
+    and mono normal supervision (dn_model.py:614-729)."""
+    gt_img = batch["image"].clamp(min=10 / 255.0)                                   # dn_model.py:633
+    pred_img = outputs["rgb"]
+    ll1 = torch.abs(batch["image"] - pred_img).mean()
+    simloss = 1 - ssim(pred_img, batch["image"])
+    loss = (1 - ssim_lambda) * ll1 + ssim_lambda * simloss                          # nerfstudio splatfacto
+    if use_depth_loss and "mono_depth" in batch:
+        gt_depth = batch["mono_depth"]
+        valid = gt_depth > depth_tolerance                                          # regularization_strategy.py:162
+        d = edge_aware_log_l1(outputs["depth"], gt_depth.float(), gt_img, valid)
+        d = d + depth_lambda * d                                                    # :184
+        loss = loss + d
+    if use_normal_loss and "normal" in batch:
+        n = torch.abs(outputs["normal"] - batch["normal"]).mean() + tv_loss(outputs["normal"])   # :188-193
+        loss = loss + n
+    loss = loss + torch.min(torch.exp(scales), dim=1, keepdim=True)[0].mean()       # :195-199
+    return loss
+
+
+def synthetic_batch(width: int, height: int, device, seed: int = 0) -> Dict[str, Tensor]:
+    """Random ground truth with the shapes the datamanager hands over (dn_datamanager.py:90-150)."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(height, width, 3, generator=g)
+    depth = torch.rand(height, width, 1, generator=g) * 9.0 + 0.5
+    nrm = F.normalize(torch.randn(height, width, 3, generator=g), dim=-1)
+    return {"image": img.to(device), "mono_depth": depth.to(device), "normal": ((nrm + 1) / 2).to(device)}

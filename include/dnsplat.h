@@ -216,6 +216,15 @@ int dnsplat_dn_depth_normals(int32_t width, int32_t height, float fx, float fy, 
 int dnsplat_camera_prepare(const float *c2w, float fx, float fy, float cx, float cy,
                            float *viewmat, float *K, float *normal_frame, dnsplat_stream_t stream);
 
+/* Densification statistics: the per-step accumulation nerfstudio's SplatfactoModel.after_train
+ * performs on the renderer's outputs (called at dn_model.py:938-942, consumed by refinement_after dn_model.py:286-296):
+ * for every Gaussian with radii > 0
+ *     xys_grad_norm += |(gx, gy)|,  vis_counts += 1,  max_2Dsize = max(max_2Dsize, radii * inv_max_size),  inv_max_size = 1 / max(W, H).
+ * xy_grads rows are grad_stride floats apart (2 for a [N,2] tensor, 16 to read the |v_xy| columns of the gradient
+ * records in place: pass v_splats + 14). */
+int dnsplat_densify_stats(int32_t N, const int32_t *radii, const float *xy_grads, int32_t grad_stride, float inv_max_size,
+                          float *xys_grad_norm, float *vis_counts, float *max_2Dsize, dnsplat_stream_t stream);
+
 /* ------------------------------------------------------------------ stage 5
  * Fused per-Gaussian back end: gradient record -> parameter gradients.
  * Replaces gsplat fully_fused_projection_bwd (A10), spherical_harmonics bwd (A5),

@@ -72,6 +72,18 @@ def _worker(rank, world, port, ret):
     assert all(torch.allclose(fake[k].grad, torch.full_like(fake[k], (1 + world) / 2)) for k in KEYS)
     assert dp.max_over_ranks(float(rank), dev) == world - 1
     assert dp.sum_over_ranks([1.0, float(rank)], dev) == [float(world), float(sum(range(world)))]
+    # densification statistics: sums over the step's increments, max over ranks (densify.py)
+    from dn_splatter_amd.densify import DensifyStats
+    prev = DensifyStats(8, "cpu")
+    prev.xys_grad_norm += 5.0           # common history
+    cur = prev.clone()
+    cur.xys_grad_norm[rank] += 1.0 + rank
+    cur.vis_counts[rank] += 1
+    cur.max_2Dsize[rank] = 0.1 * (rank + 1)
+    cur.allreduce(prev)
+    assert cur.xys_grad_norm.tolist()[:2] == [6.0, 7.0] and cur.xys_grad_norm[2] == 5.0
+    assert cur.vis_counts.tolist()[:3] == [2.0, 2.0, 1.0]
+    assert abs(float(cur.max_2Dsize[1]) - 0.2) < 1e-7 and abs(float(cur.max_2Dsize[0]) - 0.1) < 1e-7
     dp.barrier()
     if rank == 0:
         ret.update({k: params[k].grad.clone() for k in KEYS})

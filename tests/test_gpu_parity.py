@@ -285,6 +285,32 @@ def test_get_outputs_mirror_matches_reference_sequence(dns, orc, mode):
     assert_close(m_g.xys.absgrad, m_o.xys.absgrad, "xys.absgrad", flips=FLIP_FRACTION)
 
 
+def test_densify_stats_match_nerfstudio_after_train(dns):
+    """N3: one kernel == the boolean-mask torch sequence of SplatfactoModel.after_train (see densify.py)."""
+    from dn_splatter_amd import synthetic
+
+    N, W, H = 20_000, 320, 240
+    gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=3, device=DEV)
+    m = dns.DNSplatterRenderer(gp, fused=True)
+    stats = dns.DensifyStats(N, DEV)
+    ref = dict(g=torch.zeros(N, device=DEV), v=torch.ones(N, device=DEV), m=torch.zeros(N, device=DEV))
+    for view in (0, 3):
+        cam = synthetic.orbit_camera(view, width=W, height=H, focal=200.0).to(DEV)
+        out = m.get_outputs(cam)
+        for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities"):
+            gp[k].grad = None
+        (out["rgb"].sum() + out["depth"].sum()).backward()
+        stats.after_train(m, W, H)
+        visible = m.radii > 0
+        ref["g"][visible] += m.xys.absgrad[0][visible].norm(dim=-1)
+        ref["v"][visible] += 1
+        ref["m"][visible] = torch.maximum(ref["m"][visible], m.radii[visible] / float(max(W, H)))
+    assert_close(stats.xys_grad_norm, ref["g"], "xys_grad_norm", 1e-6)
+    assert torch.equal(stats.vis_counts, ref["v"])
+    assert torch.equal(stats.max_2Dsize, ref["m"])
+    assert float(stats.vis_counts.max()) == 3.0 and float(stats.max_2Dsize.max()) > 0
+
+
 def test_bin_policy_capacity_equals_sync(dns):
     inp, viewmat, K, _ = gsplat_inputs(20_000, 320, 240, focal=200.0, seed=14)
     gi = {k: v.to(DEV) for k, v in inp.items()}

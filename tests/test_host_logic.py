@@ -74,7 +74,7 @@ def test_bench_stage_bytes_sum_to_the_survey_formula():
     N, Nv, I, P, T = 1_000_000, 716_866, 21_243_626, 1920 * 1080, 8160
     sb = bench.stage_bytes(N, Nv, I, P, T)
     assert sum(sb.values()) == 84 * N + 796 * Nv + 216 * I + 76 * P + 12 * T
-    assert set(bench.WORKLOADS) == {"c1", "c2", "c3"} and bench.WORKLOADS["c2"][:3] == (1_000_000, 1920, 1080)
+    assert set(bench.WORKLOADS) == {"c1", "c2", "c3", "c5"} and bench.WORKLOADS["c2"][:3] == (1_000_000, 1920, 1080)
 
 
 def test_mirror_output_contract_and_sh_schedule(dns, orc):
@@ -120,3 +120,28 @@ def test_torch_postops_equal_their_closed_forms(dns, orc):
     if bool(empty.any()):
         assert torch.allclose(out["rgb"][empty], out["background"].expand(int(empty.sum()), 3), atol=1e-6)
         assert torch.allclose(out["depth"][empty], out["depth"].max().expand(int(empty.sum()), 1))
+
+
+def test_torch_loss_stack_restatement():
+    """dn_splatter/losses.py + regularization_strategy.py:146-199 restated in torch (they stay in PyTorch)."""
+    sys.path.insert(0, ROOT)
+    from dn_splatter_amd import torch_losses as tl
+
+    H, W = 24, 32
+    batch = tl.synthetic_batch(W, H, "cpu", seed=1)
+    # identical images: SSIM == 1, L1 == 0
+    assert abs(float(tl.ssim(batch["image"], batch["image"])) - 1.0) < 1e-6
+    g = torch.Generator().manual_seed(2)
+    out = {"rgb": torch.rand(H, W, 3, generator=g, requires_grad=True),
+           "depth": (torch.rand(H, W, 1, generator=g) * 5 + 1).requires_grad_(True),
+           "normal": torch.rand(H, W, 3, generator=g, requires_grad=True)}
+    scales = torch.randn(50, 3, requires_grad=True)
+    loss = tl.dn_loss(out, batch, scales)
+    loss.backward()
+    assert torch.isfinite(loss) and all(torch.isfinite(v.grad).all() for v in out.values()) and torch.isfinite(scales.grad).all()
+    # TV of a constant image is 0; EdgeAwareLogL1 of a perfect depth is 0
+    assert float(tl.tv_loss(torch.ones(H, W, 3))) == 0.0
+    assert float(tl.edge_aware_log_l1(batch["mono_depth"], batch["mono_depth"], batch["image"], batch["mono_depth"] > 0.1)) == 0.0
+    # scale term: mean over Gaussians of the smallest exp(scale)  (regularization_strategy.py:195-199)
+    only_scale = tl.dn_loss({k: v.detach() for k, v in out.items()}, {"image": out["rgb"].detach()}, scales)
+    assert abs(float(only_scale) - float(torch.exp(scales).min(dim=1)[0].mean())) < 1e-6
