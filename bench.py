@@ -109,9 +109,9 @@ def main():
     ap.add_argument("--bin-policy", default="capacity", choices=["sync", "capacity"])
     ap.add_argument("--two-call", action="store_true", help="reference's two-pass sequence instead of the fused pass")
     ap.add_argument("--torch-postops", action="store_true", help="keep dn_model.py:526-603 in torch instead of the HIP epilogue")
-    ap.add_argument("--losses", action="store_true",
-                    help="time dn-splatter's PyTorch loss stack (L1+SSIM, EdgeAwareLogL1 depth, normal L1+TV, scale) instead of "
-                         "feeding random cotangents (BASELINE config C5)")
+    ap.add_argument("--losses", nargs="?", const="torch", default=None, choices=["torch", "fused"],
+                    help="time dn-splatter's loss stack (L1+SSIM, EdgeAwareLogL1 depth, normal L1+TV, scale) instead of feeding "
+                         "random cotangents (BASELINE config C5): 'torch' = as the reference does, 'fused' = dnsplat_dn_loss")
     args = ap.parse_args()
 
     import dn_splatter_amd as dns
@@ -140,12 +140,17 @@ def main():
     if args.losses:
         from dn_splatter_amd import torch_losses
         batch = torch_losses.synthetic_batch(W, H, dev, seed=rank)
+        if args.losses == "fused":
+            from dn_splatter_amd import fused_loss
+            loss_counts = fused_loss.depth_counts(batch["mono_depth"])
 
     def step():
         for k in dp.GRAD_KEYS:
             gp[k].grad = None
         out = renderer.get_outputs(cam)
-        if batch is not None:
+        if batch is not None and args.losses == "fused":
+            fused_loss.dn_loss_fused(out, batch, gp["scales"], counts=loss_counts).backward()
+        elif batch is not None:
             torch_losses.dn_loss(out, batch, gp["scales"]).backward()
         else:
             # the losses stay in PyTorch (north star); their result is a dense cotangent per output image
@@ -216,7 +221,7 @@ def main():
             "config": {"workload": f"{args.workload}: {N} random-init Gaussians, 1 camera/GPU {W}x{H}, SH degree 3 + "
                                    f"expected depth + per-Gaussian normals ({D_CH} channels, "
                                    f"{'two-call' if args.two_call else 'fused one-pass'}, post-ops in {'torch' if (args.torch_postops or args.two_call) else 'HIP'}), fx=fy={focal}, orbit r=8, "
-                                   f"closed-form 3-NN scale init, {'dn-splatter PyTorch loss stack' if args.losses else 'random dense cotangents'}",
+                                   f"closed-form 3-NN scale init, {('dn-splatter loss stack (' + args.losses + ')') if args.losses else 'random dense cotangents'}",
                        "N": N, "Nv": Nv, "n_isects": I, "mean_isects_per_rank": i_all / world,
                        "mean_tile_list_len": round(I / T, 1), "pixels": P, "bin_policy": args.bin_policy,
                        "allreduce_bytes_per_step": wire,

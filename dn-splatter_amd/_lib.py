@@ -73,6 +73,16 @@ class DnPost(ctypes.Structure):
     ]
 
 
+class DnLossArgs(ctypes.Structure):
+    _fields_ = [
+        ("width", c_int32), ("height", c_int32),
+        ("rgb", c_void_p), ("depth", c_void_p), ("normal", c_void_p),
+        ("gt_rgb", c_void_p), ("gt_depth", c_void_p), ("gt_normal", c_void_p), ("depth_counts", c_void_p),
+        ("ssim_lambda", c_float), ("depth_weight", c_float), ("depth_tolerance", c_float),
+        ("maps", c_void_p), ("v_rgb", c_void_p), ("v_depth", c_void_p), ("v_normal", c_void_p), ("sums", c_void_p),
+    ]
+
+
 class RasterArgs(ctypes.Structure):
     _fields_ = [
         ("width", c_int32), ("height", c_int32), ("tile_size", c_int32), ("D", c_int32),
@@ -103,7 +113,7 @@ EXPORTS = [
     "dnsplat_project_fwd", "dnsplat_pack_splats",
     "dnsplat_bin_workspace_bytes", "dnsplat_bin_prepare", "dnsplat_bin_emit_sort", "dnsplat_bin_isect_ids",
     "dnsplat_raster_fwd", "dnsplat_raster_bwd",
-    "dnsplat_dn_depth_normals", "dnsplat_camera_prepare", "dnsplat_densify_stats",
+    "dnsplat_dn_depth_normals", "dnsplat_camera_prepare", "dnsplat_densify_stats", "dnsplat_dn_loss",
     "dnsplat_project_bwd",
 ]
 
@@ -146,6 +156,7 @@ def lib() -> ctypes.CDLL:
         L.dnsplat_dn_depth_normals.argtypes = [c_int32, c_int32, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p]
         L.dnsplat_densify_stats.argtypes = [c_int32, c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.dnsplat_dn_loss.argtypes = [ctypes.POINTER(DnLossArgs), c_void_p]
         L.dnsplat_camera_prepare.argtypes = [c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                              c_void_p]
         if L.dnsplat_abi_version() != ABI_VERSION:

@@ -15,6 +15,7 @@ $HIPCC $COMMON                   -c raster_fwd.hip -o _obj/raster_fwd.o & pids+=
 $HIPCC $COMMON -fno-slp-vectorize -c raster_bwd.hip -o _obj/raster_bwd.o & pids+=($!)
 $HIPCC $COMMON                   -c c_api.hip      -o _obj/c_api.o & pids+=($!)
 $HIPCC $COMMON -ffp-contract=off -c postops.hip    -o _obj/postops.o & pids+=($!)
+$HIPCC $COMMON                   -c losses.hip     -o _obj/losses.o & pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC _obj/project.o _obj/binning.o _obj/raster_fwd.o _obj/raster_bwd.o _obj/c_api.o _obj/postops.o -o ../libdnsplat.so
+$HIPCC --offload-arch=gfx950 -shared -fPIC _obj/project.o _obj/binning.o _obj/raster_fwd.o _obj/raster_bwd.o _obj/c_api.o _obj/postops.o _obj/losses.o -o ../libdnsplat.so
 echo "built $(realpath ../libdnsplat.so)"

@@ -1,0 +1,77 @@
+"""dn-splatter's per-pixel training loss as two HIP launches.
+
+``dn_loss_fused`` computes what ``torch_losses.dn_loss`` (the PyTorch restatement of
+``DNSplatterModel.get_loss_dict``, dn_splatter/dn_model.py:614-729) computes — same value, same gradients w.r.t. the
+rendered rgb / depth / normal images — but with the cotangents produced directly by ``dnsplat_dn_loss`` instead of by
+autograd over ~120 torch kernels.  The per-Gaussian min-scale term stays a torch expression.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import DnLossArgs
+from ._ops import _f32c, _ptr, _stream
+
+
+def depth_counts(gt_depth: Tensor, depth_tolerance: float = 0.1) -> Tensor:
+    """Normalisers of the two EdgeAwareLogL1 means (losses.py:216-222): valid pixels in columns < W-1 and rows < H-1.
+    Depends on the batch only — compute once per image, no host sync."""
+    valid = gt_depth.reshape(gt_depth.shape[0], gt_depth.shape[1]) > depth_tolerance
+    return torch.stack([valid[:, :-1].sum(), valid[:-1, :].sum()]).to(torch.float32)
+
+
+class _DnLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb, depth, normal, image, gt_depth, gt_normal, counts, ssim_lambda, depth_lambda, depth_tolerance):
+        rgb = _f32c(rgb, "rgb"); depth = _f32c(depth, "depth"); normal = _f32c(normal, "normal")
+        image = _f32c(image, "image")
+        H, W = rgb.shape[0], rgb.shape[1]
+        dev = rgb.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        maps = torch.empty(9, H, W, **f32)
+        v_rgb = torch.empty(H, W, 3, **f32)
+        v_depth = torch.empty(depth.shape, **f32)
+        v_normal = torch.empty(H, W, 3, **f32)
+        sums = torch.empty(8, **f32)
+        a = DnLossArgs()
+        a.width, a.height = W, H
+        a.rgb, a.depth, a.normal, a.gt_rgb = _ptr(rgb), _ptr(depth), _ptr(normal), _ptr(image)
+        if gt_depth is not None:
+            gt_depth = _f32c(gt_depth, "mono_depth")
+            counts = _f32c(counts, "depth_counts")
+        if gt_normal is not None:
+            gt_normal = _f32c(gt_normal, "normal gt")
+        a.gt_depth, a.gt_normal, a.depth_counts = _ptr(gt_depth), _ptr(gt_normal), _ptr(counts)
+        a.ssim_lambda, a.depth_weight, a.depth_tolerance = ssim_lambda, 1.0 + depth_lambda, depth_tolerance
+        a.maps, a.v_rgb, a.v_depth, a.v_normal, a.sums = _ptr(maps), _ptr(v_rgb), _ptr(v_depth), _ptr(v_normal), _ptr(sums)
+        _lib.run("dnsplat_dn_loss", _lib.lib().dnsplat_dn_loss, ctypes.byref(a), _stream())
+        P = float(W * H)
+        M = 3.0 * (W - 10) * (H - 10)
+        loss = (1 - ssim_lambda) * sums[1] / (3 * P) + ssim_lambda * (1 - sums[0] / M)
+        if gt_depth is not None:
+            loss = loss + (1.0 + depth_lambda) * (sums[2] / counts[0] + sums[3] / counts[1])
+        if gt_normal is not None:
+            loss = loss + sums[4] / (3 * P) + sums[5] / (3.0 * H * (W - 1)) + sums[6] / (3.0 * (H - 1) * W)
+        ctx.save_for_backward(v_rgb, v_depth, v_normal)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        v_rgb, v_depth, v_normal = ctx.saved_tensors
+        return (v_rgb * g, v_depth * g, v_normal * g) + (None,) * 7
+
+
+def dn_loss_fused(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], scales: Tensor, ssim_lambda: float = 0.2,
+                  depth_lambda: float = 0.2, depth_tolerance: float = 0.1, counts: Optional[Tensor] = None) -> Tensor:
+    """Drop-in for ``torch_losses.dn_loss`` (mono depth + mono normal supervision)."""
+    gt_depth = batch.get("mono_depth")
+    if gt_depth is not None and counts is None:
+        counts = depth_counts(gt_depth, depth_tolerance)
+    per_pixel = _DnLossFn.apply(outputs["rgb"], outputs["depth"], outputs["normal"], batch["image"], gt_depth,
+                                batch.get("normal"), counts, ssim_lambda, depth_lambda, depth_tolerance)
+    return per_pixel + torch.min(torch.exp(scales), dim=1, keepdim=True)[0].mean()   # regularization_strategy.py:195-199

@@ -225,6 +225,31 @@ int dnsplat_camera_prepare(const float *c2w, float fx, float fy, float cx, float
 int dnsplat_densify_stats(int32_t N, const int32_t *radii, const float *xy_grads, int32_t grad_stride, float inv_max_size,
                           float *xys_grad_norm, float *vis_counts, float *max_2Dsize, dnsplat_stream_t stream);
 
+/* dn-splatter's per-pixel training loss and its gradient w.r.t. the rendered images in two launches:
+ *   loss = (1 - l) mean|rgb - gt| + l (1 - SSIM(rgb, gt))                       nerfstudio splatfacto RGB term, l = ssim_lambda
+ *        + depth_weight (EdgeAwareLogL1_x + EdgeAwareLogL1_y)(depth, gt_depth)  losses.py:187-224, mask gt_depth > tolerance,
+ *                                                                               depth_weight = 1 + depth_lambda (regularization_strategy.py:184)
+ *        + mean|normal - gt_normal| + TV(normal)                                regularization_strategy.py:188-193, losses.py:279-295
+ * (dn_model.py:614-729; the per-Gaussian min-scale term is added by the caller).  Outputs the cotangents v_rgb,
+ * v_depth, v_normal of a unit loss gradient and, in sums[8], the partial sums
+ *   {sum SSIM, sum|rgb-gt|, sum EA_x, sum EA_y, sum|n-gt_n|, sum TV_h, sum TV_w, 0} from which the loss value follows. */
+typedef struct dnsplat_dn_loss_args {
+    int32_t width, height;
+    const float *rgb;          /* [H,W,3] rendered */
+    const float *depth;        /* [H,W]   rendered (filled) depth */
+    const float *normal;       /* [H,W,3] rendered normal image in [0,1] */
+    const float *gt_rgb;       /* [H,W,3] */
+    const float *gt_depth;     /* [H,W] or NULL (no depth loss) */
+    const float *gt_normal;    /* [H,W,3] or NULL (no normal losses) */
+    const float *depth_counts; /* device [2]: number of pixels with gt_depth > tolerance in columns < W-1, in rows < H-1 */
+    float ssim_lambda, depth_weight, depth_tolerance;
+    float *maps;               /* scratch [9, H, W] floats */
+    float *v_rgb, *v_depth, *v_normal;   /* out, shapes of rgb / depth / normal */
+    float *sums;               /* out device [8] */
+} dnsplat_dn_loss_args;
+
+int dnsplat_dn_loss(const dnsplat_dn_loss_args *args, dnsplat_stream_t stream);
+
 /* ------------------------------------------------------------------ stage 5
  * Fused per-Gaussian back end: gradient record -> parameter gradients.
  * Replaces gsplat fully_fused_projection_bwd (A10), spherical_harmonics bwd (A5),

@@ -78,7 +78,7 @@ def test_struct_layouts_match_the_c_compiler(dns, tmp_path):
 
     structs = {"dnsplat_scene": _lib.Scene, "dnsplat_camera": _lib.Camera, "dnsplat_proj_out": _lib.ProjOut,
                "dnsplat_bin_args": _lib.BinArgs, "dnsplat_raster_args": _lib.RasterArgs,
-               "dnsplat_proj_grads": _lib.ProjGrads, "dnsplat_dn_post": _lib.DnPost}
+               "dnsplat_proj_grads": _lib.ProjGrads, "dnsplat_dn_post": _lib.DnPost, "dnsplat_dn_loss_args": _lib.DnLossArgs}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){']
     for cname, cls in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

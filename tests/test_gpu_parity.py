@@ -311,6 +311,42 @@ def test_densify_stats_match_nerfstudio_after_train(dns):
     assert float(stats.vis_counts.max()) == 3.0 and float(stats.max_2Dsize.max()) > 0
 
 
+@pytest.mark.parametrize("W,H", [(64, 48), (75, 53), (256, 200), (11, 11)])
+def test_fused_loss_matches_the_torch_loss_stack(dns, W, H):
+    """N2: dnsplat_dn_loss (value + cotangents) == autograd over the PyTorch restatement of get_loss_dict."""
+    from dn_splatter_amd import torch_losses as tl
+    from dn_splatter_amd.fused_loss import dn_loss_fused
+
+    batch = tl.synthetic_batch(W, H, DEV, seed=W)
+    batch["mono_depth"][: H // 3, : W // 4] = 0.0          # part of the depth map invalid (<= depth_tolerance)
+    g = torch.Generator().manual_seed(1000 + H)
+    base = {"rgb": torch.rand(H, W, 3, generator=g), "depth": torch.rand(H, W, 1, generator=g) * 9 + 0.2,
+            "normal": torch.rand(H, W, 3, generator=g)}
+    base["rgb"][0, 0] = batch["image"][0, 0].cpu()          # exact ties: sign(0) must be 0 on both sides
+    scales = torch.randn(500, 3, generator=g)
+
+    def run(fn):
+        out = {k: v.clone().to(DEV).requires_grad_(True) for k, v in base.items()}
+        sc = scales.clone().to(DEV).requires_grad_(True)
+        loss = fn(out, batch, sc)
+        loss.backward()
+        return loss.detach(), {k: v.grad for k, v in out.items()}, sc.grad
+
+    l_t, g_t, s_t = run(tl.dn_loss)
+    l_f, g_f, s_f = run(dn_loss_fused)
+    assert abs(float(l_f) - float(l_t)) <= 2e-5 * abs(float(l_t)), (float(l_f), float(l_t))
+    for k in g_t:
+        assert_close(g_f[k], g_t[k], "d loss / d " + k, 2e-4)     # SSIM sensitivities divide by ~1e-4-sized variances
+    assert_close(s_f, s_t, "d loss / d scales", 1e-6)
+    # without depth / normal supervision
+    nb = {"image": batch["image"]}
+    l_t, g_t, _ = run(lambda o, b, s: tl.dn_loss(o, nb, s))
+    l_f, g_f, _ = run(lambda o, b, s: dn_loss_fused(o, nb, s))
+    assert abs(float(l_f) - float(l_t)) <= 2e-5 * abs(float(l_t))
+    assert_close(g_f["rgb"], g_t["rgb"], "rgb-only loss gradient", 2e-4)
+    assert float(g_f["depth"].abs().max()) == 0.0 and float(g_f["normal"].abs().max()) == 0.0
+
+
 def test_bin_policy_capacity_equals_sync(dns):
     inp, viewmat, K, _ = gsplat_inputs(20_000, 320, 240, focal=200.0, seed=14)
     gi = {k: v.to(DEV) for k, v in inp.items()}
