@@ -67,17 +67,14 @@ def get_viewmat(optimized_camera_to_world: Tensor) -> Tensor:
 
 
 def pcd_to_normal(xyz: Tensor) -> Tensor:
-    hd, wd, _ = xyz.shape
-    bottom_point = xyz[2:hd, 1:wd - 1, :]
-    top_point = xyz[0:hd - 2, 1:wd - 1, :]
-    right_point = xyz[1:hd - 1, 2:wd, :]
-    left_point = xyz[1:hd - 1, 0:wd - 2, :]
-    left_to_right = right_point - left_point
-    bottom_to_top = top_point - bottom_point
-    xyz_normal = torch.cross(left_to_right, bottom_to_top, dim=-1)
-    xyz_normal = F.normalize(xyz_normal, p=2, dim=-1)
-    xyz_normal = F.pad(xyz_normal.permute(2, 0, 1), (1, 1, 1, 1), mode="constant").permute(1, 2, 0)
-    return xyz_normal
+    """Normals of an organised point cloud [H,W,3] from its 4-neighbourhood (utils/normal_utils.py:9-22):
+    normalize(cross(right - left, top - bottom)) on the interior, zeros on the one-pixel border."""
+    horizontal = xyz[1:-1, 2:] - xyz[1:-1, :-2]      # right minus left neighbour
+    vertical = xyz[:-2, 1:-1] - xyz[2:, 1:-1]        # upper minus lower neighbour
+    inner = F.normalize(torch.cross(horizontal, vertical, dim=-1), p=2, dim=-1)
+    out = torch.zeros_like(xyz)
+    out[1:-1, 1:-1] = inner
+    return out
 
 
 def normal_from_depth_image(depths: Tensor, fx: float, fy: float, cx: float, cy: float, img_size: tuple,

@@ -49,24 +49,34 @@ def ssim(pred: Tensor, gt: Tensor, data_range: float = 1.0) -> Tensor:
     return s.mean()
 
 
+def _dcol(t: Tensor) -> Tensor:
+    """t[i, j] - t[i, j+1] for an [H,W,C] image."""
+    return t[:, :-1] - t[:, 1:]
+
+
+def _drow(t: Tensor) -> Tensor:
+    """t[i, j] - t[i+1, j]."""
+    return t[:-1] - t[1:]
+
+
 def edge_aware_log_l1(pred: Tensor, gt: Tensor, rgb: Tensor, mask: Optional[Tensor]) -> Tensor:
-    """losses.py:187-224, implementation="scalar"."""
-    logl1 = torch.log(1 + torch.abs(pred - gt))
-    grad_img_x = torch.mean(torch.abs(rgb[..., :, :-1, :] - rgb[..., :, 1:, :]), -1, keepdim=True)
-    grad_img_y = torch.mean(torch.abs(rgb[..., :-1, :, :] - rgb[..., 1:, :, :]), -1, keepdim=True)
-    loss_x = torch.exp(-grad_img_x) * logl1[..., :, :-1, :]
-    loss_y = torch.exp(-grad_img_y) * logl1[..., :-1, :, :]
+    """Scalar EdgeAwareLogL1 (losses.py:187-224): log(1 + |pred - gt|), down-weighted across image edges by
+    exp(-mean_c |colour difference to the right / lower neighbour|), averaged over the masked pixels separately for the
+    horizontal and the vertical term."""
+    err = torch.log(1 + (pred - gt).abs())
+    edge_x = torch.exp(-_dcol(rgb).abs().mean(dim=-1, keepdim=True))
+    edge_y = torch.exp(-_drow(rgb).abs().mean(dim=-1, keepdim=True))
+    term_x = edge_x * err[:, :-1]
+    term_y = edge_y * err[:-1]
     if mask is not None:
-        loss_x = loss_x[mask[..., :, :-1, :]]
-        loss_y = loss_y[mask[..., :-1, :, :]]
-    return loss_x.mean() + loss_y.mean()
+        term_x = term_x[mask[:, :-1]]
+        term_y = term_y[mask[:-1]]
+    return term_x.mean() + term_y.mean()
 
 
 def tv_loss(pred: Tensor) -> Tensor:
-    """losses.py:279-295."""
-    h_diff = pred[..., :, :-1, :] - pred[..., :, 1:, :]
-    w_diff = pred[..., :-1, :, :] - pred[..., 1:, :, :]
-    return torch.mean(torch.abs(h_diff)) + torch.mean(torch.abs(w_diff))
+    """TVLoss (losses.py:279-295): mean absolute difference to the right neighbour plus to the lower neighbour."""
+    return _dcol(pred).abs().mean() + _drow(pred).abs().mean()
 
 
 def dn_loss(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], scales: Tensor, ssim_lambda: float = 0.2,
