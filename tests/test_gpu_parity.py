@@ -131,6 +131,59 @@ def test_antialiased_mode(dns, orc):
     _check_backward(o, g, flips=FLIP_FRACTION)
 
 
+@pytest.mark.parametrize("near,far,radius_clip,eps2d", [(0.01, 1e10, 0.0, 0.3), (5.0, 9.0, 0.0, 0.3), (0.01, 1e10, 6.0, 0.3),
+                                                        (0.5, 50.0, 2.0, 0.1)])
+def test_culling_planes_and_extreme_geometry(dns, orc, near, far, radius_clip, eps2d):
+    """Near/far planes, radius_clip, eps2d, and a scene built to hit the awkward branches: Gaussians close to the
+    camera, far off-axis (the 1.3 tan(fov/2) clamp of the perspective Jacobian), huge and tiny ones."""
+    N, W, H = 4000, 160, 128
+    inp, viewmat, K, _ = gsplat_inputs(N, W, H, focal=110.0, seed=31, anisotropic=True)
+    g_ = torch.Generator().manual_seed(32)
+    cam_pos = torch.inverse(viewmat[0])[:3, 3]
+    fwd = -cam_pos / cam_pos.norm()
+    inp["means"][:300] = cam_pos + fwd * (0.05 + 2.0 * torch.rand(300, 1, generator=g_)) + 0.3 * torch.randn(300, 3, generator=g_)
+    inp["scales"][300:500] *= 8.0                     # splats covering a large part of the image
+    inp["scales"][500:700] *= 0.05                    # sub-pixel splats (the 0.3 blur dominates)
+    side = torch.linalg.cross(fwd, torch.tensor([0.0, 1.0, 0.0]))
+    inp["means"][700:900] = cam_pos + fwd * 4.0 + side * (4.0 + 2.0 * torch.rand(200, 1, generator=g_))   # beyond the fov clamp
+    inp["scales"][700:900] *= 6.0
+    kw = dict(sh_degree=3, render_mode="RGB+ED", absgrad=True, near_plane=near, far_plane=far, radius_clip=radius_clip,
+              eps2d=eps2d)
+    o, g = _call_both(dns, orc, inp, viewmat, K, W, H, **kw)
+    assert int((o[2]["radii"] > 0).sum()) > 100
+    _check_forward(o, g, flips=FLIP_FRACTION)
+    _check_backward(o, g, flips=FLIP_FRACTION)
+
+
+def test_legacy_rasterize_gaussians_options(dns, orc):
+    """return_alpha, explicit background, uint8 colours (legacy gsplat behaviour) of the second-pass drop-in."""
+    inp, viewmat, K, _ = gsplat_inputs(3000, 96, 64, focal=60.0, seed=41, anisotropic=True)
+    with torch.no_grad():
+        _, _, info = orc.rasterization(**inp, viewmats=viewmat, Ks=K, width=96, height=64, packed=False, sh_degree=3)
+    cols = torch.rand(3000, 5, generator=torch.Generator().manual_seed(1))
+    bg = torch.tensor([0.1, 0.2, 0.3, 0.4, 0.5])
+    common = (info["depths"][0], info["radii"][0], info["conics"][0], info["tiles_per_gauss"][0])
+    out_o, al_o = orc.rasterize_gaussians(info["means2d"][0], *common, cols, inp["opacities"][:, None], 64, 96, 16,
+                                          background=bg, return_alpha=True)
+    dev = lambda t: t.to(DEV)   # noqa: E731
+    out_g, al_g = dns.rasterize_gaussians(dev(info["means2d"][0]), *[dev(t) for t in common], dev(cols),
+                                          dev(inp["opacities"][:, None]), 64, 96, 16, background=dev(bg), return_alpha=True)
+    assert_close(out_g, out_o, "legacy render with background", flips=FLIP_FRACTION)
+    assert_close(al_g, al_o, "legacy alpha", flips=FLIP_FRACTION)
+    u8 = (cols[:, :3] * 255).to(torch.uint8)
+    out_u8 = dns.rasterize_gaussians(dev(info["means2d"][0]), *[dev(t) for t in common], dev(u8), dev(inp["opacities"][:, None]),
+                                     64, 96, 16)
+    out_f = dns.rasterize_gaussians(dev(info["means2d"][0]), *[dev(t) for t in common], dev(u8).float() / 255,
+                                    dev(inp["opacities"][:, None]), 64, 96, 16)
+    assert torch.equal(out_u8, out_f)
+    with pytest.raises(AssertionError):
+        dns.rasterize_gaussians(dev(info["means2d"][0]), *[dev(t) for t in common], dev(cols), dev(inp["opacities"][:, None]),
+                                64, 96, 16, background=dev(bg[:3]))
+    with pytest.raises(NotImplementedError):
+        dns.rasterize_gaussians(dev(info["means2d"][0]), *[dev(t) for t in common], dev(cols), dev(inp["opacities"][:, None]),
+                                64, 96, 8)
+
+
 def test_edge_empty_and_culled(dns, orc):
     """Every Gaussian behind the camera (nothing visible), and N == 0."""
     inp, viewmat, K, _ = gsplat_inputs(500, 64, 48, focal=40.0, seed=2)
