@@ -45,7 +45,7 @@ namespace {
 constexpr int TILE = 16;
 constexpr int NPIX = TILE * TILE;
 constexpr int BUCKET = 2 * DNS_WAVE;   // splats per systolic pass: two per lane, processed as packed fp32 pairs
-constexpr int QCAP = 4 * DNS_WAVE;
+
 
 struct BwdArgs {
     int width, height, tw, n_tiles;
@@ -109,9 +109,12 @@ template <int D, int SPLIT, bool DN>
 __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
 {
     __shared__ float4 pix[NPIX][3];            // [p][0..1] = v_k, [p][2] = (T, S_a, S_b, bin_final)
-    __shared__ float4 flush[16][4];            // 16 gradient rows at a time staged for the transposed flush (1 KiB:
-                                               // LDS per wave decides how many tiles a CU works on at once)
-    __shared__ int32_t queue[QCAP];            // compacted list indices waiting for a bucket
+    // compacted list indices waiting for a bucket (never more than 127 + 64) + the 1 KiB staging area of the transposed flush, which
+    // ALIASES queue entries >= 64: while a pass is flushed only the < 64 left-over entries at the front of the queue are
+    // live.  13.5 KiB per wave = 12 tiles in flight per CU (3 waves per SIMD, the VGPR limit) instead of 11.
+    __shared__ __attribute__((aligned(16))) int32_t qf[64 + 256];
+    int32_t *queue = qf;
+    float4(*flush)[4] = reinterpret_cast<float4(*)[4]>(qf + 64);
 
     const int tile = dns_xcd_remap(blockIdx.x, a.n_tiles);
     const int lane = threadIdx.x;
