@@ -79,18 +79,26 @@ class _Buffers:
         self.pinned: Dict[torch.device, Tensor] = {}
         self.capacity_hint: Dict[tuple, int] = {}
 
+    @staticmethod
+    def _key(device):
+        # one set of scratch per (device, stream): frames rendered concurrently on different HIP streams
+        # (model.get_outputs_batch) must not share the binning workspace or the pinned counter
+        return (device, torch.cuda.current_stream(device).cuda_stream)
+
     def workspace(self, device, nbytes: int) -> Tensor:
-        cur = self.ws.get(device)
+        key = self._key(device)
+        cur = self.ws.get(key)
         if cur is None or cur.numel() < nbytes:
             cur = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
-            self.ws[device] = cur
+            self.ws[key] = cur
         return cur
 
     def pinned_i64(self, device) -> Tensor:
-        cur = self.pinned.get(device)
+        key = self._key(device)
+        cur = self.pinned.get(key)
         if cur is None:
             cur = torch.zeros(1, dtype=torch.int64).pin_memory()
-            self.pinned[device] = cur
+            self.pinned[key] = cur
         return cur
 
 

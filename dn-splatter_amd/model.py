@@ -121,6 +121,36 @@ class DNSplatterRenderer:
         self.xys = self.radii = self.depths = self.conics = self.num_tiles_hit = None
         self.last_info: Dict = {}
 
+    @torch.no_grad()
+    def get_outputs_batch(self, cameras, n_streams: int = 2):
+        """Forward-only rendering of several cameras (the render loops of the offline consumers —
+        export_mesh.py:965-1017, dn_pipeline.py:194-214, scripts/render_model.py:47-69 — call get_outputs once per
+        camera, one after the other).  The frames are independent, so they are issued round-robin on ``n_streams`` HIP
+        streams: the tail of one frame's compositing kernel (its last, partly empty round of waves) and its
+        bandwidth-bound binning overlap with the next frame's VALU-bound kernels.  The C ABI is re-entrant across
+        streams (no global state); the Python scratch buffers are kept per stream.  Returns one output dict per camera,
+        identical to what get_outputs returns for it."""
+        dev = cameras[0].camera_to_worlds.device
+        cur = torch.cuda.current_stream(dev)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, min(n_streams, len(cameras))))]
+        for s in streams:
+            s.wait_stream(cur)
+        outs = []
+        was_training = self.training
+        self.training = False
+        try:
+            for i, cam in enumerate(cameras):
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    out = self.get_outputs(cam)
+                    for v in out.values():
+                        v.record_stream(cur)        # handed over to the caller's stream below
+                    outs.append(out)
+        finally:
+            self.training = was_training
+        for s in streams:
+            cur.wait_stream(s)
+        return outs
+
     def _sh_degree_to_use(self):
         c = self.config
         return min(self.step // c.sh_degree_interval, c.sh_degree)
