@@ -424,6 +424,30 @@ def test_batched_multi_stream_rendering_equals_sequential(dns):
             dns.set_bin_policy("sync")
 
 
+def test_capacity_policy_recovers_from_an_overflowing_guess(dns):
+    """'capacity' mode sizes the intersection buffers from earlier frames and enqueues everything without a host
+    round-trip; when the guess is too small the emit + composite must be redone with the exact size."""
+    from dn_splatter_amd import _ops
+
+    inp, viewmat, K, _ = gsplat_inputs(20_000, 320, 240, focal=200.0, seed=15)
+    gi = {k: v.to(DEV) for k, v in inp.items()}
+    kw = dict(viewmats=viewmat.to(DEV), Ks=K.to(DEV), width=320, height=240, packed=False, sh_degree=3, render_mode="RGB+ED")
+    try:
+        dns.set_bin_policy("sync")
+        r0, a0, i0 = dns.rasterization(**gi, **kw)
+        dns.set_bin_policy("capacity")
+        key = (torch.device(DEV), 20_000, 320, 240)
+        assert key in _ops.BUFFERS.capacity_hint
+        _ops.BUFFERS.capacity_hint[key] = 1000            # far below the real n_isects
+        r1, a1, i1 = dns.rasterization(**gi, **kw)
+        assert i1["n_isects"] == i0["n_isects"] > 1000
+        assert torch.equal(r0, r1) and torch.equal(a0, a1)
+        assert_equal_int(i1["flatten_ids"], i0["flatten_ids"], "flatten_ids after overflow")
+        assert _ops.BUFFERS.capacity_hint[key] >= i0["n_isects"]
+    finally:
+        dns.set_bin_policy("sync")
+
+
 def test_bin_policy_capacity_equals_sync(dns):
     inp, viewmat, K, _ = gsplat_inputs(20_000, 320, 240, focal=200.0, seed=14)
     gi = {k: v.to(DEV) for k, v in inp.items()}
