@@ -8,6 +8,8 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
+
+import torch
 from ctypes import c_float, c_int32, c_int64, c_size_t, c_void_p
 from pathlib import Path
 
@@ -198,8 +200,6 @@ def run(name: str, fn, *args) -> None:
     if t is None:
         check(fn(*args), name)
         return
-    import torch
-
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -114,6 +114,7 @@ class DNSplatterRenderer:
         self.fused = fused
         self.fused_postops = fused_postops   # also run dn_model.py:526-537,577-603 inside the HIP kernels
         self._bg_cache: Dict = {}
+        self._stream_pool: Dict = {}
         self.step = 10 ** 9  # all SH bands active unless the trainer says otherwise (dn_model.py:488-490)
         self._rasterization = rasterization_fn or rasterization
         self._rasterize_gaussians = rasterize_gaussians_fn or rasterize_gaussians
@@ -132,7 +133,11 @@ class DNSplatterRenderer:
         identical to what get_outputs returns for it."""
         dev = cameras[0].camera_to_worlds.device
         cur = torch.cuda.current_stream(dev)
-        streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, min(n_streams, len(cameras))))]
+        want = max(1, min(n_streams, len(cameras)))
+        pool = self._stream_pool.setdefault(dev, [])       # reuse the same streams: scratch buffers are kept per stream
+        while len(pool) < want:
+            pool.append(torch.cuda.Stream(device=dev))
+        streams = pool[:want]
         for s in streams:
             s.wait_stream(cur)
         outs = []
