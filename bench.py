@@ -166,8 +166,11 @@ def main():
     _lib.TIMER = timer
     t0 = time.perf_counter()
     wire = 0
-    for _ in range(args.steps):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks[0].record()
+    for i in range(args.steps):
         wire = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
@@ -175,6 +178,8 @@ def main():
     _lib.TIMER = None
     elapsed = dp.max_over_ranks(elapsed, dev)
 
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    q = lambda f: round(per_step[min(len(per_step) - 1, int(f * len(per_step)))], 4)   # noqa: E731
     info = renderer.last_info
     I = int(info["n_isects"])
     Nv = int((renderer.radii > 0).sum())
@@ -216,7 +221,8 @@ def main():
         res = {
             "metric": "fwd+bwd frames/sec @1M Gaussians 1080p; HBM GB/s vs roofline",
             "value": round(fps_total, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "gpu_ms_per_step_p10_p50_p90": [q(0.1), q(0.5), q(0.9)], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {N} random-init Gaussians, 1 camera/GPU {W}x{H}, SH degree 3 + "
                                    f"expected depth + per-Gaussian normals ({D_CH} channels, "
