@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bin-policy", default="capacity", choices=["sync", "capacity"])
+    ap.add_argument("--dense-allreduce", action="store_true",
+                    help="all-reduce the full 236 B/Gaussian bucket instead of exchanging the SH gradients as factors")
     ap.add_argument("--two-call", action="store_true", help="reference's two-pass sequence instead of the fused pass")
     ap.add_argument("--torch-postops", action="store_true", help="keep dn_model.py:526-603 in torch instead of the HIP epilogue")
     ap.add_argument("--losses", nargs="?", const="torch", default=None, choices=["torch", "fused"],
@@ -132,6 +134,10 @@ def main():
     dns.set_bin_policy(args.bin_policy)
     arena = dp.GradArena(gp)
     dns.set_grad_arena(arena)
+    exchange = None
+    if (world > 1 or os.environ.get("DNSPLAT_FORCE_DIST", "0") == "1") and not args.dense_allreduce and not args.two_call:
+        exchange = dp.ShFactorExchange()
+        dns.set_sh_exchange(exchange)
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
     shapes = {"rgb": (H, W, 3), "depth": (H, W, 1), "normal": (H, W, 3), "accumulation": (H, W, 1)}
     cot = {k: torch.rand(shapes[k], device=dev, generator=gen) * 2 - 1 for k in OUT_KEYS}
@@ -155,7 +161,7 @@ def main():
         else:
             # the losses stay in PyTorch (north star); their result is a dense cotangent per output image
             torch.autograd.backward([out[k] for k in OUT_KEYS], [cot[k] for k in OUT_KEYS])
-        return dp.allreduce_gradients(gp, arena)
+        return dp.allreduce_gradients(gp, arena, exchange=exchange)
 
     for _ in range(args.warmup):
         step()
@@ -232,7 +238,9 @@ def main():
                        "mean_tile_list_len": round(I / T, 1), "pixels": P, "bin_policy": args.bin_policy,
                        "allreduce_bytes_per_step": wire,
                        "grads_in_flat_bucket": bool(all(arena.holds(gp[k].grad) for k in dp.GRAD_KEYS)),
-                       "parallelism": f"dp{world} (camera per GPU, RCCL all-reduce of {wire} B/step)" if world > 1 else "single GPU"},
+                       "parallelism": (f"dp{world} (camera per GPU; per step {wire} B exchanged per GPU over RCCL: "
+                                       + ("geometry grads all-reduced, SH grads all-gathered as factors)" if exchange is not None
+                                          else "one all-reduce of the flat gradient bucket)")) if world > 1 else "single GPU"},
             "roofline": roofline,
             "frame_roofline": frame_roofline,
             "stages": stages,
@@ -240,6 +248,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             dns.set_grad_arena(None)
+            dns.set_sh_exchange(None)
             try:
                 res["cpu_baseline"] = cpu_baseline(args.workload)
             except Exception as e:  # the baseline is reported, never required for the GPU number

@@ -17,7 +17,7 @@ _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "libdnsplat.so"
 CSRC_DIR = _PKG_DIR / "csrc"
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 RECORD_FLOATS = 16
 MAX_CHANNELS = 8
 
@@ -106,6 +106,7 @@ class ProjGrads(ctypes.Structure):
         ("v_sh0", c_void_p), ("v_sh0_stride", c_int32),
         ("v_shN", c_void_p), ("v_shN_stride", c_int32),
         ("v_colors", c_void_p),
+        ("sh_factors", c_void_p),
     ]
 
 
@@ -115,7 +116,7 @@ EXPORTS = [
     "dnsplat_project_fwd", "dnsplat_pack_splats",
     "dnsplat_bin_workspace_bytes", "dnsplat_bin_prepare", "dnsplat_bin_emit_sort", "dnsplat_bin_isect_ids",
     "dnsplat_raster_fwd", "dnsplat_raster_bwd",
-    "dnsplat_dn_depth_normals", "dnsplat_camera_prepare", "dnsplat_densify_stats", "dnsplat_dn_loss",
+    "dnsplat_dn_depth_normals", "dnsplat_camera_prepare", "dnsplat_densify_stats", "dnsplat_dn_loss", "dnsplat_sh_grads_from_factors",
     "dnsplat_project_bwd",
 ]
 
@@ -158,6 +159,8 @@ def lib() -> ctypes.CDLL:
         L.dnsplat_dn_depth_normals.argtypes = [c_int32, c_int32, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p]
         L.dnsplat_densify_stats.argtypes = [c_int32, c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.dnsplat_sh_grads_from_factors.argtypes = [c_int32, c_int32, c_void_p, c_int32, c_int32, c_float, c_void_p, c_int32,
+                                                    c_void_p, c_int32, c_void_p]
         L.dnsplat_dn_loss.argtypes = [ctypes.POINTER(DnLossArgs), c_void_p]
         L.dnsplat_camera_prepare.argtypes = [c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                              c_void_p]

@@ -114,6 +114,16 @@ def set_grad_arena(arena) -> None:
     GRAD_ARENA = arena
 
 
+# Optional compact SH-gradient exchange (dp.ShFactorExchange): when set, stage 5 hands out the 6 factors per
+# Gaussian instead of the 48 coefficient gradients; dp.allreduce_gradients all-gathers them and rebuilds the sum.
+SH_EXCHANGE = None
+
+
+def set_sh_exchange(exchange) -> None:
+    global SH_EXCHANGE
+    SH_EXCHANGE = exchange
+
+
 def _grad_like(param: Tensor) -> Tensor:
     a = GRAD_ARENA
     if a is not None:
@@ -285,6 +295,10 @@ class _ProjectFn(torch.autograd.Function):
         g.radii, g.v_splats = _ptr(radii), _ptr(v_splats)
         g.v_means2d, g.v_depths, g.v_conics, g.v_compensations = _ptr(v_m2d), _ptr(v_dep), _ptr(v_con), _ptr(v_cmp)
         g.v_means, g.v_quats, g.v_scales, g.v_opacities = _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac)
+        ex = SH_EXCHANGE
+        if ex is not None and ctx.layout in ("cat", "split") and sh_K == 16:
+            # the coefficient-gradient tensors are handed to autograd unwritten; dp.allreduce_gradients fills them
+            g.sh_factors = _ptr(ex.begin(N, dev, cfg.sh_degree, sh_K, v_coeffs, v_sh0, v_shN))
         _lib.run("dnsplat_project_bwd", _lib.lib().dnsplat_project_bwd, ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(fwd),
                                                   ctypes.byref(g), _stream())
         need = ctx.needs_input_grad

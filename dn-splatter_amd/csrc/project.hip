@@ -468,6 +468,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(BwdParams p)
     // place; the block then stores the whole span with coalesced 16-byte writes
     float *lrow = sh_lds + (L == SH_DIRECT ? 0 : threadIdx.x * ShRowTraits<L>::LDS_ROW);
     float *lN = L == SH_CAT ? lrow + 3 : lrow;
+    // factor mode (multi-view data parallelism): hand out (view direction, colour gradient) instead of their outer product
+    float *fact = p.g.sh_factors ? p.g.sh_factors + (size_t)g * 6 : nullptr;
     if (g < p.s.N) {
     const int nbK = (p.s.sh_degree >= 0) ? (p.s.sh_degree + 1) * (p.s.sh_degree + 1) : 0;
 
@@ -498,6 +500,10 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(BwdParams p)
                          p.c.radius_clip, st);
     }
 
+    if (!ok && fact) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) fact[k] = 0.f;
+    }
     if (!ok) {
         if (L == SH_CAT) { lrow[0] = 0.f; lrow[1] = 0.f; lrow[2] = 0.f; }
         else if (vsh0) { vsh0[0] = 0.f; vsh0[1] = 0.f; vsh0[2] = 0.f; }
@@ -540,6 +546,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(BwdParams p)
             float bas[16];
             sh_basis(p.s.sh_degree, dx, dy, dz, bas);
             float vdn[3] = {0.f, 0.f, 0.f};
+            float fcol[3] = {0.f, 0.f, 0.f};
             float bx[16], by[16], bz[16];
             if (p.s.sh_degree >= 1) sh_basis_grad(p.s.sh_degree, dx, dy, dz, bx, by, bz);
             if (L == SH_DIRECT) {
@@ -555,8 +562,9 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(BwdParams p)
                 float vcol[3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) vcol[i] = (col[i] + 0.5f >= 0.f) ? vr[REC_CH0 + i] : 0.f;
-                if (vsh0) { vsh0[0] = bas[0] * vcol[0]; vsh0[1] = bas[0] * vcol[1]; vsh0[2] = bas[0] * vcol[2]; }
-                if (vshN) {
+                fcol[0] = vcol[0]; fcol[1] = vcol[1]; fcol[2] = vcol[2];
+                if (vsh0 && !fact) { vsh0[0] = bas[0] * vcol[0]; vsh0[1] = bas[0] * vcol[1]; vsh0[2] = bas[0] * vcol[2]; }
+                if (vshN && !fact) {
                     for (int k = 1; k < nbK; ++k) {
                         vshN[3 * (k - 1) + 0] = bas[k] * vcol[0];
                         vshN[3 * (k - 1) + 1] = bas[k] * vcol[1];
@@ -581,8 +589,9 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(BwdParams p)
                 float vcol[3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) vcol[i] = (col[i] + 0.5f >= 0.f) ? vr[REC_CH0 + i] : 0.f;
+                fcol[0] = vcol[0]; fcol[1] = vcol[1]; fcol[2] = vcol[2];
                 if (L == SH_CAT) { lrow[0] = bas[0] * vcol[0]; lrow[1] = bas[0] * vcol[1]; lrow[2] = bas[0] * vcol[2]; }
-                else if (vsh0) { vsh0[0] = bas[0] * vcol[0]; vsh0[1] = bas[0] * vcol[1]; vsh0[2] = bas[0] * vcol[2]; }
+                else if (vsh0 && !fact) { vsh0[0] = bas[0] * vcol[0]; vsh0[1] = bas[0] * vcol[1]; vsh0[2] = bas[0] * vcol[2]; }
                 for (int k = 1; k < nbK; ++k) {   // read the coefficient, then overwrite it with its gradient
                     const float a0 = lN[3 * (k - 1)], a1 = lN[3 * (k - 1) + 1], a2 = lN[3 * (k - 1) + 2];
                     const float s = a0 * vcol[0] + a1 * vcol[1] + a2 * vcol[2];
@@ -593,6 +602,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(BwdParams p)
                 }
                 for (int k = 3 * (nbK - 1); k < 45; ++k) lN[k] = 0.f;
             }
+            if (fact) { fact[0] = dx; fact[1] = dy; fact[2] = dz; fact[3] = fcol[0]; fact[4] = fcol[1]; fact[5] = fcol[2]; }
             if (p.s.sh_degree >= 1) {
                 float dot = vdn[0] * dx + vdn[1] * dy + vdn[2] * dz;
                 v_mean[0] += (vdn[0] - dot * dx) * inorm;
@@ -720,7 +730,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(BwdParams p)
     p.g.v_scales[3 * g] = v_scale[0]; p.g.v_scales[3 * g + 1] = v_scale[1]; p.g.v_scales[3 * g + 2] = v_scale[2];
     p.g.v_opacities[g] = v_opac;
     }  // g < N
-    if (L != SH_DIRECT) {
+    if (L != SH_DIRECT && !p.g.sh_factors) {
         __syncthreads();
         float *base = (L == SH_CAT ? p.g.v_sh0 : p.g.v_shN) + (size_t)g0 * ShRowTraits<L>::ROW;
         sh_stage_out<L>(base, nG * ShRowTraits<L>::ROW, sh_lds);
@@ -747,6 +757,64 @@ __global__ __launch_bounds__(256) void pack_splats_kernel(int N, const float *__
     rec4[1] = make_float4(r[4], r[5], r[6], r[7]);
     rec4[2] = make_float4(r[8], r[9], r[10], r[11]);
     rec4[3] = make_float4(r[12], r[13], r[14], r[15]);
+}
+
+// v_coeff = scale * sum over views of basis(dir_view) (x) v_colour_view  — see dnsplat_sh_grads_from_factors
+template <int L>
+__global__ __launch_bounds__(256) void sh_from_factors_kernel(int N, int n_views, const float *__restrict__ factors, int degree,
+                                                              float scale, float *__restrict__ v_sh0, int s0,
+                                                              float *__restrict__ v_shN, int sN, int restK)
+{
+    __shared__ float sh_lds[L == SH_DIRECT ? 1 : SH_STAGE_THREADS * ShRowTraits<L>::LDS_ROW];
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g0 = blockIdx.x * SH_STAGE_THREADS;
+    const int nG = min(SH_STAGE_THREADS, N - g0);
+    const int nb = (degree + 1) * (degree + 1);
+    float acc[48];
+#pragma unroll
+    for (int i = 0; i < 48; ++i) acc[i] = 0.f;
+    if (g < N) {
+        for (int v = 0; v < n_views; ++v) {
+            const float2 *f = reinterpret_cast<const float2 *>(factors + ((size_t)v * N + g) * 6);
+            const float2 f0 = f[0], f1 = f[1], f2 = f[2];   // dir.xy | dir.z col.r | col.g col.b
+            const float c0 = f1.y, c1 = f2.x, c2 = f2.y;
+            if (c0 == 0.f && c1 == 0.f && c2 == 0.f) continue;
+            float bas[16];
+            sh_basis(degree, f0.x, f0.y, f1.x, bas);
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < nb) {
+                    acc[3 * k + 0] += bas[k] * c0;
+                    acc[3 * k + 1] += bas[k] * c1;
+                    acc[3 * k + 2] += bas[k] * c2;
+                }
+        }
+    }
+    if (L == SH_DIRECT) {
+        if (g >= N) return;
+        float *r0 = v_sh0 + (size_t)g * s0;
+        r0[0] = scale * acc[0]; r0[1] = scale * acc[1]; r0[2] = scale * acc[2];
+        if (v_shN) {
+            float *rN = v_shN + (size_t)g * sN;
+            for (int k = 0; k < 3 * restK; ++k) rN[k] = k < 45 ? scale * acc[3 + k] : 0.f;
+        }
+        return;
+    }
+    if (g < N) {
+        float *lrow = sh_lds + threadIdx.x * ShRowTraits<L>::LDS_ROW;
+        if (L == SH_CAT) {
+#pragma unroll
+            for (int k = 0; k < 48; ++k) lrow[k] = scale * acc[k];
+        } else {
+            float *r0 = v_sh0 + (size_t)g * s0;
+            r0[0] = scale * acc[0]; r0[1] = scale * acc[1]; r0[2] = scale * acc[2];
+#pragma unroll
+            for (int k = 0; k < 45; ++k) lrow[k] = scale * acc[3 + k];
+        }
+    }
+    __syncthreads();
+    float *base = (L == SH_CAT ? v_sh0 : v_shN) + (size_t)g0 * ShRowTraits<L>::ROW;
+    sh_stage_out<L>(base, nG * ShRowTraits<L>::ROW, sh_lds);
 }
 
 }  // namespace
@@ -824,6 +892,35 @@ extern "C" int dnsplat_project_bwd(const dnsplat_scene *scene, const dnsplat_cam
         case SH_SPLIT: hipLaunchKernelGGL(project_bwd_kernel<SH_SPLIT>, grid, block, 0, (hipStream_t)stream, p); break;
         case SH_CAT: hipLaunchKernelGGL(project_bwd_kernel<SH_CAT>, grid, block, 0, (hipStream_t)stream, p); break;
         default: hipLaunchKernelGGL(project_bwd_kernel<SH_DIRECT>, grid, block, 0, (hipStream_t)stream, p);
+    }
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}
+
+extern "C" int dnsplat_sh_grads_from_factors(int32_t N, int32_t n_views, const float *factors, int32_t sh_degree, int32_t sh_K,
+                                             float scale, float *v_sh0, int32_t v_sh0_stride, float *v_shN,
+                                             int32_t v_shN_stride, dnsplat_stream_t stream)
+{
+    if (N < 0 || n_views < 1 || sh_degree < 0 || sh_degree > 3 || sh_K < (sh_degree + 1) * (sh_degree + 1)) return DNSPLAT_ERR_INVALID_ARG;
+    if (N == 0) return DNSPLAT_OK;
+    if (!factors || !v_sh0 || (sh_K > 1 && !v_shN)) return DNSPLAT_ERR_INVALID_ARG;
+    dnsplat_scene fake{};
+    fake.sh_degree = sh_degree; fake.sh_K = sh_K;
+    const int layout = sh_layout(&fake, v_sh0, v_sh0_stride, v_shN, v_shN_stride);
+    dim3 block(256), grid((N + 255) / 256);
+    const int restK = sh_K - 1;
+    switch (layout) {
+        case SH_SPLIT:
+            hipLaunchKernelGGL(sh_from_factors_kernel<SH_SPLIT>, grid, block, 0, (hipStream_t)stream, N, n_views, factors, sh_degree,
+                               scale, v_sh0, v_sh0_stride, v_shN, v_shN_stride, restK);
+            break;
+        case SH_CAT:
+            hipLaunchKernelGGL(sh_from_factors_kernel<SH_CAT>, grid, block, 0, (hipStream_t)stream, N, n_views, factors, sh_degree,
+                               scale, v_sh0, v_sh0_stride, v_shN, v_shN_stride, restK);
+            break;
+        default:
+            hipLaunchKernelGGL(sh_from_factors_kernel<SH_DIRECT>, grid, block, 0, (hipStream_t)stream, N, n_views, factors, sh_degree,
+                               scale, v_sh0, v_sh0_stride, v_shN, v_shN_stride, restK);
     }
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;

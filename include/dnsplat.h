@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DNSPLAT_ABI_VERSION 2
+#define DNSPLAT_ABI_VERSION 3
 #define DNSPLAT_RECORD_FLOATS 16
 #define DNSPLAT_MAX_CHANNELS 8
 
@@ -216,6 +216,16 @@ int dnsplat_dn_depth_normals(int32_t width, int32_t height, float fx, float fy, 
 int dnsplat_camera_prepare(const float *c2w, float fx, float fy, float cx, float cy,
                            float *viewmat, float *K, float *normal_frame, dnsplat_stream_t stream);
 
+/* Multi-view data parallelism, compact exchange of the SH gradients.  For one camera the gradient of Gaussian g's SH
+ * coefficients is an outer product  v_coeff[g][k][c] = basis_k(dir_g) * v_colour[g][c]  (k < (degree+1)^2, c < 3): 6 numbers
+ * determine 48.  With one camera per GPU the ranks therefore all-gather the 24-byte factors instead of all-reducing the
+ * 192-byte coefficient gradients (7 x 24 B received per Gaussian instead of ~2 x 7/8 x 192 B over xGMI at 8 GPUs), and
+ * every rank rebuilds   v_coeff = scale * sum_views basis(dir_view) (x) v_colour_view   with this kernel.
+ * factors: [n_views, N, 6] as written by dnsplat_project_bwd (sh_factors).  Layouts as dnsplat_scene.sh0 / shN. */
+int dnsplat_sh_grads_from_factors(int32_t N, int32_t n_views, const float *factors, int32_t sh_degree, int32_t sh_K,
+                                  float scale, float *v_sh0, int32_t v_sh0_stride, float *v_shN, int32_t v_shN_stride,
+                                  dnsplat_stream_t stream);
+
 /* Densification statistics: the per-step accumulation nerfstudio's SplatfactoModel.after_train
  * performs on the renderer's outputs (called at dn_model.py:938-942, consumed by refinement_after dn_model.py:286-296):
  * for every Gaussian with radii > 0
@@ -269,6 +279,9 @@ typedef struct dnsplat_proj_grads {
     float *v_sh0; int32_t v_sh0_stride;   /* like scene.sh0 / shN; NULL to skip */
     float *v_shN; int32_t v_shN_stride;
     float *v_colors;             /* [N,n_colors] when sh_degree < 0; NULL to skip */
+    float *sh_factors;           /* optional [N,6]: when non-NULL the SH coefficient gradients are NOT written; instead the
+                                    two factors of their outer product are: unit view direction (3) and the clamp-masked
+                                    colour gradient (3); zeros for culled Gaussians.  See dnsplat_sh_grads_from_factors. */
 } dnsplat_proj_grads;
 
 int dnsplat_project_bwd(const dnsplat_scene *scene, const dnsplat_camera *cam,

@@ -72,6 +72,49 @@ def _worker(rank, world, port, ret):
     assert all(torch.allclose(fake[k].grad, torch.full_like(fake[k], (1 + world) / 2)) for k in KEYS)
     assert dp.max_over_ranks(float(rank), dev) == world - 1
     assert dp.sum_over_ranks([1.0, float(rank)], dev) == [float(world), float(sum(range(world)))]
+    # SH factor exchange: all-gather of the (direction, colour gradient) pairs + rebuild == mean of the outer products.
+    # The HIP rebuild kernel is swapped for a torch reference here (autograd through the oracle's dense SH evaluation).
+    from oracle import dense_ref
+
+    def rebuild_ref(gathered, n, w, deg, K, v_coeffs, v_sh0, v_shN):
+        tot = torch.zeros(n, K, 3)
+        for v in range(w):
+            co = torch.zeros(n, K, 3, requires_grad=True)
+            (dense_ref.sh_colors(deg, gathered[v, :, :3], co) * gathered[v, :, 3:]).sum().backward()
+            tot += co.grad
+        tot /= w
+        v_sh0.copy_(tot[:, 0])
+        v_shN.copy_(tot[:, 1:])
+
+    ex = dp.ShFactorExchange()
+    ex._rebuild = rebuild_ref
+    n_g = 40
+    gen = torch.Generator().manual_seed(7 + rank)
+    fpar = {k: torch.nn.Parameter(torch.zeros(s)) for k, s in (("means", (n_g, 3)), ("scales", (n_g, 3)), ("quats", (n_g, 4)),
+                                                              ("opacities", (n_g, 1)), ("features_dc", (n_g, 3)),
+                                                              ("features_rest", (n_g, 15, 3)))}
+    far = dp.GradArena(fpar)
+    for k in KEYS:
+        fpar[k].grad = far.take(fpar[k])
+        fpar[k].grad.fill_(float(rank))
+    mine = ex.begin(n_g, torch.device("cpu"), 3, 16, None, None, None)
+    dirs = torch.nn.functional.normalize(torch.randn(n_g, 3, generator=gen), dim=-1)
+    cols = torch.randn(n_g, 3, generator=gen)
+    mine.copy_(torch.cat([dirs, cols], 1))
+    got_bytes = dp.allreduce_gradients(fpar, far, exchange=ex)
+    assert got_bytes == 11 * n_g * 4 + (world - 1) * n_g * 24
+    assert torch.allclose(fpar["quats"].grad, torch.full((n_g, 4), (world - 1) / 2))      # geometry part: plain mean
+    # every rank must hold the same rebuilt SH gradient = mean over ranks of basis (x) colour
+    chk = fpar["features_rest"].grad.clone()
+    dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+    assert torch.allclose(chk / world, fpar["features_rest"].grad, atol=1e-6)
+    own = torch.zeros(n_g, 16, 3, requires_grad=True)
+    (dense_ref.sh_colors(3, dirs, own) * cols).sum().backward()
+    allc = own.grad.clone()
+    dist.all_reduce(allc, op=dist.ReduceOp.SUM)
+    assert torch.allclose(allc[:, 1:] / world, fpar["features_rest"].grad, atol=1e-5)
+    assert torch.allclose(allc[:, 0] / world, fpar["features_dc"].grad, atol=1e-5)
+
     # densification statistics: sums over the step's increments, max over ranks (densify.py)
     from dn_splatter_amd.densify import DensifyStats
     prev = DensifyStats(8, "cpu")

@@ -424,6 +424,84 @@ def test_batched_multi_stream_rendering_equals_sequential(dns):
             dns.set_bin_policy("sync")
 
 
+@pytest.mark.parametrize("layout", ["split", "cat"])
+def test_sh_factor_exchange_rebuilds_the_multi_camera_gradient(dns, layout):
+    """Data parallel: all-gathering the 6 SH-gradient factors per Gaussian and rebuilding the sum equals averaging the
+    192-byte coefficient gradients of the cameras (dp.ShFactorExchange, dnsplat_sh_grads_from_factors) — checked here
+    with three cameras rendered one after the other on one GPU; the geometry gradients are untouched by the mode."""
+    import ctypes
+
+    from dn_splatter_amd import _lib, _ops, dp, synthetic
+
+    N, W, H = 20_000, 320, 240
+    gp0 = synthetic.make_gauss_params(N, sh_rest_std=0.2, seed=9)
+    gp0["scales"] = gp0["scales"].detach() + torch.randn(N, 3, generator=torch.Generator().manual_seed(10)) * 0.5
+    cams = [synthetic.orbit_camera(v, width=W, height=H, focal=200.0).to(DEV) for v in (0, 2, 5)]
+
+    def one(cam, exchange):
+        gp = {k: v.detach().to(DEV).clone().requires_grad_(k != "normals") for k, v in gp0.items()}
+        dns.set_sh_exchange(exchange)
+        try:
+            if layout == "split":
+                m = dns.DNSplatterRenderer(gp, fused=True)
+                out = m.get_outputs(cam)
+                loss = (out["rgb"] * torch.linspace(0.5, 1.5, 3, device=DEV)).sum() + out["depth"].sum() + out["normal"].sum()
+                sh = None
+            else:
+                sh = torch.cat([gp["features_dc"][:, None], gp["features_rest"]], 1).detach().requires_grad_(True)
+                q = gp["quats"] / gp["quats"].norm(dim=-1, keepdim=True)
+                r, a, _ = dns.rasterization(gp["means"], q, torch.exp(gp["scales"]), torch.sigmoid(gp["opacities"]).squeeze(-1), sh,
+                                            dns.get_viewmat(cam.camera_to_worlds), cam.get_intrinsics_matrices(), W, H,
+                                            packed=False, sh_degree=3, render_mode="RGB+ED")
+                loss = (r[..., :3] * torch.linspace(0.5, 1.5, 3, device=DEV)).sum() + r[..., 3].sum() + a.sum()
+            loss.backward()
+        finally:
+            dns.set_sh_exchange(None)
+        torch.cuda.synchronize()
+        return gp, sh
+
+    dense = [one(c, None) for c in cams]
+    ex = dp.ShFactorExchange()
+    factors = []
+    for c in cams:
+        gp_f, sh_f = one(c, ex)
+        assert ex.meta is not None
+        factors.append(ex.mine.clone())
+        ex.meta = None
+        for k in ("means", "scales", "quats", "opacities"):       # geometry gradients do not depend on the mode
+            ref = dense[len(factors) - 1][0][k].grad
+            assert_close(gp_f[k].grad, ref, "factor mode grad " + k, 1e-4)    # two runs differ by atomic order only
+    fac = torch.stack(factors).contiguous()
+    if layout == "split":
+        v0 = torch.empty(N, 3, device=DEV)
+        vN = torch.empty(N, 15, 3, device=DEV)
+        _lib.check(_lib.lib().dnsplat_sh_grads_from_factors(N, 3, _ops._ptr(fac), 3, 16, 1.0 / 3, _ops._ptr(v0), 3, _ops._ptr(vN), 45,
+                                                            _ops._stream()), "dnsplat_sh_grads_from_factors")
+        ref0 = sum(d[0]["features_dc"].grad for d in dense) / 3
+        refN = sum(d[0]["features_rest"].grad for d in dense) / 3
+        assert_close(v0, ref0, "rebuilt features_dc gradient", 1e-5)
+        assert_close(vN, refN, "rebuilt features_rest gradient", 1e-5)
+    else:
+        vc = torch.empty(N, 16, 3, device=DEV)
+        _lib.check(_lib.lib().dnsplat_sh_grads_from_factors(N, 3, _ops._ptr(fac), 3, 16, 1.0 / 3, _ops._ptr(vc), 48,
+                                                            _ops._ptr(vc.view(-1)[3:]), 48, _ops._stream()),
+                   "dnsplat_sh_grads_from_factors")
+        ref = sum(d[1].grad for d in dense) / 3
+        assert_close(vc, ref, "rebuilt SH coefficient gradient", 1e-5)
+    # the single-rank exchange (what DNSPLAT_FORCE_DIST=1 exercises with RCCL) reproduces the dense gradient
+    gp_1, sh_1 = one(cams[0], ex)
+    if layout == "split":
+        assert ex.finish(v_sh0=gp_1["features_dc"].grad, v_shN=gp_1["features_rest"].grad) == 0
+    else:
+        assert ex.finish(v_coeffs=sh_1.grad) == 0
+    torch.cuda.synchronize()
+    if layout == "split":
+        assert_close(gp_1["features_rest"].grad, dense[0][0]["features_rest"].grad, "single-rank exchange", 1e-6)
+        assert_close(gp_1["features_dc"].grad, dense[0][0]["features_dc"].grad, "single-rank exchange dc", 1e-6)
+    else:
+        assert_close(sh_1.grad, dense[0][1].grad, "single-rank exchange", 1e-6)
+
+
 def test_capacity_policy_recovers_from_an_overflowing_guess(dns):
     """'capacity' mode sizes the intersection buffers from earlier frames and enqueues everything without a host
     round-trip; when the guess is too small the emit + composite must be redone with the exact size."""
