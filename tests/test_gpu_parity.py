@@ -5,6 +5,7 @@ Written like tests of the two gsplat calls dn-splatter makes (dn_splatter/dn_mod
 compared bit-exactly; floats at the 1e-4 tolerance BASELINE.json states (see _scenes.REL_TOL).
 """
 import math
+import os
 
 import pytest
 import torch
@@ -581,6 +582,24 @@ def c2(dns):
     m = dns.DNSplatterRenderer(gp, fused=True)
     out = m.get_outputs(cam)
     return gp, cam, m, out
+
+
+def test_c2_scene_centre_crop_matches_oracle(dns, orc):
+    """The BASELINE C2 scene itself (1 M Gaussians, fx = fy = 1200, 1080p principal point), rendered through a
+    384 x 384 window at the image centre so that the CPU oracle finishes in seconds: same Gaussians, same depth
+    complexity (~3000 entries per tile list, every pixel saturating) as the benchmark.  Both sides get the same
+    activated inputs, so every integer output is compared bit for bit."""
+    W, H, C = 1920, 1080, 384
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    inp, viewmat, K, _ = gsplat_inputs(1_000_000, W, H, focal=1200.0, seed=0)
+    K = K.clone()
+    K[..., 0, 2] -= (W - C) // 2
+    K[..., 1, 2] -= (H - C) // 2
+    o, g = _call_both(dns, orc, inp, viewmat, K, C, C, sh_degree=3, render_mode="RGB+ED", absgrad=True)
+    assert g[2]["n_isects"] > 1_000_000
+    assert float(g[1].min()) > 0.999                            # saturating pixels, like the full frame
+    _check_forward(o, g, flips=FLIP_FRACTION)
+    _check_backward(o, g, quat_atol=1e-4, flips=FLIP_FRACTION)
 
 
 def test_c2_full_size_binning_properties(dns, c2):
