@@ -44,7 +44,17 @@ namespace {
 
 constexpr int TILE = 16;
 constexpr int NPIX = TILE * TILE;
-constexpr int BUCKET = 2 * DNS_WAVE;   // splats per systolic pass: two per lane, processed as packed fp32 pairs
+constexpr int BUCKET = 2 * DNS_WAVE;   // splats in the array at a time: two per lane, processed as packed fp32 pairs
+#ifndef DNS_BWD_GROUP
+#define DNS_BWD_GROUP 16
+#endif
+constexpr int GROUP = DNS_BWD_GROUP;            // lanes that change splats at the same step
+constexpr int NGROUP = DNS_WAVE / GROUP;
+#ifndef DNS_BWD_FLUSH_REC
+#define DNS_BWD_FLUSH_REC 16
+#endif
+constexpr int FLUSH_REC = DNS_BWD_FLUSH_REC;    // gradient records staged in LDS per round of the transposed flush
+constexpr int PERIOD = NPIX + GROUP - 1;        // steps from one bucket to the next: 256 pixels + GROUP - 1 idle slots
 
 
 struct BwdArgs {
@@ -112,9 +122,8 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
     // compacted list indices waiting for a bucket (never more than 127 + 64) + the 1 KiB staging area of the transposed flush, which
     // ALIASES queue entries >= 64: while a pass is flushed only the < 64 left-over entries at the front of the queue are
     // live.  13.5 KiB per wave = 12 tiles in flight per CU (3 waves per SIMD, the VGPR limit) instead of 11.
-    __shared__ __attribute__((aligned(16))) int32_t qf[64 + 256];
-    int32_t *queue = qf;
-    float4(*flush)[4] = reinterpret_cast<float4(*)[4]>(qf + 64);
+    __shared__ int32_t queue[BUCKET + DNS_WAVE];
+    __shared__ float4 flush[FLUSH_REC][4];
 
     const int tile = dns_xcd_remap(blockIdx.x, a.n_tiles);
     const int lane = threadIdx.x;
@@ -222,11 +231,37 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     int cursor = hi;  // next (highest) list index not yet examined
-    int qn = 0;       // entries waiting in the queue (wave-uniform)
+    int qn = 0;       // entries waiting in the queue beyond the current bucket (wave-uniform)
     const uint32_t pix_base = (uint32_t)(uintptr_t)&pix[0][0];   // LDS byte address of the table
 
+    // ---- per-lane state of the stream: two splats (x = A, farther; y = B, nearer), their partial sums, the
+    // pixel counter of the lane's current bucket and the pixel state handed to the next lane --------------------
+    const f2 zero2 = {0.f, 0.f};
+    int gid_a = 0, gid_b = 0;
+    int cmp_a = 0x7fffffff, cmp_b = 0x7fffffff;   // list index of the lane's splats; "none" lies above every bin_final
+    f2 sx = zero2, sy = zero2, ca = zero2, cb = zero2, cc = zero2, opac = zero2, na = zero2, nb = zero2, nc = zero2;
+    f2 ch[8];
+    f2 g_x = zero2, g_y = zero2, g_ca = zero2, g_cb = zero2, g_cc = zero2, g_o = zero2, g_ax = zero2, g_ay = zero2;
+    f2 g_ch[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ch[k] = zero2; g_ch[k] = zero2; }
+    bool touched_a = false, touched_b = false;
+    int p = -(1 << 20);                           // negative = not started; a group's switch sets it to -(lane % GROUP)
+    float T_out = 0.f, SA_out = 0.f, SB_out = 0.f;
+
+    const int col = lane & 15;
+    const bool col_used = col < REC_CH0 + D || col >= REC_ABSX;
+    const float *fl = reinterpret_cast<const float *>(&flush[0][0]);
+    int prev_take = 0;
+
     for (;;) {
-        // ---- fill the queue with contributing entries until a full bucket (2 per lane) is available ----
+        // ==== bucket boundary: bring the left-over queue entries to the front, then test list entries (64 at a
+        // time, one per lane) until a full bucket of contributing splats is waiting or the list is exhausted ====
+        if (qn > 0) {
+            const int moved = lane < qn ? queue[BUCKET + lane] : 0;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < qn) queue[lane] = moved;
+        }
         while (qn < BUCKET && cursor >= range_start) {
             const int idx = cursor - lane;
             bool keep = false;
@@ -240,171 +275,175 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
             qn += __popcll(m);
             cursor -= DNS_WAVE;
         }
-        if (qn == 0) break;
         __builtin_amdgcn_wave_barrier();
-        const int take = min(qn, BUCKET);
-        // lane l owns entries 2l (A, farther) and 2l+1 (B, nearer): a pixel meets them in list order
-        const int idx_a = 2 * lane < take ? queue[2 * lane] : -1;
-        const int idx_b = 2 * lane + 1 < take ? queue[2 * lane + 1] : -1;
-        const int rest = qn - take;
-        const int moved = lane < rest ? queue[BUCKET + lane] : 0;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < rest) queue[lane] = moved;
-        qn = rest;
+        const int take = min(qn, BUCKET);     // entries [0, take) are this bucket; lane l owns 2l (A) and 2l+1 (B)
+        qn -= take;                           // what is left sits at [BUCKET, BUCKET + qn) until the next boundary
+        const bool last = take == 0;          // nothing new: only drain what is still in the lanes
 
-        // ---- this lane's two splats for the pass, as packed pairs (x = A, y = B) ------------------
-        int gid_a = 0, gid_b = 0;
-        float4 ra0 = make_float4(0.f, 0.f, 0.f, 0.f), ra1 = ra0, ra2 = ra0, ra3 = ra0;
-        float4 rb0 = ra0, rb1 = ra0, rb2 = ra0, rb3 = ra0;
-        if (idx_a >= 0) {
-            gid_a = a.flatten_ids[idx_a];
-            const float4 *rec = a.splats + (size_t)gid_a * 4;
-            ra0 = rec[0]; ra1 = rec[1];
-            if (D > 2) ra2 = rec[2];
-            if (D > 6) ra3 = rec[3];
-        }
-        if (idx_b >= 0) {
-            gid_b = a.flatten_ids[idx_b];
-            const float4 *rec = a.splats + (size_t)gid_b * 4;
-            rb0 = rec[0]; rb1 = rec[1];
-            if (D > 2) rb2 = rec[2];
-            if (D > 6) rb3 = rec[3];
-        }
-        const f2 sx = {ra0.x, rb0.x}, sy = {ra0.y, rb0.y};
-        const f2 ca = {ra0.z, rb0.z}, cb = {ra0.w, rb0.w}, cc = {ra1.x, rb1.x}, opac = {ra1.y, rb1.y};
-        const DnsConicE qa = dns_conic_e(ra0.z, ra0.w, ra1.x), qb = dns_conic_e(rb0.z, rb0.w, rb1.x);
-        const f2 na = {qa.na, qb.na}, nb = {qa.nb, qb.nb}, nc = {qa.nc, qb.nc};
-        const f2 ch[8] = {{ra1.z, rb1.z}, {ra1.w, rb1.w}, {ra2.x, rb2.x}, {ra2.y, rb2.y},
-                          {ra2.z, rb2.z}, {ra2.w, rb2.w}, {ra3.x, rb3.x}, {ra3.y, rb3.y}};
-        // lanes without a splat can never be valid: give them an index above every bin_final
-        const int cmp_a = idx_a >= 0 ? idx_a : 0x7fffffff;
-        const int cmp_b = idx_b >= 0 ? idx_b : 0x7fffffff;
-
-        const f2 zero2 = {0.f, 0.f};
-        f2 g_x = zero2, g_y = zero2, g_ca = zero2, g_cb = zero2, g_cc = zero2, g_o = zero2, g_ax = zero2, g_ay = zero2;
-        f2 g_ch[8];
+        for (int grp = 0; grp < NGROUP; ++grp) {
+            if (last && 2 * GROUP * grp >= prev_take) break;          // the remaining groups hold no splats
+            // ==== group switch: GROUP lanes finish their old splats together and take new ones ====================
+            // Lane l meets pixel p of a bucket at step (bucket start) + l + p, so lanes reach the end of a bucket one
+            // step apart.  GROUP - 1 idle slots between the buckets of the pixel stream let GROUP neighbouring lanes
+            // change splats at the same (wave-uniform) step: the first lane of the group is about to start pixel 0,
+            // lane i of it is i slots before pixel 0.
+            const bool mine = (lane / GROUP) == grp;
+            const uint64_t gmask = (GROUP == 64 ? ~0ull : ((1ull << GROUP) - 1ull)) << (GROUP * grp);
+            // -- flush: transpose through LDS, one atomic row per touched splat (A rows, then B rows): the group's
+            //    lanes park their 16 partial sums, then the whole wave adds those records to global memory, each
+            //    atomic instruction covering 4 complete 64-byte records.
 #pragma unroll
-        for (int k = 0; k < 8; ++k) g_ch[k] = zero2;
-        bool touched_a = false, touched_b = false;
-
-        float T_out = 0.f, SA_out = 0.f, SB_out = 0.f;
-        // The pixel row of the step is requested first and waited for only after the row-independent part
-        // (pixel coordinates, exponents, exp2) has been issued, which covers the LDS latency.
-#ifdef DNS_BWD_SKIP_LOOP
-        for (int s = 0; s < 0; ++s) {
-#else
-        for (int s = 0; s < NPIX + DNS_WAVE - 1; ++s) {
-#endif
-            const int p = s - lane;
-            const bool active = (unsigned)p < (unsigned)NPIX;
-            int pcur = p & (NPIX - 1);
-            v4f c0, c1, cst;
-            row_issue(pix_base + pcur * 48, c0, c1, cst, pcur);
-
-            const float px = fx0 + (float)(pcur & 15), py = fy0 + (float)(pcur >> 4);
-            const f2 dx = sx - px, dy = sy - py;
-            // same fused-multiply-add sequence as dns_exponent(), two splats at a time (v_pk_*_f32)
-            const f2 e = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(na, dx, nb * dy), (nc * dy) * dy);
-            f2 vis = {dns_exp2(e.x), dns_exp2(e.y)};
-            row_wait(c0, c1, cst, vis);
-            const f2 ov = opac * vis;
-            const float al_a = fminf((float)DNS_ALPHA_MAX, ov.x), al_b = fminf((float)DNS_ALPHA_MAX, ov.y);
-            // state arrives from the previous lane; lane 0 takes it from the pixel's LDS row
-            float T = dpp_wave_shr1(T_out, cst.x);
-            float SA = dpp_wave_shr1(SA_out, cst.y);
-            float SB = dpp_wave_shr1(SB_out, cst.z);
-            const int bin_final = __float_as_int(cst.w);
-            const bool valid_a = active && cmp_a <= bin_final && e.x <= 0.f && al_a >= (float)DNS_ALPHA_MIN;
-            const bool valid_b = active && cmp_b <= bin_final && e.y <= 0.f && al_b >= (float)DNS_ALPHA_MIN;
-            {   // straight-line: an idle step costs the same as a busy one, but no phi copies at a join
-                touched_a |= valid_a; touched_b |= valid_b;
-                // an invalid pair takes alpha = 0 (=> 1/(1-alpha) = 1, weight 0: state and sums unchanged) and m = 0
-                const f2 alpha = {valid_a ? al_a : 0.f, valid_b ? al_b : 0.f};
-                const f2 m = {(valid_a && ov.x <= (float)DNS_ALPHA_MAX) ? 1.f : 0.f,
-                              (valid_b && ov.y <= (float)DNS_ALPHA_MAX) ? 1.f : 0.f};
-                const f2 om = 1.f - alpha;
-                const f2 ra = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
-                const float T1 = T * ra.x, T2 = T1 * ra.y;          // the pixel meets A, then B
-                const f2 Tv = {T1, T2};
-                const f2 fac = alpha * Tv;
-                // the pixel's cotangents as aligned register pairs; a channel is broadcast to both splats by
-                // selecting one half of its pair (op_sel), not by copying it
-                const f2 pp[4] = {__builtin_shufflevector(c0, c0, 0, 1), __builtin_shufflevector(c0, c0, 2, 3),
-                                  __builtin_shufflevector(c1, c1, 0, 1), __builtin_shufflevector(c1, c1, 2, 3)};
-                f2 cva = zero2, cvb = zero2;
-#pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    const f2 vk = (k & 1) ? __builtin_shufflevector(pp[k >> 1], pp[k >> 1], 1, 1)
-                                          : __builtin_shufflevector(pp[k >> 1], pp[k >> 1], 0, 0);
-                    // two plain v_fmac: hipcc would materialise the broadcast pair for a packed FMA here
-                    g_ch[k].x = __builtin_fmaf(fac.x, vk.x, g_ch[k].x);
-                    g_ch[k].y = __builtin_fmaf(fac.y, vk.y, g_ch[k].y);
-                    if (k < split) cva = __builtin_elementwise_fma(ch[k], vk, cva);
-                    else cvb = __builtin_elementwise_fma(ch[k], vk, cvb);
-                }
-                const float SA1 = __builtin_fmaf(fac.x, cva.x, SA);
-                const f2 SAv = {SA, SA1};
-                const f2 va_a = Tv * cva - ra * SAv;
-                SA = __builtin_fmaf(fac.y, cva.y, SA1);
-                f2 va = va_a;
-                if (SPLIT != D) {
-                    const float SB1 = __builtin_fmaf(fac.x, cvb.x, SB);
-                    const f2 SBv = {SB, SB1};
-                    va += Tv * cvb - ra * SBv;
-                    SB = __builtin_fmaf(fac.y, cvb.y, SB1);
-                }
-                const f2 nov = -(ov * m);
-                const f2 vs = nov * va, vs_a = nov * va_a;
-                const f2 hx = vs * dx, hy = vs * dy;
-                g_ca = __builtin_elementwise_fma(hx, dx, g_ca);      // x 1/2 at the flush
-                g_cb = __builtin_elementwise_fma(hx, dy, g_cb);
-                g_cc = __builtin_elementwise_fma(hy, dy, g_cc);
-                const f2 gx = vs_a * (ca * dx + cb * dy);
-                const f2 gy = vs_a * (cb * dx + cc * dy);
-                g_x += gx; g_y += gy;
-                g_ax += __builtin_elementwise_abs(gx); g_ay += __builtin_elementwise_abs(gy);
-                g_o = __builtin_elementwise_fma(vis * m, va, g_o);
-                T = T2;
-            }
-            T_out = T; SA_out = SA; SB_out = SB;
-            // park the state of the pixel leaving the array for the next (nearer) bucket
-            if (lane == DNS_WAVE - 1 && active) pix[pcur][2] = make_float4(T, SA, SB, cst.w);
-        }
-
-        // ---- flush: transpose through LDS, one atomic row per touched splat (A rows, then B rows) ----
-        // Sixteen lanes at a time park their 16 partial sums; then the whole wave adds those 16 records to
-        // global memory with 4 atomic instructions, each covering 4 complete 64-byte records.
-        const int col = lane & 15;
-        const bool col_used = col < REC_CH0 + D || col >= REC_ABSX;
-        const float *fl = reinterpret_cast<const float *>(&flush[0][0]);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int gid = half ? gid_b : gid_a;
-            const uint64_t tmask = __ballot(half ? touched_b : touched_a);
+            for (int half = 0; half < 2; ++half) {
+                const uint64_t tmask = __ballot(half ? touched_b : touched_a) & gmask;
+                if (tmask == 0) continue;                                    // wave-uniform
+                const int gid = half ? gid_b : gid_a;
 #define SEL(v) (half ? (v).y : (v).x)
-            const float4 f0 = make_float4(SEL(g_x), SEL(g_y), 0.5f * SEL(g_ca), SEL(g_cb));
-            const float4 f1 = make_float4(0.5f * SEL(g_cc), SEL(g_o), SEL(g_ch[0]), SEL(g_ch[1]));
-            const float4 f2v = make_float4(SEL(g_ch[2]), SEL(g_ch[3]), SEL(g_ch[4]), SEL(g_ch[5]));
-            const float4 f3 = make_float4(SEL(g_ch[6]), SEL(g_ch[7]), SEL(g_ax), SEL(g_ay));
+#pragma unroll
+                for (int sub = 0; sub < GROUP / FLUSH_REC; ++sub) {
+                    if (((tmask >> (GROUP * grp + FLUSH_REC * sub)) & ((1ull << FLUSH_REC) - 1ull)) == 0) continue;   // wave-uniform
+                    if (mine && (lane % GROUP) / FLUSH_REC == sub) {
+                        const int r = lane % FLUSH_REC;
+                        flush[r][0] = make_float4(SEL(g_x), SEL(g_y), 0.5f * SEL(g_ca), SEL(g_cb));
+                        flush[r][1] = make_float4(0.5f * SEL(g_cc), SEL(g_o), SEL(g_ch[0]), SEL(g_ch[1]));
+                        flush[r][2] = make_float4(SEL(g_ch[2]), SEL(g_ch[3]), SEL(g_ch[4]), SEL(g_ch[5]));
+                        flush[r][3] = make_float4(SEL(g_ch[6]), SEL(g_ch[7]), SEL(g_ax), SEL(g_ay));
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int j = 0; j < FLUSH_REC / 4; ++j) {
+                        const int rec = j * 4 + (lane >> 4);                         // record within the round
+                        const int src = GROUP * grp + FLUSH_REC * sub + rec;         // the lane that owns that splat
+                        const int rgid = __shfl(gid, src, DNS_WAVE);
+                        const float val = fl[j * 64 + lane];
+                        if (((tmask >> src) & 1) && col_used) unsafeAtomicAdd(a.v_splats + (size_t)rgid * DNS_REC + col, val);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
 #undef SEL
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (((tmask >> (16 * q)) & 0xffffull) == 0) continue;     // wave-uniform: none of these 16 splats touched
-                if ((lane >> 4) == q) {
-                    flush[lane & 15][0] = f0; flush[lane & 15][1] = f1; flush[lane & 15][2] = f2v; flush[lane & 15][3] = f3;
+            }
+            // -- the group's new splats, as packed pairs
+            if (mine) {
+                const int idx_a = 2 * lane < take ? queue[2 * lane] : -1;
+                const int idx_b = 2 * lane + 1 < take ? queue[2 * lane + 1] : -1;
+                float4 ra0 = make_float4(0.f, 0.f, 0.f, 0.f), ra1 = ra0, ra2 = ra0, ra3 = ra0;
+                float4 rb0 = ra0, rb1 = ra0, rb2 = ra0, rb3 = ra0;
+                gid_a = 0; gid_b = 0;
+                if (idx_a >= 0) {
+                    gid_a = a.flatten_ids[idx_a];
+                    const float4 *rec = a.splats + (size_t)gid_a * 4;
+                    ra0 = rec[0]; ra1 = rec[1];
+                    if (D > 2) ra2 = rec[2];
+                    if (D > 6) ra3 = rec[3];
                 }
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int row = j * 4 + (lane >> 4);          // 0..15 within this group of lanes
-                    const int src = 16 * q + row;                 // the lane that owns that splat
-                    const int rgid = __shfl(gid, src, DNS_WAVE);
-                    const float val = fl[j * 64 + lane];
-                    if (((tmask >> src) & 1) && col_used) unsafeAtomicAdd(a.v_splats + (size_t)rgid * DNS_REC + col, val);
+                if (idx_b >= 0) {
+                    gid_b = a.flatten_ids[idx_b];
+                    const float4 *rec = a.splats + (size_t)gid_b * 4;
+                    rb0 = rec[0]; rb1 = rec[1];
+                    if (D > 2) rb2 = rec[2];
+                    if (D > 6) rb3 = rec[3];
                 }
-                __builtin_amdgcn_wave_barrier();
+                sx = f2{ra0.x, rb0.x}; sy = f2{ra0.y, rb0.y};
+                ca = f2{ra0.z, rb0.z}; cb = f2{ra0.w, rb0.w}; cc = f2{ra1.x, rb1.x}; opac = f2{ra1.y, rb1.y};
+                const DnsConicE qa = dns_conic_e(ra0.z, ra0.w, ra1.x), qb = dns_conic_e(rb0.z, rb0.w, rb1.x);
+                na = f2{qa.na, qb.na}; nb = f2{qa.nb, qb.nb}; nc = f2{qa.nc, qb.nc};
+                ch[0] = f2{ra1.z, rb1.z}; ch[1] = f2{ra1.w, rb1.w}; ch[2] = f2{ra2.x, rb2.x}; ch[3] = f2{ra2.y, rb2.y};
+                ch[4] = f2{ra2.z, rb2.z}; ch[5] = f2{ra2.w, rb2.w}; ch[6] = f2{ra3.x, rb3.x}; ch[7] = f2{ra3.y, rb3.y};
+                cmp_a = idx_a >= 0 ? idx_a : 0x7fffffff;
+                cmp_b = idx_b >= 0 ? idx_b : 0x7fffffff;
+                g_x = zero2; g_y = zero2; g_ca = zero2; g_cb = zero2; g_cc = zero2; g_o = zero2; g_ax = zero2; g_ay = zero2;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g_ch[k] = zero2;
+                touched_a = false; touched_b = false;
+                p = -(lane % GROUP);
+            }
+            int nsteps = grp < NGROUP - 1 ? GROUP : PERIOD - GROUP * (NGROUP - 1);
+            if (last) {
+                if (2 * GROUP * (grp + 1) >= prev_take) break;           // that was the last group with anything to flush
+                nsteps = GROUP;
+            }
+
+            // ==== the stream: nsteps steps, one pixel per lane per step ===========================================
+            // The pixel row of the step is requested first and waited for only after the row-independent part
+            // (pixel coordinates, exponents, exp2) has been issued, which covers the LDS latency.
+            for (int s = 0; s < nsteps; ++s) {
+                const bool active = (unsigned)p < (unsigned)NPIX;
+                int pcur = p & (NPIX - 1);
+                v4f c0, c1, cst;
+                row_issue(pix_base + pcur * 48, c0, c1, cst, pcur);
+
+                const float px = fx0 + (float)(pcur & 15), py = fy0 + (float)(pcur >> 4);
+                const f2 dx = sx - px, dy = sy - py;
+                // same fused-multiply-add sequence as dns_exponent(), two splats at a time (v_pk_*_f32)
+                const f2 e = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(na, dx, nb * dy), (nc * dy) * dy);
+                f2 vis = {dns_exp2(e.x), dns_exp2(e.y)};
+                row_wait(c0, c1, cst, vis);
+                const f2 ov = opac * vis;
+                const float al_a = fminf((float)DNS_ALPHA_MAX, ov.x), al_b = fminf((float)DNS_ALPHA_MAX, ov.y);
+                // state arrives from the previous lane; lane 0 takes it from the pixel's LDS row
+                float T = dpp_wave_shr1(T_out, cst.x);
+                float SA = dpp_wave_shr1(SA_out, cst.y);
+                float SB = dpp_wave_shr1(SB_out, cst.z);
+                const int bin_final = __float_as_int(cst.w);
+                const bool valid_a = active && cmp_a <= bin_final && e.x <= 0.f && al_a >= (float)DNS_ALPHA_MIN;
+                const bool valid_b = active && cmp_b <= bin_final && e.y <= 0.f && al_b >= (float)DNS_ALPHA_MIN;
+                {   // straight-line: an idle step costs the same as a busy one, but no phi copies at a join
+                    touched_a |= valid_a; touched_b |= valid_b;
+                    // an invalid pair takes alpha = 0 (=> 1/(1-alpha) = 1, weight 0: state and sums unchanged) and m = 0
+                    const f2 alpha = {valid_a ? al_a : 0.f, valid_b ? al_b : 0.f};
+                    const f2 m = {(valid_a && ov.x <= (float)DNS_ALPHA_MAX) ? 1.f : 0.f,
+                                  (valid_b && ov.y <= (float)DNS_ALPHA_MAX) ? 1.f : 0.f};
+                    const f2 om = 1.f - alpha;
+                    const f2 ra = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                    const float T1 = T * ra.x, T2 = T1 * ra.y;          // the pixel meets A, then B
+                    const f2 Tv = {T1, T2};
+                    const f2 fac = alpha * Tv;
+                    // the pixel's cotangents as aligned register pairs; a channel is broadcast to both splats by
+                    // selecting one half of its pair (op_sel), not by copying it
+                    const f2 pp[4] = {__builtin_shufflevector(c0, c0, 0, 1), __builtin_shufflevector(c0, c0, 2, 3),
+                                      __builtin_shufflevector(c1, c1, 0, 1), __builtin_shufflevector(c1, c1, 2, 3)};
+                    f2 cva = zero2, cvb = zero2;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        const f2 vk = (k & 1) ? __builtin_shufflevector(pp[k >> 1], pp[k >> 1], 1, 1)
+                                              : __builtin_shufflevector(pp[k >> 1], pp[k >> 1], 0, 0);
+                        // two plain v_fmac: hipcc would materialise the broadcast pair for a packed FMA here
+                        g_ch[k].x = __builtin_fmaf(fac.x, vk.x, g_ch[k].x);
+                        g_ch[k].y = __builtin_fmaf(fac.y, vk.y, g_ch[k].y);
+                        if (k < split) cva = __builtin_elementwise_fma(ch[k], vk, cva);
+                        else cvb = __builtin_elementwise_fma(ch[k], vk, cvb);
+                    }
+                    const float SA1 = __builtin_fmaf(fac.x, cva.x, SA);
+                    const f2 SAv = {SA, SA1};
+                    const f2 va_a = Tv * cva - ra * SAv;
+                    SA = __builtin_fmaf(fac.y, cva.y, SA1);
+                    f2 va = va_a;
+                    if (SPLIT != D) {
+                        const float SB1 = __builtin_fmaf(fac.x, cvb.x, SB);
+                        const f2 SBv = {SB, SB1};
+                        va += Tv * cvb - ra * SBv;
+                        SB = __builtin_fmaf(fac.y, cvb.y, SB1);
+                    }
+                    const f2 nov = -(ov * m);
+                    const f2 vs = nov * va, vs_a = nov * va_a;
+                    const f2 hx = vs * dx, hy = vs * dy;
+                    g_ca = __builtin_elementwise_fma(hx, dx, g_ca);      // x 1/2 at the flush
+                    g_cb = __builtin_elementwise_fma(hx, dy, g_cb);
+                    g_cc = __builtin_elementwise_fma(hy, dy, g_cc);
+                    const f2 gx = vs_a * (ca * dx + cb * dy);
+                    const f2 gy = vs_a * (cb * dx + cc * dy);
+                    g_x += gx; g_y += gy;
+                    g_ax += __builtin_elementwise_abs(gx); g_ay += __builtin_elementwise_abs(gy);
+                    g_o = __builtin_elementwise_fma(vis * m, va, g_o);
+                    T = T2;
+                }
+                T_out = T; SA_out = SA; SB_out = SB;
+                // park the state of the pixel leaving the array for the next (nearer) bucket
+                if (lane == DNS_WAVE - 1 && active) pix[pcur][2] = make_float4(T, SA, SB, cst.w);
+                ++p;
             }
         }
+        if (last) break;
+        prev_take = take;
     }
 }
 
