@@ -304,7 +304,7 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
                     if (mine && (lane % GROUP) / FLUSH_REC == sub) {
                         const int r = lane % FLUSH_REC;
                         flush[r][0] = make_float4(SEL(g_x), SEL(g_y), 0.5f * SEL(g_ca), SEL(g_cb));
-                        flush[r][1] = make_float4(0.5f * SEL(g_cc), SEL(g_o), SEL(g_ch[0]), SEL(g_ch[1]));
+                        flush[r][1] = make_float4(0.5f * SEL(g_cc), SEL(g_o) / SEL(opac), SEL(g_ch[0]), SEL(g_ch[1]));
                         flush[r][2] = make_float4(SEL(g_ch[2]), SEL(g_ch[3]), SEL(g_ch[4]), SEL(g_ch[5]));
                         flush[r][3] = make_float4(SEL(g_ch[6]), SEL(g_ch[7]), SEL(g_ax), SEL(g_ay));
                     }
@@ -365,6 +365,10 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
             // ==== the stream: nsteps steps, one pixel per lane per step ===========================================
             // The pixel row of the step is requested first and waited for only after the row-independent part
             // (pixel coordinates, exponents, exp2) has been issued, which covers the LDS latency.
+            // Settle every LDS result the switch left pending (bpermutes of a skipped flush round, queue reads) HERE:
+            // otherwise hipcc's wait insertion may find one of their registers overwritten in the loop and put an
+            // s_waitcnt lgkmcnt(0) right behind the row loads of every step (tools/check_asm_hazards.py: "early wait").
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), vmcnt / expcnt untouched
             for (int s = 0; s < nsteps; ++s) {
                 const bool active = (unsigned)p < (unsigned)NPIX;
                 int pcur = p & (NPIX - 1);
@@ -390,8 +394,10 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
                     touched_a |= valid_a; touched_b |= valid_b;
                     // an invalid pair takes alpha = 0 (=> 1/(1-alpha) = 1, weight 0: state and sums unchanged) and m = 0
                     const f2 alpha = {valid_a ? al_a : 0.f, valid_b ? al_b : 0.f};
-                    const f2 m = {(valid_a && ov.x <= (float)DNS_ALPHA_MAX) ? 1.f : 0.f,
-                                  (valid_b && ov.y <= (float)DNS_ALPHA_MAX) ? 1.f : 0.f};
+                    // opacity x vis where the pair is valid and alpha is not clamped, else 0: the weight of d/d(sigma)
+                    // and, divided by the opacity again at the flush, of d/d(opacity)
+                    const f2 ovm = {(valid_a && ov.x <= (float)DNS_ALPHA_MAX) ? ov.x : 0.f,
+                                    (valid_b && ov.y <= (float)DNS_ALPHA_MAX) ? ov.y : 0.f};
                     const f2 om = 1.f - alpha;
                     const f2 ra = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
                     const float T1 = T * ra.x, T2 = T1 * ra.y;          // the pixel meets A, then B
@@ -423,8 +429,7 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
                         va += Tv * cvb - ra * SBv;
                         SB = __builtin_fmaf(fac.y, cvb.y, SB1);
                     }
-                    const f2 nov = -(ov * m);
-                    const f2 vs = nov * va, vs_a = nov * va_a;
+                    const f2 vs = -ovm * va, vs_a = -ovm * va_a;
                     const f2 hx = vs * dx, hy = vs * dy;
                     g_ca = __builtin_elementwise_fma(hx, dx, g_ca);      // x 1/2 at the flush
                     g_cb = __builtin_elementwise_fma(hx, dy, g_cb);
@@ -432,8 +437,10 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
                     const f2 gx = vs_a * (ca * dx + cb * dy);
                     const f2 gy = vs_a * (cb * dx + cc * dy);
                     g_x += gx; g_y += gy;
-                    g_ax += __builtin_elementwise_abs(gx); g_ay += __builtin_elementwise_abs(gy);
-                    g_o = __builtin_elementwise_fma(vis * m, va, g_o);
+                    // |.| as a source modifier of a plain add: cheaper than masking the sign bits and a packed add
+                    g_ax.x += __builtin_fabsf(gx.x); g_ax.y += __builtin_fabsf(gx.y);
+                    g_ay.x += __builtin_fabsf(gy.x); g_ay.y += __builtin_fabsf(gy.y);
+                    g_o = __builtin_elementwise_fma(ovm, va, g_o);             // / opacity at the flush
                     T = T2;
                 }
                 T_out = T; SA_out = SA; SB_out = SB;

@@ -36,6 +36,17 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float seed)
             if (OP == 16) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(a[i]));
             if (OP == 17) asm volatile("v_cmp_le_f32 s[10:11], %0, %1" :: "v"(a[i]), "v"(c) : "s10", "s11");
             if (OP == 18) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+            if (OP == 20) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p[i]) : "v"(m2), "v"(c2));
+            if (OP == 21) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(p[i]) : "v"(m2));
+            if (OP == 22) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(p[i]) : "v"(m2), "v"(c2));
+            if (OP == 23) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[i]) : "v"(p[(i + 1) & 7]), "v"(p[(i + 2) & 7]));
+            if (OP == 24) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
+            if (OP == 25) asm volatile("v_pk_mul_f32 %0, %1, %2" : "+v"(p[i]) : "v"(p[(i + 1) & 7]), "v"(p[(i + 2) & 7]));
+            if (OP == 26) asm volatile("v_mul_f32 %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
+            if (OP == 27) asm volatile("v_fma_f32 %0, %1, %2, %3" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]), "v"(a[(i + 3) & 7]));
+            if (OP == 28) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "+v"(p[i]) : "v"(p[(i + 1) & 7]), "v"(p[(i + 2) & 7]), "v"(p[(i + 3) & 7]));
+            if (OP == 29) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p[i]) : "v"(p[(i + 1) & 7]), "v"(p[(i + 2) & 7]));
+            if (OP == 30) asm volatile("v_pk_add_f32 %0, %1, %2" : "+v"(p[i]) : "v"(p[(i + 1) & 7]), "v"(p[(i + 2) & 7]));
             if (OP == 19) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
         }
     }
@@ -73,6 +84,8 @@ int main()
         run<2>("v_exp_f32", w); run<3>("v_rcp_f32", w); run<6>("v_cndmask_b32", w); run<7>("nop+mov_dpp", w);
         run<10>("v_cmp_le_f32", w); run<11>("v_min_f32", w); run<12>("cndmask_e64_sgpr", w); run<13>("cmp+cndmask", w);
         run<14>("v_mov_b32", w); run<15>("v_and_b32", w); run<16>("v_cvt_ubyte0", w); run<17>("v_cmp->sgpr", w); run<18>("v_fmac_f32", w); run<19>("v_max3_f32", w);
+        run<23>("pk_fma 3reg", w); run<24>("fmac 3reg", w); run<25>("pk_mul 3reg", w); run<26>("mul 3reg", w); run<27>("fma 4reg", w); run<28>("pk_fma 4reg", w); run<29>("pk_fma 3reg opsel", w); run<30>("pk_add 3reg", w);
+        run<20>("pk_fma opselhi", w); run<21>("pk_mul opselhi", w); run<22>("pk_fma opsel", w);
     }
     return 0;
 }
