@@ -104,19 +104,31 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t *
     if (threadIdx.x <= mask) table[(size_t)threadIdx.x * nb + blockIdx.x] = hist[threadIdx.x];
 }
 
-// one workgroup per digit: exclusive scan of table[d][0..nb) in place, totals[d] = row sum
+// one workgroup per digit: exclusive scan of table[d][0..nb) in place, totals[d] = row sum.  Eight consecutive
+// counters per thread and round: the tile passes scan ~5 k counters per digit, which is 3 rounds instead of 21.
 __global__ __launch_bounds__(SC_THREADS) void radix_scan_kernel(uint32_t *__restrict__ table, int nb,
                                                                 uint32_t *__restrict__ totals)
 {
     __shared__ uint32_t lds_wave[4];
     uint32_t *row = table + (size_t)blockIdx.x * nb;
     uint32_t carry = 0;
-    for (int start = 0; start < nb; start += SC_THREADS) {
-        int i = start + threadIdx.x;
-        uint32_t v = (i < nb) ? row[i] : 0u;
+    for (int start = 0; start < nb; start += SC_CHUNK) {
+        const int i0 = start + threadIdx.x * SC_ITEMS;
+        uint32_t v[SC_ITEMS];
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < SC_ITEMS; ++k) {
+            v[k] = (i0 + k < nb) ? row[i0 + k] : 0u;
+            s += v[k];
+        }
         uint32_t tot;
-        uint32_t inc = block_incl_scan_256(v, lds_wave, tot);
-        if (i < nb) row[i] = carry + inc - v;
+        const uint32_t inc = block_incl_scan_256(s, lds_wave, tot);
+        uint32_t run = carry + inc - s;
+#pragma unroll
+        for (int k = 0; k < SC_ITEMS; ++k) {
+            if (i0 + k < nb) row[i0 + k] = run;
+            run += v[k];
+        }
         carry += tot;
     }
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
@@ -124,11 +136,16 @@ __global__ __launch_bounds__(SC_THREADS) void radix_scan_kernel(uint32_t *__rest
 
 // DBITS = digit width of this pass (<= 8): the tile passes split their 13 bits 7 + 6 instead of 8 + 8 — fewer
 // ballots per key and longer per-digit runs for the coalesced run stores.
-template <bool WRITE_KEYS, int DBITS>
+//
+// LAST = the final pass of the tile sort: the sorted keys themselves are not needed any more (no key store), but where
+// a tile's entries start is.  Inside one digit's run of the LDS-sorted chunk the keys are non-decreasing (the stream
+// was already sorted on the lower bits and the pass is stable), so "key differs from its left neighbour" marks the
+// chunk-local first entry of a tile; the minimum of those positions over the chunks is the tile's offset.
+template <bool LAST, int DBITS>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ n_ptr, uint32_t n_cap, int shift,
-    const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nb)
+    const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nb, int32_t *__restrict__ tile_first)
 {
     // The chunk is first sorted by digit INSIDE LDS (stable), then written out run by run: consecutive lanes
     // store to consecutive addresses of one digit's run, so the stores coalesce.  A direct scatter from the
@@ -215,8 +232,9 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
             const uint32_t k = keys_s[i];
             const uint32_t d = (k >> shift) & DMASK;
             const uint32_t dst = gbase[d] + (i - dstart[d]);
-            if (WRITE_KEYS) keys_out[dst] = k;
+            if (!LAST) keys_out[dst] = k;
             vals_out[dst] = vals_s[i];
+            if (LAST && (i == 0 || keys_s[i - 1] != k)) atomicMin(&tile_first[k], (int32_t)dst);
         }
     }
 }
@@ -328,23 +346,40 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// 5. tile offsets from the tile-sorted keys (gsplat isect_offset_encode), T+1 entries
-__global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t *__restrict__ tkeys,
-                                                           const uint32_t *__restrict__ n_ptr, uint32_t n_cap,
-                                                           int n_tiles, int32_t *__restrict__ offsets)
+// 5. tile offsets (gsplat isect_offset_encode), T+1 entries: offsets[t] = number of entries with tile id < t.
+// tile_first_init fills the array with n; the last scatter pass lowers the entries of the non-empty tiles to the
+// position of their first entry (atomicMin); tile_offsets_fill gives every empty tile the offset of the next
+// non-empty one (a suffix minimum), which is the same number.
+__global__ __launch_bounds__(256) void tile_first_init_kernel(const uint32_t *__restrict__ n_ptr, uint32_t n_cap, int n_tiles,
+                                                              int32_t *__restrict__ offsets)
 {
-    const uint32_t n = min(*n_ptr, n_cap);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n == 0) {
-        if (i <= (uint32_t)n_tiles) offsets[i] = 0;
-        return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n_tiles) offsets[i] = (int32_t)min(*n_ptr, n_cap);
+}
+
+constexpr int TO_THREADS = 1024;
+__global__ __launch_bounds__(TO_THREADS) void tile_offsets_fill_kernel(int n_tiles, int32_t *__restrict__ offsets)
+{
+    __shared__ int32_t seg_min[TO_THREADS];
+    const int total = n_tiles + 1;
+    const int per = (total + TO_THREADS - 1) / TO_THREADS;
+    const int lo = threadIdx.x * per, hi = min(lo + per, total);
+    int32_t m = 0x7fffffff;
+    for (int i = hi - 1; i >= lo; --i) m = min(m, offsets[i]);
+    seg_min[threadIdx.x] = m;
+    __syncthreads();
+    // suffix minimum over the per-thread segments (Hillis-Steele, log2(1024) rounds)
+    for (int off = 1; off < TO_THREADS; off <<= 1) {
+        const int32_t other = threadIdx.x + off < TO_THREADS ? seg_min[threadIdx.x + off] : 0x7fffffff;
+        __syncthreads();
+        seg_min[threadIdx.x] = min(seg_min[threadIdx.x], other);
+        __syncthreads();
     }
-    if (i >= n) return;
-    const int cur = (int)tkeys[i];
-    const int prev = (i == 0) ? -1 : (int)tkeys[i - 1];
-    for (int t = prev + 1; t <= cur; ++t) offsets[t] = (int32_t)i;
-    if (i == n - 1)
-        for (int t = cur + 1; t <= n_tiles; ++t) offsets[t] = (int32_t)n;
+    int32_t run = threadIdx.x + 1 < TO_THREADS ? seg_min[threadIdx.x + 1] : 0x7fffffff;   // minimum of everything to the right
+    for (int i = hi - 1; i >= lo; --i) {
+        run = min(run, offsets[i]);
+        offsets[i] = run;
+    }
 }
 
 __global__ __launch_bounds__(256) void isect_ids_kernel(int n_tiles, const int32_t *__restrict__ offsets,
@@ -408,15 +443,22 @@ BinWs carve(void *ws, int N, int64_t cap)
     return b;
 }
 
-// one LSD pass over `dbits` bits at `shift`
+// one LSD pass over `dbits` bits at `shift`; tile_first != nullptr marks the last pass of the tile sort
 void radix_pass(hipStream_t stream, const uint32_t *ka, const uint32_t *va, uint32_t *kb, uint32_t *vb, const uint32_t *n_ptr,
-                uint32_t n_cap, int shift, int dbits, uint32_t *table, uint32_t *totals, int nb)
+                uint32_t n_cap, int shift, int dbits, uint32_t *table, uint32_t *totals, int nb, int32_t *tile_first = nullptr)
 {
     const uint32_t mask = (1u << dbits) - 1u;
     hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(RS_THREADS), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb);
     hipLaunchKernelGGL(radix_scan_kernel, dim3(1 << dbits), dim3(SC_THREADS), 0, stream, table, nb, totals);
-#define DNS_SCATTER(B) hipLaunchKernelGGL((radix_scatter_kernel<true, B>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb, \
-                                          n_ptr, n_cap, shift, table, totals, nb)
+#define DNS_SCATTER(B)                                                                                                        \
+    do {                                                                                                                      \
+        if (tile_first)                                                                                                       \
+            hipLaunchKernelGGL((radix_scatter_kernel<true, B>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb, n_ptr, \
+                               n_cap, shift, table, totals, nb, tile_first);                                                  \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((radix_scatter_kernel<false, B>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb, n_ptr, \
+                               n_cap, shift, table, totals, nb, tile_first);                                                  \
+    } while (0)
     switch (dbits) {
         case 1: DNS_SCATTER(1); break;
         case 2: DNS_SCATTER(2); break;
@@ -513,21 +555,21 @@ extern "C" int dnsplat_bin_emit_sort(const dnsplat_bin_args *a, dnsplat_stream_t
                        a->radii, a->tile_size, tw, th, cap, w.tkey_a, w.tval_a);
     const int bits = tile_bits(n_tiles);
     const int passes = (bits + 7) / 8;
+    hipLaunchKernelGGL(tile_first_init_kernel, dim3((n_tiles + 1 + 255) / 256), dim3(256), 0, stream, w.total, cap, n_tiles,
+                       a->tile_offsets);
     uint32_t *ka = w.tkey_a, *kb = w.tkey_b, *va = w.tval_a, *vb = w.tval_b;
     int shift = 0;
     for (int pass = 0; pass < passes; ++pass) {
         const int dbits = (bits - shift + (passes - pass) - 1) / (passes - pass);   // 13 bits -> 7 + 6
         const bool last = pass == passes - 1;
         uint32_t *vout = last ? (uint32_t *)a->flatten_ids : vb;
-        radix_pass(stream, ka, va, kb, vout, w.total, cap, shift, dbits, w.tab_i, w.totals, w.nb_i);
+        radix_pass(stream, ka, va, kb, vout, w.total, cap, shift, dbits, w.tab_i, w.totals, w.nb_i,
+                   last ? a->tile_offsets : nullptr);
         shift += dbits;
         uint32_t *t = ka; ka = kb; kb = t;
         t = va; va = vb; vb = t;
     }
-    // sorted tile keys are in `ka` after the swap
-    const uint32_t cover = cap > (uint32_t)(n_tiles + 1) ? cap : (uint32_t)(n_tiles + 1);
-    hipLaunchKernelGGL(tile_offsets_kernel, dim3((cover + 255) / 256), dim3(256), 0, stream, ka, w.total, cap, n_tiles,
-                       a->tile_offsets);
+    hipLaunchKernelGGL(tile_offsets_fill_kernel, dim3(1), dim3(TO_THREADS), 0, stream, n_tiles, a->tile_offsets);
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;
 }
