@@ -83,7 +83,10 @@ __global__ __launch_bounds__(256) void depth_keys_kernel(int N, const int32_t *_
 
 // ------------------------------------------------------------------------------------------------
 // 2. one LSD radix pass = histogram, per-digit scan, stable scatter
-__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t *__restrict__ keys,
+// K = key type: uint32_t for the depth keys, uint16_t for tile ids (any image up to 65536 tiles), which halves the
+// key traffic of the two I-sized passes.
+template <typename K>
+__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const K *__restrict__ keys,
                                                                 const uint32_t *__restrict__ n_ptr, uint32_t n_cap,
                                                                 int shift, uint32_t mask, uint32_t *__restrict__ table,
                                                                 int nb)
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t *
 #pragma unroll
         for (int i = 0; i < RS_ITEMS; ++i) {
             uint32_t idx = base + i * RS_THREADS + threadIdx.x;
-            if (idx < n) atomicAdd(&hist[(keys[idx] >> shift) & mask], 1u);
+            if (idx < n) atomicAdd(&hist[((uint32_t)keys[idx] >> shift) & mask], 1u);
         }
     }
     __syncthreads();
@@ -141,9 +144,9 @@ __global__ __launch_bounds__(SC_THREADS) void radix_scan_kernel(uint32_t *__rest
 // a tile's entries start is.  Inside one digit's run of the LDS-sorted chunk the keys are non-decreasing (the stream
 // was already sorted on the lower bits and the pass is stable), so "key differs from its left neighbour" marks the
 // chunk-local first entry of a tile; the minimum of those positions over the chunks is the tile's offset.
-template <bool LAST, int DBITS>
+template <typename K, bool LAST, int DBITS>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
-    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
+    const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ n_ptr, uint32_t n_cap, int shift,
     const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nb, int32_t *__restrict__ tile_first)
 {
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     __shared__ uint32_t wave_loc[RS_WAVES][RS_DIGITS];   // chunk-local position of a (wave, digit) run
     __shared__ uint32_t dstart[RS_DIGITS];               // chunk-local start of a digit's run
     __shared__ uint32_t gbase[RS_DIGITS];                // global start of this chunk's run of a digit
-    __shared__ uint32_t keys_s[RS_CHUNK];
+    __shared__ K keys_s[RS_CHUNK];
     __shared__ uint32_t vals_s[RS_CHUNK];
     __shared__ uint32_t lds_wave[4];
     constexpr uint32_t DMASK = (1u << DBITS) - 1u;
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     for (int r = 0; r < RS_ITEMS; ++r) {
         const uint32_t idx = wave_start + r * DNS_WAVE + lane;
         const bool valid = idx < n;
-        key[r] = valid ? keys_in[idx] : 0u;
+        key[r] = valid ? (uint32_t)keys_in[idx] : 0u;
         val[r] = valid ? vals_in[idx] : 0u;
         const uint32_t d = (key[r] >> shift) & DMASK;
         // match-any by digit: DBITS ballots partition the wave into equal-digit lane sets
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         if (idx < n) {
             const uint32_t d = (key[r] >> shift) & DMASK;
             const uint32_t lpos = wave_loc[w][d] + rnk[r];
-            keys_s[lpos] = key[r];
+            keys_s[lpos] = (K)key[r];
             vals_s[lpos] = val[r];
         }
     }
@@ -232,9 +235,9 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
             const uint32_t k = keys_s[i];
             const uint32_t d = (k >> shift) & DMASK;
             const uint32_t dst = gbase[d] + (i - dstart[d]);
-            if (!LAST) keys_out[dst] = k;
+            if (!LAST) keys_out[dst] = (K)k;
             vals_out[dst] = vals_s[i];
-            if (LAST && (i == 0 || keys_s[i - 1] != k)) atomicMin(&tile_first[k], (int32_t)dst);
+            if (LAST && (i == 0 || (uint32_t)keys_s[i - 1] != k)) atomicMin(&tile_first[k], (int32_t)dst);
         }
     }
 }
@@ -306,11 +309,12 @@ __global__ __launch_bounds__(SC_THREADS) void scan_final_kernel(int N, const uin
 // 4. emission in depth order.  One wave owns 64 consecutive sorted Gaussians; for each one that hits
 // tiles, the 64 lanes write its (tile, gaussian) pairs side by side (row-major over its tile bbox,
 // the reference's emission order).
+template <typename K>
 __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__restrict__ order,
                                                    const uint32_t *__restrict__ cum,
                                                    const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                                                    int tile_size, int tw, int th, uint32_t cap,
-                                                   uint32_t *__restrict__ tkeys, uint32_t *__restrict__ tvals)
+                                                   K *__restrict__ tkeys, uint32_t *__restrict__ tvals)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = lane_id();
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__rest
             const uint32_t dst = s_start + t;
             if (dst < cap) {
                 const int ty = s_y0 + (int)(t / (uint32_t)s_bw), tx = s_x0 + (int)(t % (uint32_t)s_bw);
-                tkeys[dst] = (uint32_t)(ty * tw + tx);
+                tkeys[dst] = (K)(ty * tw + tx);
                 tvals[dst] = s_gid;
             }
         }
@@ -443,21 +447,24 @@ BinWs carve(void *ws, int N, int64_t cap)
     return b;
 }
 
+int tile_bits(int n_tiles);
+
 // one LSD pass over `dbits` bits at `shift`; tile_first != nullptr marks the last pass of the tile sort
-void radix_pass(hipStream_t stream, const uint32_t *ka, const uint32_t *va, uint32_t *kb, uint32_t *vb, const uint32_t *n_ptr,
+template <typename K>
+void radix_pass(hipStream_t stream, const K *ka, const uint32_t *va, K *kb, uint32_t *vb, const uint32_t *n_ptr,
                 uint32_t n_cap, int shift, int dbits, uint32_t *table, uint32_t *totals, int nb, int32_t *tile_first = nullptr)
 {
     const uint32_t mask = (1u << dbits) - 1u;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(RS_THREADS), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb);
+    hipLaunchKernelGGL(radix_hist_kernel<K>, dim3(nb), dim3(RS_THREADS), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb);
     hipLaunchKernelGGL(radix_scan_kernel, dim3(1 << dbits), dim3(SC_THREADS), 0, stream, table, nb, totals);
-#define DNS_SCATTER(B)                                                                                                        \
-    do {                                                                                                                      \
-        if (tile_first)                                                                                                       \
-            hipLaunchKernelGGL((radix_scatter_kernel<true, B>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb, n_ptr, \
-                               n_cap, shift, table, totals, nb, tile_first);                                                  \
-        else                                                                                                                  \
-            hipLaunchKernelGGL((radix_scatter_kernel<false, B>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb, n_ptr, \
-                               n_cap, shift, table, totals, nb, tile_first);                                                  \
+#define DNS_SCATTER(B)                                                                                                      \
+    do {                                                                                                                    \
+        if (tile_first)                                                                                                     \
+            hipLaunchKernelGGL((radix_scatter_kernel<K, true, B>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb,   \
+                               n_ptr, n_cap, shift, table, totals, nb, tile_first);                                         \
+        else                                                                                                                \
+            hipLaunchKernelGGL((radix_scatter_kernel<K, false, B>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb,  \
+                               n_ptr, n_cap, shift, table, totals, nb, tile_first);                                         \
     } while (0)
     switch (dbits) {
         case 1: DNS_SCATTER(1); break;
@@ -470,6 +477,32 @@ void radix_pass(hipStream_t stream, const uint32_t *ka, const uint32_t *va, uint
         default: DNS_SCATTER(8); break;
     }
 #undef DNS_SCATTER
+}
+
+// emission + stable sort of the (tile, gaussian) pairs by tile id + tile offsets
+template <typename K>
+void emit_and_sort(hipStream_t stream, const dnsplat_bin_args *a, const BinWs &w, int tw, int th, int n_tiles, uint32_t cap)
+{
+    K *ka = reinterpret_cast<K *>(w.tkey_a), *kb = reinterpret_cast<K *>(w.tkey_b);
+    uint32_t *va = w.tval_a, *vb = w.tval_b;
+    hipLaunchKernelGGL(emit_kernel<K>, dim3((a->N + 255) / 256), dim3(256), 0, stream, a->N, w.val_a, w.cum, a->means2d,
+                       a->radii, a->tile_size, tw, th, cap, ka, va);
+    const int bits = tile_bits(n_tiles);
+    const int passes = (bits + 7) / 8;
+    hipLaunchKernelGGL(tile_first_init_kernel, dim3((n_tiles + 1 + 255) / 256), dim3(256), 0, stream, w.total, cap, n_tiles,
+                       a->tile_offsets);
+    int shift = 0;
+    for (int pass = 0; pass < passes; ++pass) {
+        const int dbits = (bits - shift + (passes - pass) - 1) / (passes - pass);   // 13 bits -> 7 + 6
+        const bool last = pass == passes - 1;
+        uint32_t *vout = last ? (uint32_t *)a->flatten_ids : vb;
+        radix_pass<K>(stream, ka, va, kb, vout, w.total, cap, shift, dbits, w.tab_i, w.totals, w.nb_i,
+                      last ? a->tile_offsets : nullptr);
+        shift += dbits;
+        K *t = ka; ka = kb; kb = t;
+        uint32_t *u = va; va = vb; vb = u;
+    }
+    hipLaunchKernelGGL(tile_offsets_fill_kernel, dim3(1), dim3(TO_THREADS), 0, stream, n_tiles, a->tile_offsets);
 }
 
 int tile_bits(int n_tiles)
@@ -517,7 +550,7 @@ extern "C" int dnsplat_bin_prepare(const dnsplat_bin_args *a, dnsplat_stream_t s
         uint32_t *ka = w.key_a, *kb = w.key_b, *va = w.val_a, *vb = w.val_b;
         for (int pass = 0; pass < 4; ++pass) {
             const int shift = 8 * pass;
-            radix_pass(stream, ka, va, kb, vb, w.n_gauss, n_u32, shift, 8, w.tab_n, w.totals, w.nb_n);
+            radix_pass<uint32_t>(stream, ka, va, kb, vb, w.n_gauss, n_u32, shift, 8, w.tab_n, w.totals, w.nb_n);
             uint32_t *t = ka; ka = kb; kb = t;
             t = va; va = vb; vb = t;
         }
@@ -551,25 +584,8 @@ extern "C" int dnsplat_bin_emit_sort(const dnsplat_bin_args *a, dnsplat_stream_t
             return DNSPLAT_ERR_LAUNCH;
         return DNSPLAT_OK;
     }
-    hipLaunchKernelGGL(emit_kernel, dim3((a->N + 255) / 256), dim3(256), 0, stream, a->N, w.val_a, w.cum, a->means2d,
-                       a->radii, a->tile_size, tw, th, cap, w.tkey_a, w.tval_a);
-    const int bits = tile_bits(n_tiles);
-    const int passes = (bits + 7) / 8;
-    hipLaunchKernelGGL(tile_first_init_kernel, dim3((n_tiles + 1 + 255) / 256), dim3(256), 0, stream, w.total, cap, n_tiles,
-                       a->tile_offsets);
-    uint32_t *ka = w.tkey_a, *kb = w.tkey_b, *va = w.tval_a, *vb = w.tval_b;
-    int shift = 0;
-    for (int pass = 0; pass < passes; ++pass) {
-        const int dbits = (bits - shift + (passes - pass) - 1) / (passes - pass);   // 13 bits -> 7 + 6
-        const bool last = pass == passes - 1;
-        uint32_t *vout = last ? (uint32_t *)a->flatten_ids : vb;
-        radix_pass(stream, ka, va, kb, vout, w.total, cap, shift, dbits, w.tab_i, w.totals, w.nb_i,
-                   last ? a->tile_offsets : nullptr);
-        shift += dbits;
-        uint32_t *t = ka; ka = kb; kb = t;
-        t = va; va = vb; vb = t;
-    }
-    hipLaunchKernelGGL(tile_offsets_fill_kernel, dim3(1), dim3(TO_THREADS), 0, stream, n_tiles, a->tile_offsets);
+    if (n_tiles <= 0x10000) emit_and_sort<uint16_t>(stream, a, w, tw, th, n_tiles, cap);
+    else emit_and_sort<uint32_t>(stream, a, w, tw, th, n_tiles, cap);
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;
 }
