@@ -24,8 +24,12 @@
 namespace {
 
 constexpr int RS_THREADS = 256;                  // 4 waves per workgroup
-constexpr int RS_ITEMS = 16;                     // keys per lane per pass
-constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
+constexpr int RS_ITEMS_I = 16;                   // keys per lane in the I-sized tile passes: 4096 per workgroup
+#ifndef DNS_RS_ITEMS_N
+#define DNS_RS_ITEMS_N 8
+#endif
+constexpr int RS_ITEMS_N = DNS_RS_ITEMS_N;                    // ... in the N-sized depth passes: 1 M keys are only 245 chunks of 4096, less than
+                                                 // one workgroup per CU and a 16-round ranking chain each; 2048-key chunks fill the chip (measured best of 2/4/8/16)
 constexpr int RS_WAVES = RS_THREADS / DNS_WAVE;
 constexpr int RS_DIGITS = 256;
 
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256) void depth_keys_kernel(int N, const int32_t *_
 // 2. one LSD radix pass = histogram, per-digit scan, stable scatter
 // K = key type: uint32_t for the depth keys, uint16_t for tile ids (any image up to 65536 tiles), which halves the
 // key traffic of the two I-sized passes.
-template <typename K>
+template <typename K, int ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const K *__restrict__ keys,
                                                                 const uint32_t *__restrict__ n_ptr, uint32_t n_cap,
                                                                 int shift, uint32_t mask, uint32_t *__restrict__ table,
@@ -95,10 +99,10 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const K *__restr
     const uint32_t n = min(*n_ptr, n_cap);
     hist[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * RS_CHUNK;
+    const uint32_t base = blockIdx.x * (RS_THREADS * ITEMS);
     if (base < n) {
 #pragma unroll
-        for (int i = 0; i < RS_ITEMS; ++i) {
+        for (int i = 0; i < ITEMS; ++i) {
             uint32_t idx = base + i * RS_THREADS + threadIdx.x;
             if (idx < n) atomicAdd(&hist[((uint32_t)keys[idx] >> shift) & mask], 1u);
         }
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(SC_THREADS) void radix_scan_kernel(uint32_t *__rest
 // a tile's entries start is.  Inside one digit's run of the LDS-sorted chunk the keys are non-decreasing (the stream
 // was already sorted on the lower bits and the pass is stable), so "key differs from its left neighbour" marks the
 // chunk-local first entry of a tile; the minimum of those positions over the chunks is the tile's offset.
-template <typename K, bool LAST, int DBITS>
+template <typename K, bool LAST, int DBITS, int ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ n_ptr, uint32_t n_cap, int shift,
@@ -158,14 +162,15 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     __shared__ uint32_t wave_loc[RS_WAVES][RS_DIGITS];   // chunk-local position of a (wave, digit) run
     __shared__ uint32_t dstart[RS_DIGITS];               // chunk-local start of a digit's run
     __shared__ uint32_t gbase[RS_DIGITS];                // global start of this chunk's run of a digit
-    __shared__ K keys_s[RS_CHUNK];
-    __shared__ uint32_t vals_s[RS_CHUNK];
+    constexpr int CHUNK = RS_THREADS * ITEMS;
+    __shared__ K keys_s[CHUNK];
+    __shared__ uint32_t vals_s[CHUNK];
     __shared__ uint32_t lds_wave[4];
     constexpr uint32_t DMASK = (1u << DBITS) - 1u;
     const uint32_t n = min(*n_ptr, n_cap);
-    const uint32_t base = blockIdx.x * RS_CHUNK;
+    const uint32_t base = blockIdx.x * CHUNK;
     if (base >= n) return;
-    const uint32_t n_valid = min((uint32_t)RS_CHUNK, n - base);
+    const uint32_t n_valid = min((uint32_t)CHUNK, n - base);
     const int w = threadIdx.x / DNS_WAVE;
     const uint32_t lane = lane_id();
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -174,10 +179,10 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     for (int i = 0; i < RS_WAVES; ++i) wave_cnt[i][threadIdx.x] = 0;
     __syncthreads();
 
-    uint32_t key[RS_ITEMS], val[RS_ITEMS], rnk[RS_ITEMS];
-    const uint32_t wave_start = base + w * (DNS_WAVE * RS_ITEMS);
+    uint32_t key[ITEMS], val[ITEMS], rnk[ITEMS];
+    const uint32_t wave_start = base + w * (DNS_WAVE * ITEMS);
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const uint32_t idx = wave_start + r * DNS_WAVE + lane;
         const bool valid = idx < n;
         key[r] = valid ? (uint32_t)keys_in[idx] : 0u;
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const uint32_t idx = wave_start + r * DNS_WAVE + lane;
         if (idx < n) {
             const uint32_t d = (key[r] >> shift) & DMASK;
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const uint32_t i = r * RS_THREADS + threadIdx.x;
         if (i < n_valid) {
             const uint32_t k = keys_s[i];
@@ -420,8 +425,8 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 BinWs carve(void *ws, int N, int64_t cap)
 {
     BinWs b{};
-    b.nb_n = (N + RS_CHUNK - 1) / RS_CHUNK;
-    b.nb_i = (int)((cap + RS_CHUNK - 1) / RS_CHUNK);
+    b.nb_n = (N + RS_THREADS * RS_ITEMS_N - 1) / (RS_THREADS * RS_ITEMS_N);
+    b.nb_i = (int)((cap + RS_THREADS * RS_ITEMS_I - 1) / (RS_THREADS * RS_ITEMS_I));
     b.nb_scan = (N + SC_CHUNK - 1) / SC_CHUNK;
     if (b.nb_n < 1) b.nb_n = 1;
     if (b.nb_i < 1) b.nb_i = 1;
@@ -450,20 +455,20 @@ BinWs carve(void *ws, int N, int64_t cap)
 int tile_bits(int n_tiles);
 
 // one LSD pass over `dbits` bits at `shift`; tile_first != nullptr marks the last pass of the tile sort
-template <typename K>
+template <typename K, int ITEMS>
 void radix_pass(hipStream_t stream, const K *ka, const uint32_t *va, K *kb, uint32_t *vb, const uint32_t *n_ptr,
                 uint32_t n_cap, int shift, int dbits, uint32_t *table, uint32_t *totals, int nb, int32_t *tile_first = nullptr)
 {
     const uint32_t mask = (1u << dbits) - 1u;
-    hipLaunchKernelGGL(radix_hist_kernel<K>, dim3(nb), dim3(RS_THREADS), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb);
+    hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb);
     hipLaunchKernelGGL(radix_scan_kernel, dim3(1 << dbits), dim3(SC_THREADS), 0, stream, table, nb, totals);
 #define DNS_SCATTER(B)                                                                                                      \
     do {                                                                                                                    \
         if (tile_first)                                                                                                     \
-            hipLaunchKernelGGL((radix_scatter_kernel<K, true, B>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb,   \
+            hipLaunchKernelGGL((radix_scatter_kernel<K, true, B, ITEMS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb,   \
                                n_ptr, n_cap, shift, table, totals, nb, tile_first);                                         \
         else                                                                                                                \
-            hipLaunchKernelGGL((radix_scatter_kernel<K, false, B>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb,  \
+            hipLaunchKernelGGL((radix_scatter_kernel<K, false, B, ITEMS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb,  \
                                n_ptr, n_cap, shift, table, totals, nb, tile_first);                                         \
     } while (0)
     switch (dbits) {
@@ -496,7 +501,7 @@ void emit_and_sort(hipStream_t stream, const dnsplat_bin_args *a, const BinWs &w
         const int dbits = (bits - shift + (passes - pass) - 1) / (passes - pass);   // 13 bits -> 7 + 6
         const bool last = pass == passes - 1;
         uint32_t *vout = last ? (uint32_t *)a->flatten_ids : vb;
-        radix_pass<K>(stream, ka, va, kb, vout, w.total, cap, shift, dbits, w.tab_i, w.totals, w.nb_i,
+        radix_pass<K, RS_ITEMS_I>(stream, ka, va, kb, vout, w.total, cap, shift, dbits, w.tab_i, w.totals, w.nb_i,
                       last ? a->tile_offsets : nullptr);
         shift += dbits;
         K *t = ka; ka = kb; kb = t;
@@ -550,7 +555,7 @@ extern "C" int dnsplat_bin_prepare(const dnsplat_bin_args *a, dnsplat_stream_t s
         uint32_t *ka = w.key_a, *kb = w.key_b, *va = w.val_a, *vb = w.val_b;
         for (int pass = 0; pass < 4; ++pass) {
             const int shift = 8 * pass;
-            radix_pass<uint32_t>(stream, ka, va, kb, vb, w.n_gauss, n_u32, shift, 8, w.tab_n, w.totals, w.nb_n);
+            radix_pass<uint32_t, RS_ITEMS_N>(stream, ka, va, kb, vb, w.n_gauss, n_u32, shift, 8, w.tab_n, w.totals, w.nb_n);
             uint32_t *t = ka; ka = kb; kb = t;
             t = va; va = vb; vb = t;
         }
