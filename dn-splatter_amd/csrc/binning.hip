@@ -311,9 +311,11 @@ __global__ __launch_bounds__(SC_THREADS) void scan_final_kernel(int N, const uin
 }
 
 // ------------------------------------------------------------------------------------------------
-// 4. emission in depth order.  One wave owns 64 consecutive sorted Gaussians; for each one that hits
-// tiles, the 64 lanes write its (tile, gaussian) pairs side by side (row-major over its tile bbox,
-// the reference's emission order).
+// 4. emission in depth order.  One wave owns 64 consecutive sorted Gaussians; those that hit tiles are taken two at
+// a time, each half of the wave writing one Gaussian's (tile, gaussian) pairs side by side (row-major over its tile
+// bbox, the reference's emission order).  The kernel is instruction-bound (a visible Gaussian covers ~30 tiles, less
+// than a wave), hence two per round and a float reciprocal instead of the integer division for (row, column):
+// floor((t + 0.5) / bw) is exact in fp32 for t < 2^16 tiles and bw <= 256 tile columns, far inside the 0.5 / bw margin.
 template <typename K>
 __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__restrict__ order,
                                                    const uint32_t *__restrict__ cum,
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__rest
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = lane_id();
     uint32_t gid = 0, end = 0, start = 0;
-    int x0 = 0, y0 = 0, bw = 0;
+    int x0 = 0, y0 = 0, bw = 1;
     if (j < N) {
         gid = order[j];
         end = cum[j];
@@ -335,19 +337,29 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__rest
             bw = x1 - x0;
         }
     }
+    const bool exact = tw <= 256 && tw * th <= 65536;      // the fp32 reciprocal route is exact
     uint64_t todo = __ballot(end > start);
+    const uint32_t half = lane >> 5, hl = lane & 31;
     while (todo) {
-        const int src = __ffsll((unsigned long long)todo) - 1;
+        const int src0 = __ffsll((unsigned long long)todo) - 1;
         todo &= todo - 1;
-        const uint32_t s_gid = __shfl(gid, src, DNS_WAVE);
-        const uint32_t s_start = __shfl(start, src, DNS_WAVE);
-        const uint32_t s_cnt = __shfl(end, src, DNS_WAVE) - s_start;
-        const int s_x0 = __shfl(x0, src, DNS_WAVE), s_y0 = __shfl(y0, src, DNS_WAVE), s_bw = __shfl(bw, src, DNS_WAVE);
-        for (uint32_t t = lane; t < s_cnt; t += DNS_WAVE) {
+        int src1 = -1;
+        if (todo) { src1 = __ffsll((unsigned long long)todo) - 1; todo &= todo - 1; }
+        const int src = half ? src1 : src0;
+        const int from = src < 0 ? 0 : src;
+        const uint32_t s_gid = __shfl(gid, from, DNS_WAVE);
+        const uint32_t s_start = __shfl(start, from, DNS_WAVE);
+        const uint32_t s_cnt = src < 0 ? 0u : __shfl(end, from, DNS_WAVE) - s_start;
+        const int s_x0 = __shfl(x0, from, DNS_WAVE), s_y0 = __shfl(y0, from, DNS_WAVE), s_bw = __shfl(bw, from, DNS_WAVE);
+        const float inv_bw = 1.f / (float)s_bw;
+        for (uint32_t t = hl; t < s_cnt; t += 32) {
             const uint32_t dst = s_start + t;
             if (dst < cap) {
-                const int ty = s_y0 + (int)(t / (uint32_t)s_bw), tx = s_x0 + (int)(t % (uint32_t)s_bw);
-                tkeys[dst] = (K)(ty * tw + tx);
+                int row;
+                if (exact) row = (int)(((float)t + 0.5f) * inv_bw);
+                else row = (int)(t / (uint32_t)s_bw);
+                const int colm = (int)t - row * s_bw;
+                tkeys[dst] = (K)((s_y0 + row) * tw + s_x0 + colm);
                 tvals[dst] = s_gid;
             }
         }
