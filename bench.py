@@ -14,7 +14,10 @@ synthetic random-init Gaussians (the reference's own initialisation, BASELINE.md
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      — the dominant stage's algorithmic HBM bytes per launch / its mean HIP-event duration in the
-                  timed region, against the 8 TB/s HBM3E peak (guides/MI355X_MICROARCH.md);
+                  timed region, against the 8 TB/s HBM3E peak (guides/MI355X_MICROARCH.md).  Only that stage is
+                  bracketed with events inside the timed region (an event pair costs a ~6 us bubble on the stream);
+                  the other entries of `stages` come from PROBE_STEPS fully instrumented steps run between the
+                  warm-up and the timed region;
   cpu_baseline  — the CPU oracle (a port: the reference has no CPU rasterizer and gsplat's needs CUDA) timed on
                   the host cores on a bounded crop of the same workload.
 """
@@ -43,6 +46,8 @@ WORKLOADS = {
 }
 
 OUT_KEYS = ("rgb", "depth", "normal", "accumulation")
+STAGE_NAMES = ("dnsplat_project_fwd", "binning", "dnsplat_raster_fwd", "dnsplat_raster_bwd", "dnsplat_project_bwd")
+PROBE_STEPS = 3
 SH_K = 16
 D_CH = 7
 
@@ -165,10 +170,29 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # Stage breakdown: PROBE_STEPS fully instrumented steps OUTSIDE the timed region.  Bracketing all six stages with
+    # HIP events costs ~80 us of stream time per frame (a ~6 us bubble per event pair, seen in the rocprofv3 timeline),
+    # so the timed region below only brackets the dominant stage, whose live duration the roofline figure needs.
     torch.cuda.synchronize()
+    probe = _lib.StageTimer()
+    _lib.TIMER = probe
+    for _ in range(PROBE_STEPS):
+        step()
+    torch.cuda.synchronize()
+    _lib.TIMER = None
+    pstats = probe.summary()
+
+    def stage_ms(st, name, steps):
+        if name == "binning":
+            return sum(st[k][2] for k in ("dnsplat_bin_prepare", "dnsplat_bin_emit_sort") if k in st) / max(steps, 1)
+        return st[name][1] if name in st else None
+
+    probe_ms = {name: stage_ms(pstats, name, PROBE_STEPS) for name in STAGE_NAMES}
+    dominant = max((n for n in probe_ms if probe_ms[n] is not None), key=lambda n: probe_ms[n])
+    live = ("dnsplat_bin_prepare", "dnsplat_bin_emit_sort") if dominant == "binning" else (dominant,)
     dp.barrier()
     torch.cuda.synchronize()
-    timer = _lib.StageTimer()
+    timer = _lib.StageTimer(only=live)
     _lib.TIMER = timer
     t0 = time.perf_counter()
     wire = 0
@@ -192,16 +216,12 @@ def main():
     stats = timer.summary()
     stages = {}
     sb = stage_bytes(N, Nv, I, P, T)
-    bin_ms = sum(stats[k][2] for k in ("dnsplat_bin_prepare", "dnsplat_bin_emit_sort") if k in stats) / max(args.steps, 1)
     for name, b in sb.items():
-        if name == "binning":
-            ms = bin_ms
-        elif name in stats:
-            ms = stats[name][1]
-        else:
+        ms = stage_ms(stats, name, args.steps) if name == dominant else probe_ms.get(name)
+        if ms is None:
             continue
-        stages[name] = {"ms": round(ms, 4), "alg_bytes": b, "GBps": round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
-    dominant = max(stages, key=lambda k: stages[k]["ms"])
+        stages[name] = {"ms": round(ms, 4), "alg_bytes": b, "GBps": round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                        "measured": "timed region" if name == dominant else f"{PROBE_STEPS} instrumented steps before it"}
     pmc_traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):

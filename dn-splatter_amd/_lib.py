@@ -179,8 +179,9 @@ class StageTimer:
     """Per-stage GPU time from HIP events recorded on the stream the kernels are enqueued on (torch's current
     stream — the one every dnsplat_* call receives).  Used by bench.py for the roofline figures; off by default."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.events = {}
+        self.only = set(only) if only else None   # bracket these entry points only (an event pair costs ~10 us of stream time)
 
     def add(self, name, e0, e1):
         self.events.setdefault(name, []).append((e0, e1))
@@ -200,7 +201,7 @@ TIMER = None  # set to a StageTimer to record
 def run(name: str, fn, *args) -> None:
     """Call one C-ABI entry point, raising on a non-zero code; brackets it with HIP events if TIMER is set."""
     t = TIMER
-    if t is None:
+    if t is None or (t.only is not None and name not in t.only):
         check(fn(*args), name)
         return
     e0 = torch.cuda.Event(enable_timing=True)
