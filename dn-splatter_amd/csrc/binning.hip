@@ -189,11 +189,11 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         val[r] = valid ? vals_in[idx] : 0u;
         const uint32_t d = (key[r] >> shift) & DMASK;
         // match-any by digit: DBITS ballots partition the wave into equal-digit lane sets
-        uint64_t m = __ballot(valid);
+        uint64_t m = dns_ballot(valid);
 #pragma unroll
         for (int bit = 0; bit < DBITS; ++bit) {
             const bool b = (d >> bit) & 1;
-            const uint64_t bal = __ballot(b);
+            const uint64_t bal = dns_ballot(b);
             m &= b ? bal : ~bal;
         }
         const uint32_t prior = wave_cnt[w][d];            // same address across the set -> LDS broadcast
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__rest
         }
     }
     const bool exact = tw <= 256 && tw * th <= 65536;      // the fp32 reciprocal route is exact
-    uint64_t todo = __ballot(end > start);
+    uint64_t todo = dns_ballot(end > start);
     const uint32_t half = lane >> 5, hl = lane & 31;
     while (todo) {
         const int src0 = __ffsll((unsigned long long)todo) - 1;

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
                 const float4 r0 = a.splats[(size_t)g * 4], r1 = a.splats[(size_t)g * 4 + 1];
                 keep = !dns_cull_rect(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, fx0, rxh, fy0, ryh);
             }
-            const uint64_t m = __ballot(keep);
+            const uint64_t m = dns_ballot(keep);
             if (keep) queue[qn + __popcll(m & lt_mask)] = idx;
             qn += __popcll(m);
             cursor -= DNS_WAVE;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
             //    atomic instruction covering 4 complete 64-byte records.
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                const uint64_t tmask = __ballot(half ? touched_b : touched_a) & gmask;
+                const uint64_t tmask = dns_ballot(half ? touched_b : touched_a) & gmask;
                 if (tmask == 0) continue;                                    // wave-uniform
                 const int gid = half ? gid_b : gid_a;
 #define SEL(v) (half ? (v).y : (v).x)

@@ -60,6 +60,20 @@ __device__ __forceinline__ float dn_epilogue(const FwdArgs &a, size_t pid, const
     return raw[3];
 }
 
+// lane-wise select on a wave mask held in scalar registers: mask bit set ? a : b  (sel0: b = 0)
+__device__ __forceinline__ float sel(uint64_t mask, float a, float b)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ float sel0(uint64_t mask, float a)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(a), "s"(mask));
+    return r;
+}
+
 template <int D, bool DN>
 __global__ __launch_bounds__(FWD_THREADS) void raster_fwd_kernel(FwdArgs a)
 {
@@ -85,8 +99,8 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_fwd_kernel(FwdArgs a)
     float acc0[D], acc1[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
-    int last0 = 0, last1 = 0;
-    bool done0 = !in0, done1 = !in1;
+    float last0 = 0.f, last1 = 0.f;                  // list index of the last blended splat, as raw bits (sel() moves floats)
+    uint64_t done0 = ~dns_ballot(in0), done1 = ~dns_ballot(in1);   // wave masks: pixel saturated (or outside the image)
 
     float4(*my)[4] = lds[wave];
     // pixel-centre rectangle of this wave's 16x8 half tile, for the per-splat cull test
@@ -107,12 +121,12 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_fwd_kernel(FwdArgs a)
     }
 
     for (int batch_start = range_start; batch_start < range_end; batch_start += DNS_WAVE) {
-        if (!__any(!(done0 && done1))) break;
+        if ((done0 & done1) == ~0ull) break;
         // Splats that cannot reach alpha >= 1/255 anywhere in the half tile are dropped here, once per
         // (wave, splat), instead of being rejected 128 times by the per-pixel test.
         const bool keep = (batch_start + lane < range_end) &&
                           !dns_cull_rect(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rxl, rxh, ryl, ryh);
-        uint64_t todo = __ballot(keep);
+        uint64_t todo = dns_ballot(keep);
         // stage the prefetched records (waits for the gather here) with the conic pre-scaled for exp2,
         // then start the next gather
         {
@@ -133,11 +147,19 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_fwd_kernel(FwdArgs a)
             }
         }
         __builtin_amdgcn_wave_barrier();
+        // The per-pixel predicates are kept as explicit wave masks (uint64_t in scalar registers) and combined with
+        // scalar and/or; selections take the mask as the v_cndmask operand (sel / sel0).  Written with bools, hipcc merges
+        // every predicate that is live across a branch with three scalar instructions per merge and rebuilds masks through
+        // v_cndmask + v_cmp: the loop then issued as many scalar as vector instructions and was bound by both.
+        // A kept splat nearly always hits some pixel of the strip, so the blend is unconditional (weight 0 for a skipped pair).
         while (todo) {
             const int t = __ffsll((unsigned long long)todo) - 1;
             todo &= todo - 1;
             const float4 g0 = my[t][0];  // x y na nb
             const float4 g1 = my[t][1];  // nc opac ch0 ch1
+            float4 g2, g3;
+            if (D > 2) g2 = my[t][2];
+            if (D > 6) g3 = my[t][3];
             DnsConicE q;
             q.na = g0.z; q.nb = g0.w; q.nc = g1.x;
             const float dx = g0.x - px;
@@ -146,24 +168,26 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_fwd_kernel(FwdArgs a)
             const float e1 = dns_exponent(q, dx, dy1);
             const float alpha0 = fminf((float)DNS_ALPHA_MAX, g1.y * dns_exp2(e0));
             const float alpha1 = fminf((float)DNS_ALPHA_MAX, g1.y * dns_exp2(e1));
-            bool c0 = !done0 && e0 <= 0.f && alpha0 >= (float)DNS_ALPHA_MIN;
-            bool c1 = !done1 && e1 <= 0.f && alpha1 >= (float)DNS_ALPHA_MIN;
+            const uint64_t valid0 = dns_ballot(e0 <= 0.f) & dns_ballot(alpha0 >= (float)DNS_ALPHA_MIN) & ~done0;
+            const uint64_t valid1 = dns_ballot(e1 <= 0.f) & dns_ballot(alpha1 >= (float)DNS_ALPHA_MIN) & ~done1;
             const float nT0 = T0 * (1.f - alpha0), nT1 = T1 * (1.f - alpha1);
-            if (c0 && nT0 <= (float)DNS_T_MIN) { done0 = true; c0 = false; }
-            if (c1 && nT1 <= (float)DNS_T_MIN) { done1 = true; c1 = false; }
-            if (__any(c0 || c1)) {
-                float ch[8];
-                ch[0] = g1.z; ch[1] = g1.w;
-                if (D > 2) { const float4 g2 = my[t][2]; ch[2] = g2.x; ch[3] = g2.y; ch[4] = g2.z; ch[5] = g2.w; }
-                if (D > 6) { const float4 g3 = my[t][3]; ch[6] = g3.x; ch[7] = g3.y; }
-                const float v0 = c0 ? alpha0 * T0 : 0.f;
-                const float v1 = c1 ? alpha1 * T1 : 0.f;
+            const uint64_t stop0 = valid0 & dns_ballot(nT0 <= (float)DNS_T_MIN);
+            const uint64_t stop1 = valid1 & dns_ballot(nT1 <= (float)DNS_T_MIN);
+            done0 |= stop0;
+            done1 |= stop1;
+            const uint64_t c0 = valid0 & ~stop0, c1 = valid1 & ~stop1;
+            float ch[8];
+            ch[0] = g1.z; ch[1] = g1.w;
+            if (D > 2) { ch[2] = g2.x; ch[3] = g2.y; ch[4] = g2.z; ch[5] = g2.w; }
+            if (D > 6) { ch[6] = g3.x; ch[7] = g3.y; }
+            const float v0 = sel0(c0, alpha0 * T0);
+            const float v1 = sel0(c1, alpha1 * T1);
 #pragma unroll
-                for (int k = 0; k < D; ++k) { acc0[k] += ch[k] * v0; acc1[k] += ch[k] * v1; }
-                if (c0) { T0 = nT0; last0 = batch_start + t; }
-                if (c1) { T1 = nT1; last1 = batch_start + t; }
-            }
-            if (!__any(!(done0 && done1))) break;
+            for (int k = 0; k < D; ++k) { acc0[k] += ch[k] * v0; acc1[k] += ch[k] * v1; }
+            const float idx = __int_as_float(batch_start + t);
+            T0 = sel(c0, nT0, T0); last0 = sel(c0, idx, last0);
+            T1 = sel(c1, nT1, T1); last1 = sel(c1, idx, last1);
+            if ((done0 & done1) == ~0ull) todo = 0;      // all 128 pixels saturated (not a `break`: a second loop exit makes hipcc copy every accumulator at the latch)
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -174,7 +198,7 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_fwd_kernel(FwdArgs a)
         const size_t pid = (size_t)py_i0 * a.width + px_i;
         const float al = 1.f - T0;
         a.alphas[pid] = al;
-        a.last_ids[pid] = last0;
+        a.last_ids[pid] = __float_as_int(last0);
         float raw[8];
 #pragma unroll
         for (int k = 0; k < D; ++k) {
@@ -190,7 +214,7 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_fwd_kernel(FwdArgs a)
         const size_t pid = (size_t)py_i1 * a.width + px_i;
         const float al = 1.f - T1;
         a.alphas[pid] = al;
-        a.last_ids[pid] = last1;
+        a.last_ids[pid] = __float_as_int(last1);
         float raw[8];
 #pragma unroll
         for (int k = 0; k < D; ++k) {

@@ -28,6 +28,10 @@
         if (e__ != hipSuccess) return DNSPLAT_ERR_LAUNCH;    \
     } while (0)
 
+// wave64 ballot straight from the predicate: HIP's __ballot(int) widens the bool first, and hipcc then rebuilds the mask
+// with a v_cndmask + v_cmp pair when the predicate already lives in scalar registers
+__device__ __forceinline__ uint64_t dns_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 static inline int dns_tiles_w(int width, int tile) { return (width + tile - 1) / tile; }
 static inline int dns_tiles_h(int height, int tile) { return (height + tile - 1) / tile; }
 
