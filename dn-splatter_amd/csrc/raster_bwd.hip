@@ -125,7 +125,7 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
     __shared__ int32_t queue[BUCKET + DNS_WAVE];
     __shared__ float4 flush[FLUSH_REC][4];
 
-    const int tile = dns_xcd_remap(blockIdx.x, a.n_tiles);
+    const int tile = dns_tile_of_block(blockIdx.x, a.n_tiles, a.tw);
     const int lane = threadIdx.x;
     const int range_start = a.tile_offsets[tile];
     const int range_end = a.tile_offsets[tile + 1];

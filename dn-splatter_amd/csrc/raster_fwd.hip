@@ -80,7 +80,7 @@ __global__ __launch_bounds__(FWD_THREADS) void raster_fwd_kernel(FwdArgs a)
     // one 64-record slice per wave: [wave][splat][4 x float4]
     __shared__ float4 lds[FWD_WAVES][DNS_WAVE][4];
 
-    const int tile = dns_xcd_remap(blockIdx.x, a.n_tiles);
+    const int tile = dns_tile_of_block(blockIdx.x, a.n_tiles, a.tw);
     const int wave = threadIdx.x / DNS_WAVE;
     const int lane = threadIdx.x & (DNS_WAVE - 1);
     const int tile_x = tile % a.tw, tile_y = tile / a.tw;
