@@ -274,10 +274,20 @@ def main():
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
-        print(json.dumps(res))
+    else:
+        res = None
     dp.barrier()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    if res is not None:
+        # The JSON line must be the last thing on stdout: RCCL writes its version banner through C stdio, which a pipe
+        # only sees when that buffer is flushed — after Python's own prints unless it is flushed first.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

@@ -17,7 +17,7 @@ _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "libdnsplat.so"
 CSRC_DIR = _PKG_DIR / "csrc"
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 RECORD_FLOATS = 16
 MAX_CHANNELS = 8
 
@@ -107,6 +107,7 @@ class ProjGrads(ctypes.Structure):
         ("v_shN", c_void_p), ("v_shN_stride", c_int32),
         ("v_colors", c_void_p),
         ("sh_factors", c_void_p),
+        ("sh_grads_skip", c_int32),
     ]
 
 
@@ -116,7 +117,7 @@ EXPORTS = [
     "dnsplat_project_fwd", "dnsplat_pack_splats",
     "dnsplat_bin_workspace_bytes", "dnsplat_bin_prepare", "dnsplat_bin_emit_sort", "dnsplat_bin_isect_ids",
     "dnsplat_raster_fwd", "dnsplat_raster_bwd",
-    "dnsplat_dn_depth_normals", "dnsplat_camera_prepare", "dnsplat_densify_stats", "dnsplat_dn_loss", "dnsplat_sh_grads_from_factors",
+    "dnsplat_dn_depth_normals", "dnsplat_camera_prepare", "dnsplat_densify_stats", "dnsplat_dn_loss", "dnsplat_sh_grads_from_factors", "dnsplat_sh_factors",
     "dnsplat_project_bwd",
 ]
 

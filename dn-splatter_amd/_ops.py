@@ -231,7 +231,7 @@ class _ProjectFn(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.sh_K = sh_K
         ctx.layout = "cat" if coeffs is not None else ("split" if cfg.sh_degree >= 0 else "colors")
-        ctx.save_for_backward(means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, radii)
+        ctx.save_for_backward(means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, radii, splats)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(radii, tiles)
         empty = torch.empty(0, device=dev)
@@ -242,7 +242,7 @@ class _ProjectFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_means2d, v_depths, v_conics, v_comp, v_splats, _r, _t, _n):
-        means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, radii = ctx.saved_tensors
+        means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, radii, splats_fwd = ctx.saved_tensors
         cfg: ProjCfg = ctx.cfg
         N = means.shape[0]
         dev = means.device
@@ -297,8 +297,14 @@ class _ProjectFn(torch.autograd.Function):
         g.v_means, g.v_quats, g.v_scales, g.v_opacities = _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac)
         ex = SH_EXCHANGE
         if ex is not None and ctx.layout in ("cat", "split") and sh_K == 16:
-            # the coefficient-gradient tensors are handed to autograd unwritten; dp.allreduce_gradients fills them
-            g.sh_factors = _ptr(ex.begin(N, dev, cfg.sh_degree, sh_K, v_coeffs, v_sh0, v_shN))
+            # The coefficient-gradient tensors are handed to autograd unwritten; dp.allreduce_gradients fills them.  The
+            # factors come from their own small kernel so that their all-gather is already under way while the geometry
+            # gradients are computed below.
+            fac = ex.begin(N, dev, cfg.sh_degree, sh_K)
+            _lib.run("dnsplat_sh_factors", _lib.lib().dnsplat_sh_factors, N, _ptr(means), _ptr(radii), _ptr(viewmat), _ptr(splats_fwd),
+                     _ptr(v_splats), _ptr(fac), _stream())
+            ex.launch()
+            g.sh_grads_skip = 1
         _lib.run("dnsplat_project_bwd", _lib.lib().dnsplat_project_bwd, ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(fwd),
                                                   ctypes.byref(g), _stream())
         need = ctx.needs_input_grad

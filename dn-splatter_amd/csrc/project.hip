@@ -470,6 +470,9 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(BwdParams p)
     float *lN = L == SH_CAT ? lrow + 3 : lrow;
     // factor mode (multi-view data parallelism): hand out (view direction, colour gradient) instead of their outer product
     float *fact = p.g.sh_factors ? p.g.sh_factors + (size_t)g * 6 : nullptr;
+    // the coefficient gradients are produced elsewhere: from the factors written here, or (sh_grads_skip) from those
+    // dnsplat_sh_factors wrote ahead of this launch
+    const bool sh_elsewhere = p.g.sh_factors || p.g.sh_grads_skip;
     if (g < p.s.N) {
     const int nbK = (p.s.sh_degree >= 0) ? (p.s.sh_degree + 1) * (p.s.sh_degree + 1) : 0;
 
@@ -563,8 +566,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(BwdParams p)
 #pragma unroll
                 for (int i = 0; i < 3; ++i) vcol[i] = (col[i] + 0.5f >= 0.f) ? vr[REC_CH0 + i] : 0.f;
                 fcol[0] = vcol[0]; fcol[1] = vcol[1]; fcol[2] = vcol[2];
-                if (vsh0 && !fact) { vsh0[0] = bas[0] * vcol[0]; vsh0[1] = bas[0] * vcol[1]; vsh0[2] = bas[0] * vcol[2]; }
-                if (vshN && !fact) {
+                if (vsh0 && !sh_elsewhere) { vsh0[0] = bas[0] * vcol[0]; vsh0[1] = bas[0] * vcol[1]; vsh0[2] = bas[0] * vcol[2]; }
+                if (vshN && !sh_elsewhere) {
                     for (int k = 1; k < nbK; ++k) {
                         vshN[3 * (k - 1) + 0] = bas[k] * vcol[0];
                         vshN[3 * (k - 1) + 1] = bas[k] * vcol[1];
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(BwdParams p)
                 for (int i = 0; i < 3; ++i) vcol[i] = (col[i] + 0.5f >= 0.f) ? vr[REC_CH0 + i] : 0.f;
                 fcol[0] = vcol[0]; fcol[1] = vcol[1]; fcol[2] = vcol[2];
                 if (L == SH_CAT) { lrow[0] = bas[0] * vcol[0]; lrow[1] = bas[0] * vcol[1]; lrow[2] = bas[0] * vcol[2]; }
-                else if (vsh0 && !fact) { vsh0[0] = bas[0] * vcol[0]; vsh0[1] = bas[0] * vcol[1]; vsh0[2] = bas[0] * vcol[2]; }
+                else if (vsh0 && !sh_elsewhere) { vsh0[0] = bas[0] * vcol[0]; vsh0[1] = bas[0] * vcol[1]; vsh0[2] = bas[0] * vcol[2]; }
                 for (int k = 1; k < nbK; ++k) {   // read the coefficient, then overwrite it with its gradient
                     const float a0 = lN[3 * (k - 1)], a1 = lN[3 * (k - 1) + 1], a2 = lN[3 * (k - 1) + 2];
                     const float s = a0 * vcol[0] + a1 * vcol[1] + a2 * vcol[2];
@@ -730,7 +733,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(BwdParams p)
     p.g.v_scales[3 * g] = v_scale[0]; p.g.v_scales[3 * g + 1] = v_scale[1]; p.g.v_scales[3 * g + 2] = v_scale[2];
     p.g.v_opacities[g] = v_opac;
     }  // g < N
-    if (L != SH_DIRECT && !p.g.sh_factors) {
+    if (L != SH_DIRECT && !(p.g.sh_factors || p.g.sh_grads_skip)) {
         __syncthreads();
         float *base = (L == SH_CAT ? p.g.v_sh0 : p.g.v_shN) + (size_t)g0 * ShRowTraits<L>::ROW;
         sh_stage_out<L>(base, nG * ShRowTraits<L>::ROW, sh_lds);
@@ -893,6 +896,51 @@ extern "C" int dnsplat_project_bwd(const dnsplat_scene *scene, const dnsplat_cam
         case SH_CAT: hipLaunchKernelGGL(project_bwd_kernel<SH_CAT>, grid, block, 0, (hipStream_t)stream, p); break;
         default: hipLaunchKernelGGL(project_bwd_kernel<SH_DIRECT>, grid, block, 0, (hipStream_t)stream, p);
     }
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}
+
+namespace {
+// The two factors of the SH-coefficient gradient alone (what project_bwd_kernel writes to sh_factors), from the forward's
+// records: the clamp mask is "the clamped colour in the record is positive".
+__global__ __launch_bounds__(256) void sh_factors_kernel(int N, const float *__restrict__ means, const int32_t *__restrict__ radii,
+                                                         const float *__restrict__ viewmat, const float *__restrict__ splats,
+                                                         const float *__restrict__ v_splats, float *__restrict__ factors)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (radii[g] > 0) {
+        float Rv[9], t[3], pos[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Rv[3 * i + j] = viewmat[4 * i + j];
+            t[i] = viewmat[4 * i + 3];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pos[i] = -(Rv[0 + i] * t[0] + Rv[3 + i] * t[1] + Rv[6 + i] * t[2]);
+        float dx = means[3 * g] - pos[0], dy = means[3 * g + 1] - pos[1], dz = means[3 * g + 2] - pos[2];
+        const float inorm = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+        f[0] = dx * inorm; f[1] = dy * inorm; f[2] = dz * inorm;
+        const float *rec = splats + (size_t)g * DNS_REC + REC_CH0;
+        const float *vr = v_splats + (size_t)g * DNS_REC + REC_CH0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) f[3 + i] = rec[i] > 0.f ? vr[i] : 0.f;
+    }
+    float2 *out = reinterpret_cast<float2 *>(factors + (size_t)g * 6);
+    out[0] = make_float2(f[0], f[1]); out[1] = make_float2(f[2], f[3]); out[2] = make_float2(f[4], f[5]);
+}
+}  // namespace
+
+extern "C" int dnsplat_sh_factors(int32_t N, const float *means, const int32_t *radii, const float *viewmat, const float *splats,
+                                  const float *v_splats, float *factors, dnsplat_stream_t stream)
+{
+    if (N < 0) return DNSPLAT_ERR_INVALID_ARG;
+    if (N == 0) return DNSPLAT_OK;
+    if (!means || !radii || !viewmat || !splats || !v_splats || !factors) return DNSPLAT_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(sh_factors_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, means, radii, viewmat, splats,
+                       v_splats, factors);
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;
 }

@@ -85,33 +85,53 @@ class ShFactorExchange:
         self.mine: Optional[Tensor] = None
         self.gathered: Optional[Tensor] = None
         self.meta = None
+        self.work = None      # the all-gather in flight (launch())
 
-    def begin(self, N, device, sh_degree, sh_K, v_coeffs, v_sh0, v_shN) -> Tensor:
-        """Called by the projection backward: returns the [N,6] buffer it must fill, remembers where the rebuilt
-        gradients go."""
+    def begin(self, N, device, sh_degree, sh_K, v_coeffs=None, v_sh0=None, v_shN=None) -> Tensor:
+        """Called by the projection backward: returns the [N,6] buffer the factors go to and remembers the shape of the
+        gradients to rebuild."""
         if self.mine is None or self.mine.shape[0] != N or self.mine.device != device:
             self.mine = torch.empty(N, 6, dtype=torch.float32, device=device)
         # no tensor references are kept here: autograd only adopts the returned gradient tensors as .grad (instead of
         # cloning them) while nobody else holds them
         self.meta = (N, sh_degree, sh_K)
+        self.work = None
         return self.mine
+
+    def _gather_buffer(self, w: int) -> Tensor:
+        N = self.meta[0]
+        if self.gathered is None or self.gathered.shape != (w, N, 6) or self.gathered.device != self.mine.device:
+            self.gathered = torch.empty(w, N, 6, dtype=torch.float32, device=self.mine.device)
+        return self.gathered
+
+    def launch(self, group=None) -> None:
+        """Start the all-gather of the factors (enqueued after whatever filled ``mine`` on the current stream) without
+        waiting for it: the projection backward calls this right after ``dnsplat_sh_factors`` and BEFORE
+        ``dnsplat_project_bwd``, so the 24 B/Gaussian travel while the geometry gradients are computed."""
+        if self.meta is None or not _collectives_on(group):
+            return
+        buf = self._gather_buffer(world_size(group))
+        self.work = dist.all_gather_into_tensor(buf.view(-1), self.mine.view(-1), group=group, async_op=True)
 
     def finish(self, group=None, v_coeffs: Optional[Tensor] = None, v_sh0: Optional[Tensor] = None,
                v_shN: Optional[Tensor] = None) -> int:
-        """All-gather the factors and rebuild the averaged coefficient gradients into the given ``.grad`` tensors
-        (``v_coeffs`` [N,16,3], or ``v_sh0`` [N,3] + ``v_shN`` [N,15,3]).  Returns the bytes received."""
+        """Complete the all-gather (or run it, if launch() was not called) and rebuild the averaged coefficient gradients
+        into the given ``.grad`` tensors (``v_coeffs`` [N,16,3], or ``v_sh0`` [N,3] + ``v_shN`` [N,15,3]).  Returns the
+        bytes received."""
         if self.meta is None:
             return 0
         N, sh_degree, sh_K = self.meta
-        self.meta = None
         w = world_size(group)
-        if self.gathered is None or self.gathered.shape != (w, N, 6) or self.gathered.device != self.mine.device:
-            self.gathered = torch.empty(w, N, 6, dtype=torch.float32, device=self.mine.device)
-        if w > 1 or _collectives_on(group):
-            dist.all_gather_into_tensor(self.gathered.view(-1), self.mine.view(-1), group=group)
+        buf = self._gather_buffer(w)
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        elif w > 1 or _collectives_on(group):
+            dist.all_gather_into_tensor(buf.view(-1), self.mine.view(-1), group=group)
         else:
-            self.gathered.copy_(self.mine[None])
-        self._rebuild(self.gathered, N, w, sh_degree, sh_K, v_coeffs, v_sh0, v_shN)
+            buf.copy_(self.mine[None])
+        self.meta = None
+        self._rebuild(buf, N, w, sh_degree, sh_K, v_coeffs, v_sh0, v_shN)
         return (w - 1) * N * 24
 
 
@@ -164,14 +184,31 @@ def _collectives_on(group=None) -> bool:
     return dist.get_world_size(group) > 1 or os.environ.get("DNSPLAT_FORCE_DIST", "0") == "1"
 
 
+class _MeanWork:
+    """Handle of an in-place mean over ranks: ``wait()`` completes it (RCCL averages natively; gloo sums and is scaled
+    here)."""
+
+    def __init__(self, work, t: Optional[Tensor], scale: float):
+        self.work, self.t, self.scale = work, t, scale
+
+    def wait(self) -> None:
+        if self.work is not None:
+            self.work.wait()
+        if self.t is not None:
+            self.t.mul_(self.scale)
+
+
 def allreduce_mean_(t: Tensor, group=None, async_op: bool = False):
-    """In-place mean over ranks.  RCCL has a native AVG; gloo sums and we scale."""
+    """In-place mean over ranks.  With ``async_op`` the collective is only enqueued; call ``wait()`` on the result."""
     w = world_size(group)
     if not _collectives_on(group):
-        return None
+        return _MeanWork(None, None, 1.0) if async_op else None
     if t.is_cuda:
-        return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
-    work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=False)
+        work = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
+        return _MeanWork(work, None, 1.0) if async_op else work
+    work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    if async_op:
+        return _MeanWork(work, t, 1.0 / w)
     t.mul_(1.0 / w)
     return work
 
@@ -187,8 +224,12 @@ def allreduce_gradients(params: Dict[str, Tensor], arena: Optional[GradArena] = 
         if arena is None or not all(arena.holds(params[k].grad) for k in GEOMETRY_KEYS):
             raise RuntimeError("the SH factor exchange needs the gradients in a GradArena (dp.GradArena + set_grad_arena)")
         n_geo = sum(arena.slices[k][1] for k in GEOMETRY_KEYS)
-        allreduce_mean_(arena.flat[:n_geo], group)
-        return n_geo * 4 + exchange.finish(group, v_sh0=params["features_dc"].grad, v_shN=params["features_rest"].grad)
+        # the geometry all-reduce is queued behind the factor all-gather on the communication stream and runs while the
+        # SH rows are rebuilt from the gathered factors on the compute stream
+        geo = allreduce_mean_(arena.flat[:n_geo], group, async_op=True)
+        got = exchange.finish(group, v_sh0=params["features_dc"].grad, v_shN=params["features_rest"].grad)
+        geo.wait()
+        return n_geo * 4 + got
     if not _collectives_on(group):
         return 0
     grads = [params[k].grad for k in GRAD_KEYS]

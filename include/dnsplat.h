@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DNSPLAT_ABI_VERSION 3
+#define DNSPLAT_ABI_VERSION 4
 #define DNSPLAT_RECORD_FLOATS 16
 #define DNSPLAT_MAX_CHANNELS 8
 
@@ -226,6 +226,14 @@ int dnsplat_sh_grads_from_factors(int32_t N, int32_t n_views, const float *facto
                                   float scale, float *v_sh0, int32_t v_sh0_stride, float *v_shN, int32_t v_shN_stride,
                                   dnsplat_stream_t stream);
 
+/* The same factors [N,6] without the rest of the projection backward, from the forward's outputs (means, radii, viewmat
+ * of dnsplat_camera, splats = dnsplat_proj_out.splats) and the gradient records of dnsplat_raster_bwd.  Lets the host start
+ * the all-gather of the factors BEFORE dnsplat_project_bwd (then called with sh_grads_skip = 1), so that the exchange runs
+ * while the geometry gradients are still being computed.  Agrees with the sh_factors output of dnsplat_project_bwd except
+ * for a colour that sits exactly on the clamp (c + 0.5 == 0), which this kernel masks. */
+int dnsplat_sh_factors(int32_t N, const float *means, const int32_t *radii, const float *viewmat, const float *splats,
+                       const float *v_splats, float *factors, dnsplat_stream_t stream);
+
 /* Densification statistics: the per-step accumulation nerfstudio's SplatfactoModel.after_train
  * performs on the renderer's outputs (called at dn_model.py:938-942, consumed by refinement_after dn_model.py:286-296):
  * for every Gaussian with radii > 0
@@ -282,6 +290,8 @@ typedef struct dnsplat_proj_grads {
     float *sh_factors;           /* optional [N,6]: when non-NULL the SH coefficient gradients are NOT written; instead the
                                     two factors of their outer product are: unit view direction (3) and the clamp-masked
                                     colour gradient (3); zeros for culled Gaussians.  See dnsplat_sh_grads_from_factors. */
+    int32_t sh_grads_skip;       /* non-zero: neither the SH coefficient gradients nor the factors are written — the caller
+                                    took the factors from dnsplat_sh_factors before this launch (sh_factors must be NULL) */
 } dnsplat_proj_grads;
 
 int dnsplat_project_bwd(const dnsplat_scene *scene, const dnsplat_camera *cam,

@@ -114,6 +114,19 @@ def _worker(rank, world, port, ret):
     dist.all_reduce(allc, op=dist.ReduceOp.SUM)
     assert torch.allclose(allc[:, 1:] / world, fpar["features_rest"].grad, atol=1e-5)
     assert torch.allclose(allc[:, 0] / world, fpar["features_dc"].grad, atol=1e-5)
+    # the same through the early launch: the all-gather is started before the geometry gradients exist (what the projection
+    # backward does right after dnsplat_sh_factors) and completed inside allreduce_gradients
+    want_dc, want_rest = fpar["features_dc"].grad.clone(), fpar["features_rest"].grad.clone()
+    mine = ex.begin(n_g, torch.device("cpu"), 3, 16)
+    mine.copy_(torch.cat([dirs, cols], 1))
+    ex.launch()
+    assert ex.work is not None
+    for k in dp.GEOMETRY_KEYS:
+        fpar[k].grad.fill_(float(rank))
+    fpar["features_dc"].grad.zero_(); fpar["features_rest"].grad.zero_()
+    assert dp.allreduce_gradients(fpar, far, exchange=ex) == got_bytes and ex.work is None
+    assert torch.allclose(fpar["means"].grad, torch.full((n_g, 3), (world - 1) / 2))
+    assert torch.equal(fpar["features_dc"].grad, want_dc) and torch.equal(fpar["features_rest"].grad, want_rest)
 
     # densification statistics: sums over the step's increments, max over ranks (densify.py)
     from dn_splatter_amd.densify import DensifyStats
