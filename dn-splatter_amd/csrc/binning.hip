@@ -349,7 +349,10 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__rest
         const int from = src < 0 ? 0 : src;
         const uint32_t s_gid = __shfl(gid, from, DNS_WAVE);
         const uint32_t s_start = __shfl(start, from, DNS_WAVE);
-        const uint32_t s_cnt = src < 0 ? 0u : __shfl(end, from, DNS_WAVE) - s_start;
+        // every shuffle is executed by the whole wave: under a lane-dependent branch the lanes that skip it are inactive
+        // SOURCES as well, and ds_bpermute returns 0 for them
+        const uint32_t s_end = __shfl(end, from, DNS_WAVE);
+        const uint32_t s_cnt = src < 0 ? 0u : s_end - s_start;
         const int s_x0 = __shfl(x0, from, DNS_WAVE), s_y0 = __shfl(y0, from, DNS_WAVE), s_bw = __shfl(bw, from, DNS_WAVE);
         const float inv_bw = 1.f / (float)s_bw;
         for (uint32_t t = hl; t < s_cnt; t += 32) {

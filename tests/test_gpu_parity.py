@@ -503,6 +503,25 @@ def test_sh_factor_exchange_rebuilds_the_multi_camera_gradient(dns, layout):
         assert_close(sh_1.grad, dense[0][1].grad, "single-rank exchange", 1e-6)
 
 
+def test_small_frame_stays_in_the_millisecond_range(dns):
+    """Regression guard.  A wave shuffle placed under a lane-dependent branch once made the emit kernel read a neighbour's
+    count as 0 and spin through 2^32 / 32 guarded iterations: every result stayed bit-exact, but a 320 x 240 frame (300
+    tiles: the smallest two-pass tile sort) took 5.6 s.  Parity tests do not notice that; this one does."""
+    import time
+
+    inp, viewmat, K, _ = gsplat_inputs(20_000, 320, 240, focal=200.0, seed=0)
+    gi = to_leaf(inp, DEV)
+    for it in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r, a, _info = dns.rasterization(**gi, viewmats=viewmat.to(DEV), Ks=K.to(DEV), width=320, height=240, packed=False,
+                                        sh_degree=3, render_mode="RGB+ED", absgrad=True)
+        (r.sum() + a.sum()).backward()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert dt < 0.25, f"fwd+bwd of a 320x240 / 20k-Gaussian frame took {dt * 1e3:.0f} ms"
+
+
 def test_capacity_policy_recovers_from_an_overflowing_guess(dns):
     """'capacity' mode sizes the intersection buffers from earlier frames and enqueues everything without a host
     round-trip; when the guess is too small the emit + composite must be redone with the exact size."""
