@@ -9,13 +9,15 @@
 //   1. the N Gaussians are stably radix-sorted once by their 32 depth bits (4 passes over N, N << I);
 //   2. (tile, gaussian) pairs are emitted in that depth order — one wave per 64 Gaussians, lanes
 //      write a Gaussian's tiles cooperatively so stores are coalesced;
-//   3. the pairs are stably radix-sorted on the tile id alone (ceil(log2(T)/8) = 2 passes over I).
+//   3. the pairs are stably radix-sorted on the tile id alone (ceil(log2(T)/8) = 2 passes over I),
+//      with 16-bit tile keys; the last pass stores no keys and yields the tile offsets on the way.
 // A stable sort by tile of a depth-ordered stream is exactly the (tile, depth, emission index)
 // order the reference's stable 64-bit sort yields, so flatten_ids / tile offsets are bit-identical
-// while the I-sized traffic drops from 6 passes x 12 B to 2 passes x 8 B.
+// while the I-sized traffic drops from 6 passes x 12 B to 2 passes x 6 B (4 B in the last one).
 //
 // All ranking inside a radix pass is done with wave64 ballots (match-by-digit) and LDS counters:
-// no atomics on the data path, fully deterministic.  Every kernel takes its element count from a
+// no atomics on the data path (the tile offsets are an atomicMin per (chunk, tile) run), fully
+// deterministic.  Every kernel takes its element count from a
 // device word, so the whole stage can be enqueued without a host round-trip on n_isects (the
 // caller bounds it with `isect_capacity`).
 

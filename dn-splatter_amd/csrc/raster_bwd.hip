@@ -8,18 +8,22 @@
 // per (warp, splat).  On a 64-wide wave that reduction (15 values x 6 DPP steps) costs more than
 // the gradient math itself.  This kernel turns the problem by 90 degrees — a wave64 SYSTOLIC pass:
 //
-//   * one wave owns one 16x16 tile; lane l owns ONE SPLAT of the current bucket of 64 (lane 0 =
-//     back-most) for the whole pass and keeps that splat's 16 partial gradients in VGPRs;
-//   * the 256 pixels stream through the lanes, back to front: at step s lane l works on pixel s-l.
-//     What travels with a pixel is only its running state (T, S_a, S_b) — three v_mov_dpp
-//     wave_shr:1 per step — where S = sum_k buffer_k * v_k collapses the reference's per-channel
-//     `buffer` into one scalar per gradient group (v_alpha = T*(c.v) - S/(1-alpha));
+//   * one wave owns one 16x16 tile; lane l owns TWO SPLATS of the current bucket of 128 (lane 0 =
+//     back-most), carried as packed fp32 pairs, and keeps their 2 x 16 partial gradients in VGPRs;
+//   * the 256 pixels stream through the lanes, back to front: one pixel per lane per step, lane l
+//     one step behind lane l-1.  What travels with a pixel is only its running state (T, S_a, S_b) —
+//     three v_mov_dpp wave_shr:1 per step — where S = sum_k buffer_k * v_k collapses the reference's
+//     per-channel `buffer` into one scalar per gradient group (v_alpha = T*(c.v) - S/(1-alpha));
 //   * per-pixel constants (upstream gradient, last contributing index) sit in a 12 KiB LDS table,
-//     read with conflict-free ds_read_b128 (48-byte stride over consecutive lanes) one step AHEAD of
-//     their use, so the LDS latency hides behind the previous step's arithmetic;
+//     read with conflict-free ds_read_b128 (48-byte stride over consecutive lanes), issued before and
+//     awaited after the row-independent arithmetic of the step;
 //   * state leaving lane 63 is parked back in the pixel's LDS row and picked up by lane 0 in the
 //     next (nearer) bucket — the arithmetic order per pixel is exactly the reference's
 //     back-to-front replay (T *= 1/(1-alpha); buffer += c*alpha*T);
+//   * the stream is CONTINUOUS over the buckets of a tile: 15 idle slots separate two buckets, which
+//     lets 16 neighbouring lanes change their splats at the same wave-uniform step (four staggered
+//     group switches per bucket) instead of draining and refilling the whole array — 271 steps per
+//     bucket instead of 256 + 63;
 //   * a splat's 16 partials are summed over all 256 pixels in registers: NO cross-lane reduction,
 //     and ONE atomic row per (tile, splat).  The flush is transposed through LDS so that each
 //     global_atomic_add_f32 instruction covers whole 64-byte gradient records (16 lanes per record).

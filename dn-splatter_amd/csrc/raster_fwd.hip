@@ -16,7 +16,9 @@
 //   * the gather for batch b+1 is issued before batch b is consumed; the loads stay in flight
 //     behind the LDS/VALU loop (vmcnt is only waited on when the registers are written to LDS).
 //   * workgroup = the two half tiles of one tile (shared L1 lines for the record gather);
-//     blockIdx -> tile goes through the XCD band remap so that tiles sharing splats share an L2.
+//   * the per-pixel predicates (alive, inside the splat's support, saturating) live as explicit wave
+//     masks in scalar registers and selections take the mask as the v_cndmask operand: written with
+//     bools the loop issued as many scalar as vector instructions and was bound by both.
 
 #include "splat_common.h"
 
