@@ -42,6 +42,8 @@
 // compile-time constant for the two shapes that occur (SPLIT == D: everything feeds xy; D == 7,
 // SPLIT == 4: the fused colour+depth | normal pass); other splits take the generic instantiation.
 
+#include <type_traits>
+
 #include "splat_common.h"
 
 namespace {
@@ -284,6 +286,7 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
         qn -= take;                           // what is left sits at [BUCKET, BUCKET + qn) until the next boundary
         const bool last = take == 0;          // nothing new: only drain what is still in the lanes
 
+#pragma nounroll
         for (int grp = 0; grp < NGROUP; ++grp) {
             if (last && 2 * GROUP * grp >= prev_take) break;          // the remaining groups hold no splats
             // ==== group switch: GROUP lanes finish their old splats together and take new ones ====================
@@ -373,6 +376,12 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
             // otherwise hipcc's wait insertion may find one of their registers overwritten in the loop and put an
             // s_waitcnt lgkmcnt(0) right behind the row loads of every step (tools/check_asm_hazards.py: "early wait").
             __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), vmcnt / expcnt untouched
+            // Two instantiations of the step loop.  alpha = min(0.999, opacity x vis) can only clamp for a splat whose
+            // opacity exceeds 0.999 (vis <= 1 for a valid pair); while no lane holds such a splat — random initialisation,
+            // most of training — the clamp, the "gradient only where not clamped" compare and one of the two selects per
+            // splat drop out of the step (alpha and its gradient weight are then the same number).
+            auto step_loop = [&](auto clamp_tag) {
+            constexpr bool CLAMP = decltype(clamp_tag)::value;
             for (int s = 0; s < nsteps; ++s) {
                 const bool active = (unsigned)p < (unsigned)NPIX;
                 int pcur = p & (NPIX - 1);
@@ -386,7 +395,8 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
                 f2 vis = {dns_exp2(e.x), dns_exp2(e.y)};
                 row_wait(c0, c1, cst, vis);
                 const f2 ov = opac * vis;
-                const float al_a = fminf((float)DNS_ALPHA_MAX, ov.x), al_b = fminf((float)DNS_ALPHA_MAX, ov.y);
+                const float al_a = CLAMP ? fminf((float)DNS_ALPHA_MAX, ov.x) : ov.x;
+                const float al_b = CLAMP ? fminf((float)DNS_ALPHA_MAX, ov.y) : ov.y;
                 // state arrives from the previous lane; lane 0 takes it from the pixel's LDS row
                 float T = dpp_wave_shr1(T_out, cst.x);
                 float SA = dpp_wave_shr1(SA_out, cst.y);
@@ -400,8 +410,9 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
                     const f2 alpha = {valid_a ? al_a : 0.f, valid_b ? al_b : 0.f};
                     // opacity x vis where the pair is valid and alpha is not clamped, else 0: the weight of d/d(sigma)
                     // and, divided by the opacity again at the flush, of d/d(opacity)
-                    const f2 ovm = {(valid_a && ov.x <= (float)DNS_ALPHA_MAX) ? ov.x : 0.f,
-                                    (valid_b && ov.y <= (float)DNS_ALPHA_MAX) ? ov.y : 0.f};
+                    const f2 ovm = CLAMP ? f2{(valid_a && ov.x <= (float)DNS_ALPHA_MAX) ? ov.x : 0.f,
+                                              (valid_b && ov.y <= (float)DNS_ALPHA_MAX) ? ov.y : 0.f}
+                                         : alpha;
                     const f2 om = 1.f - alpha;
                     const f2 ra = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
                     const float T1 = T * ra.x, T2 = T1 * ra.y;          // the pixel meets A, then B
@@ -452,6 +463,9 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
                 if (lane == DNS_WAVE - 1 && active) pix[pcur][2] = make_float4(T, SA, SB, cst.w);
                 ++p;
             }
+            };
+            if (dns_ballot(opac.x > (float)DNS_ALPHA_MAX || opac.y > (float)DNS_ALPHA_MAX) != 0ull) step_loop(std::true_type{});
+            else step_loop(std::false_type{});
         }
         if (last) break;
         prev_take = take;

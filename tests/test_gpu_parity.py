@@ -228,6 +228,41 @@ def test_edge_single_gaussian_closed_form(dns):
     assert abs(float(r[0, 32, 32, 3]) - z) < 1e-5   # expected depth = z*alpha/alpha
 
 
+def test_saturated_opacities_take_the_alpha_clamp(dns, orc):
+    """Opacities of 1.0 and 0.9995: alpha = min(0.999, o vis) clamps near the splat centres, where the reference passes no
+    gradient to the conic / mean / opacity through alpha.  The backward kernel has a separate instantiation of its step loop
+    for buckets that hold such splats; a quarter of the Gaussians here do, the rest keep the clamp-free loop busy."""
+    inp, viewmat, K, _ = gsplat_inputs(6000, 160, 128, focal=110.0, seed=12, anisotropic=True)
+    inp["opacities"][::4] = 1.0
+    inp["opacities"][1::8] = 0.9995
+    o, g = _call_both(dns, orc, inp, viewmat, K, 160, 128, sh_degree=3, render_mode="RGB+ED", absgrad=True)
+    clamped = (o[2]["radii"][0] > 0) & (inp["opacities"] > 0.999)
+    assert int(clamped.sum()) > 500
+    _check_forward(o, g, flips=FLIP_FRACTION)
+    _check_backward(o, g, flips=FLIP_FRACTION)
+    # and the fused 7-channel pass (the instantiation the benchmark uses)
+    from dn_splatter_amd import synthetic
+    gp = synthetic.make_gauss_params(5000, sh_rest_std=0.2, seed=13)
+    gp["opacities"] = gp["opacities"].detach().clone()
+    gp["opacities"][::3] = 12.0                                   # sigmoid(12) = 0.999994
+    cam = synthetic.orbit_camera(3, width=144, height=112, focal=100.0)
+    res = {}
+    for name, device, kw in (("hip", DEV, dict(fused=True)),
+                             ("oracle", "cpu", dict(fused=False, rasterization_fn=orc.rasterization,
+                                                    rasterize_gaussians_fn=orc.rasterize_gaussians))):
+        params = {k: v.detach().to(device).clone().requires_grad_(k != "normals") for k, v in gp.items()}
+        out = dns.DNSplatterRenderer(params, **kw).get_outputs(cam.to(device))
+        gen = torch.Generator().manual_seed(4)
+        keys = ("rgb", "depth", "normal", "accumulation")
+        torch.autograd.backward([out[k] for k in keys], [(torch.rand(out[k].shape, generator=gen) * 2 - 1).to(device) for k in keys])
+        res[name] = (out, params)
+    torch.cuda.synchronize()
+    for k in ("rgb", "depth", "normal", "accumulation"):
+        assert_close(res["hip"][0][k], res["oracle"][0][k], "clamped fused " + k, flips=FLIP_FRACTION)
+    for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities"):
+        assert_close(res["hip"][1][k].grad, res["oracle"][1][k].grad, "clamped fused grad " + k, flips=FLIP_FRACTION)
+
+
 def test_occluded_and_transparent_gaussians(dns, orc):
     """T4 properties: zero-opacity Gaussians contribute nothing and get no colour gradient."""
     inp, viewmat, K, _ = gsplat_inputs(3000, 96, 80, focal=70.0, seed=11, anisotropic=True)
