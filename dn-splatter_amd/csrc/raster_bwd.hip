@@ -49,7 +49,17 @@
 namespace {
 
 constexpr int TILE = 16;
-constexpr int NPIX = TILE * TILE;
+// rows of a tile one wave owns.  A wave's speed does not depend on how many other waves share its SIMD (measured: a tile takes
+// the same ~570 us with 2816 or with 50 waves in flight), so the end of the kernel — waves draining with nothing left to start —
+// is pure loss, and it lasts about one work unit.  Half tiles make the units half as long (and the rectangle cull and the
+// per-pixel list bound tighter), at the price of 15 idle slots per 128 instead of per 256 stream steps and two atomic rows per
+// (tile, splat).
+#ifndef DNS_BWD_ROWS
+#define DNS_BWD_ROWS 8
+#endif
+constexpr int ROWS = DNS_BWD_ROWS;
+constexpr int PARTS = TILE / ROWS;              // waves (workgroups) per tile
+constexpr int NPIX = TILE * ROWS;
 constexpr int BUCKET = 2 * DNS_WAVE;   // splats in the array at a time: two per lane, processed as packed fp32 pairs
 #ifndef DNS_BWD_GROUP
 #define DNS_BWD_GROUP 16
@@ -131,12 +141,13 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
     __shared__ int32_t queue[BUCKET + DNS_WAVE];
     __shared__ float4 flush[FLUSH_REC][4];
 
-    const int tile = dns_tile_of_block(blockIdx.x, a.n_tiles, a.tw);
+    const int tile = dns_tile_of_block(blockIdx.x / PARTS, a.n_tiles, a.tw);
+    const int part = blockIdx.x % PARTS;
     const int lane = threadIdx.x;
     const int range_start = a.tile_offsets[tile];
     const int range_end = a.tile_offsets[tile + 1];
     if (range_end <= range_start) return;
-    const int tile_x0 = (tile % a.tw) * TILE, tile_y0 = (tile / a.tw) * TILE;
+    const int tile_x0 = (tile % a.tw) * TILE, tile_y0 = (tile / a.tw) * TILE + part * ROWS;
     const int split = SPLIT >= 0 ? SPLIT : a.xy_split;
 
     // ---- prologue: per-pixel table --------------------------------------------------------------
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
     __builtin_amdgcn_wave_barrier();
 
     const float fx0 = (float)tile_x0 + 0.5f, fy0 = (float)tile_y0 + 0.5f;
-    const float rxh = fx0 + 15.f, ryh = fy0 + 15.f;
+    const float rxh = fx0 + 15.f, ryh = fy0 + (float)(ROWS - 1);
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     int cursor = hi;  // next (highest) list index not yet examined
@@ -475,7 +486,7 @@ __global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
 template <int D, int SPLIT, bool DN = false>
 int launch_bwd(const BwdArgs &ba, hipStream_t stream)
 {
-    hipLaunchKernelGGL((raster_bwd_kernel<D, SPLIT, DN>), dim3(ba.n_tiles), dim3(DNS_WAVE), 0, stream, ba);
+    hipLaunchKernelGGL((raster_bwd_kernel<D, SPLIT, DN>), dim3(ba.n_tiles * PARTS), dim3(DNS_WAVE), 0, stream, ba);
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;
 }
