@@ -57,6 +57,17 @@ constexpr int TILE = 16;
 #ifndef DNS_BWD_ROWS
 #define DNS_BWD_ROWS 8
 #endif
+// Register budget.  Left alone hipcc uses ~164 VGPRs (3 waves per SIMD).  Forcing a fourth wave per SIMD
+// (amdgpu_waves_per_eu(4,4): 128 VGPRs) puts nine loop-invariant splat parameters into scratch that are re-read every step:
+// measured 1.68 -> 2.74 ms.  A fourth wave needs a step that fits 128 registers by construction.
+#ifndef DNS_BWD_WAVES_PER_EU
+#define DNS_BWD_WAVES_PER_EU 0
+#endif
+#if DNS_BWD_WAVES_PER_EU > 0
+#define DNS_BWD_OCCUPANCY __attribute__((amdgpu_waves_per_eu(DNS_BWD_WAVES_PER_EU, DNS_BWD_WAVES_PER_EU)))
+#else
+#define DNS_BWD_OCCUPANCY
+#endif
 constexpr int ROWS = DNS_BWD_ROWS;
 constexpr int PARTS = TILE / ROWS;              // waves (workgroups) per tile
 constexpr int NPIX = TILE * ROWS;
@@ -132,7 +143,7 @@ __device__ __forceinline__ float dpp_wave_shr1(float from_prev, float lane0_valu
 
 // SPLIT >= 0: compile-time split; SPLIT < 0: run-time a.xy_split
 template <int D, int SPLIT, bool DN>
-__global__ __launch_bounds__(DNS_WAVE) void raster_bwd_kernel(BwdArgs a)
+__global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(BwdArgs a)
 {
     __shared__ float4 pix[NPIX][3];            // [p][0..1] = v_k, [p][2] = (T, S_a, S_b, bin_final)
     // compacted list indices waiting for a bucket (never more than 127 + 64) + the 1 KiB staging area of the transposed flush, which
