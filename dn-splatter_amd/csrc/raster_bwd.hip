@@ -158,6 +158,12 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
     const int range_start = a.tile_offsets[tile];
     const int range_end = a.tile_offsets[tile + 1];
     if (range_end <= range_start) return;
+#ifdef DNS_BWD_TIMELINE
+    // instrumented build (tools/bwd_timeline.sh): per work unit (start, end) of the 100 MHz wall clock and the list depth, written
+    // through the v_alphas pointer, which the fused (DN) pass does not use
+    unsigned long long *dbg_tl = DN ? (unsigned long long *)a.v_alphas : nullptr;
+    const unsigned long long tl_t0 = wall_clock64();
+#endif
     const int tile_x0 = (tile % a.tw) * TILE, tile_y0 = (tile / a.tw) * TILE + part * ROWS;
     const int split = SPLIT >= 0 ? SPLIT : a.xy_split;
 
@@ -492,6 +498,13 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
         if (last) break;
         prev_take = take;
     }
+#ifdef DNS_BWD_TIMELINE
+    if (dbg_tl && lane == 0) {
+        dbg_tl[3 * blockIdx.x] = tl_t0;
+        dbg_tl[3 * blockIdx.x + 1] = wall_clock64();
+        dbg_tl[3 * blockIdx.x + 2] = (unsigned long long)(hi - range_start + 1);
+    }
+#endif
 }
 
 template <int D, int SPLIT, bool DN = false>

@@ -1,0 +1,58 @@
+"""Per-work-unit timeline of raster_bwd on the benchmark frame (instrumented build, see tools/bwd_timeline.sh):
+waves in flight over time, unit duration against its start time and its list depth.
+
+What it showed at the end of round 1: a unit takes the same time whether 2816 or 50 waves are in flight — a wave is
+bound by its own instruction latency, not by sharing its SIMD — so the drain at the end of the kernel (nothing left to
+start, waves finishing one by one) is pure loss and lasts about one unit: 20 % of the kernel with whole-tile units,
+which is why a wave now owns half a tile."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import dn_splatter_amd as dns  # noqa: E402
+from dn_splatter_amd import _lib, synthetic  # noqa: E402
+
+dev = "cuda:0"
+N, W, H, focal = 1_000_000, 1920, 1080, 1200.0
+gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=0, device=dev)
+cam = synthetic.orbit_camera(0, n_views=8, width=W, height=H, focal=focal).to(dev)
+r = dns.DNSplatterRenderer(gp, fused=True)
+units = ((W + 15) // 16) * ((H + 15) // 16) * int(os.environ.get("PARTS", "2"))
+dbg = torch.zeros(3 * units, dtype=torch.int64, device=dev)
+L = _lib.lib()
+orig = L.dnsplat_raster_bwd
+
+
+def wrapped(argp, stream):
+    argp._obj.v_alphas = dbg.data_ptr()
+    return orig(argp, stream)
+
+
+gen = torch.Generator(device=dev).manual_seed(1)
+keys = ("rgb", "depth", "normal", "accumulation")
+for it in range(3):
+    for k in gp:
+        gp[k].grad = None
+    out = r.get_outputs(cam)
+    cot = [torch.rand(out[k].shape, device=dev, generator=gen) * 2 - 1 for k in keys]
+    if it == 2:
+        L.dnsplat_raster_bwd = wrapped
+    torch.autograd.backward([out[k] for k in keys], cot)
+torch.cuda.synchronize()
+d = dbg.cpu().numpy().reshape(units, 3)
+ok = d[:, 1] > 0
+t0, t1, depth = d[ok, 0].astype(np.float64), d[ok, 1].astype(np.float64), d[ok, 2].astype(np.float64)
+base = t0.min()
+t0, t1 = (t0 - base) / 100.0, (t1 - base) / 100.0          # 100 MHz ticks -> us
+dur = t1 - t0
+print(f"units {ok.sum()}  kernel span {t1.max():.0f} us  unit duration mean {dur.mean():.0f} p10 {np.quantile(dur, 0.1):.0f} "
+      f"p90 {np.quantile(dur, 0.9):.0f} max {dur.max():.0f} us  perfectly packed: {dur.sum() / 2816:.0f}+ us")
+edges = np.linspace(0, t1.max(), 21)
+for a, b in zip(edges[:-1], edges[1:]):
+    inflight = np.clip(np.minimum(t1, b) - np.maximum(t0, a), 0, None).sum() / (b - a)
+    m = (t0 >= a) & (t0 < b)
+    print(f"{a:7.0f}-{b:7.0f} us: {inflight:6.0f} in flight, {m.sum():5d} started" + (f", their mean duration {dur[m].mean():.0f} us" if m.any() else ""))
+print("corr(duration, list depth) =", round(float(np.corrcoef(dur, depth)[0, 1]), 3))
