@@ -62,6 +62,18 @@ __device__ __forceinline__ float dn_epilogue(const FwdArgs &a, size_t pid, const
     return raw[3];
 }
 
+// Register budget: hipcc lands on 65 VGPRs, one too many for the eighth wave per SIMD.  Capped at 64 the spills stay outside
+// the per-splat loop, yet the kernel gets slower (0.573 -> 0.627 ms): unlike the backward this one is bound by vector issue, not
+// by the latency of a wave, so an eighth wave buys nothing.  DNS_FWD_WAVES_PER_EU = 0 leaves the choice to the compiler.
+#ifndef DNS_FWD_WAVES_PER_EU
+#define DNS_FWD_WAVES_PER_EU 0
+#endif
+#if DNS_FWD_WAVES_PER_EU > 0
+#define DNS_FWD_OCCUPANCY __attribute__((amdgpu_waves_per_eu(DNS_FWD_WAVES_PER_EU, DNS_FWD_WAVES_PER_EU)))
+#else
+#define DNS_FWD_OCCUPANCY
+#endif
+
 // lane-wise select on a wave mask held in scalar registers: mask bit set ? a : b  (sel0: b = 0)
 __device__ __forceinline__ float sel(uint64_t mask, float a, float b)
 {
@@ -77,7 +89,7 @@ __device__ __forceinline__ float sel0(uint64_t mask, float a)
 }
 
 template <int D, bool DN>
-__global__ __launch_bounds__(FWD_THREADS) void raster_fwd_kernel(FwdArgs a)
+__global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kernel(FwdArgs a)
 {
     // one 64-record slice per wave: [wave][splat][4 x float4]
     __shared__ float4 lds[FWD_WAVES][DNS_WAVE][4];
