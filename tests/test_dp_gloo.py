@@ -117,9 +117,21 @@ def _worker(rank, world, port, ret):
     # the same through the early launch: the all-gather is started before the geometry gradients exist (what the projection
     # backward does right after dnsplat_sh_factors) and completed inside allreduce_gradients
     want_dc, want_rest = fpar["features_dc"].grad.clone(), fpar["features_rest"].grad.clone()
-    mine = ex.begin(n_g, torch.device("cpu"), 3, 16)
-    mine.copy_(torch.cat([dirs, cols], 1))
-    ex.launch()
+    class _LaunchInBackward(torch.autograd.Function):
+        """The product starts the all-gather from inside the projection backward, i.e. on autograd's worker thread."""
+
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            mine = ex.begin(n_g, torch.device("cpu"), 3, 16)
+            mine.copy_(torch.cat([dirs, cols], 1))
+            ex.launch()
+            return g
+
+    _LaunchInBackward.apply(torch.zeros(1, requires_grad=True)).sum().backward()
     assert ex.work is not None
     for k in dp.GEOMETRY_KEYS:
         fpar[k].grad.fill_(float(rank))
