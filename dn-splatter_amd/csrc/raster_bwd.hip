@@ -49,17 +49,16 @@
 namespace {
 
 constexpr int TILE = 16;
-// rows of a tile one wave owns.  A wave's speed does not depend on how many other waves share its SIMD (measured: a tile takes
-// the same ~570 us with 2816 or with 50 waves in flight), so the end of the kernel — waves draining with nothing left to start —
-// is pure loss, and it lasts about one work unit.  Half tiles make the units half as long (and the rectangle cull and the
-// per-pixel list bound tighter), at the price of 15 idle slots per 128 instead of per 256 stream steps and two atomic rows per
-// (tile, splat).
+// rows of a tile one wave owns.  With whole tiles a work unit took ~570 us of a 2 ms launch and the last third of the launch was a
+// drain at 39 % occupancy (tools/bwd_timeline.sh): the end of the kernel lasts about one unit.  Half tiles make the units half as
+// long (and the rectangle cull and the per-pixel list bound tighter), at the price of 15 idle slots per 128 instead of per 256
+// stream steps and two atomic rows per (tile, splat).
 #ifndef DNS_BWD_ROWS
 #define DNS_BWD_ROWS 8
 #endif
-// Register budget.  Left alone hipcc uses ~164 VGPRs (3 waves per SIMD).  Forcing a fourth wave per SIMD
-// (amdgpu_waves_per_eu(4,4): 128 VGPRs) puts nine loop-invariant splat parameters into scratch that are re-read every step:
-// measured 1.68 -> 2.74 ms.  A fourth wave needs a step that fits 128 registers by construction.
+// Register budget.  Left alone hipcc uses ~164 VGPRs (3 waves per SIMD), which already keep the SIMDs 95 % busy (PMC).  Forcing a
+// fourth wave per SIMD (amdgpu_waves_per_eu(4,4): 128 VGPRs) puts nine loop-invariant splat parameters into scratch that are
+// re-read every step: measured 1.68 -> 2.74 ms.
 #ifndef DNS_BWD_WAVES_PER_EU
 #define DNS_BWD_WAVES_PER_EU 0
 #endif

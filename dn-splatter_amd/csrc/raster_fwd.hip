@@ -63,8 +63,8 @@ __device__ __forceinline__ float dn_epilogue(const FwdArgs &a, size_t pid, const
 }
 
 // Register budget: hipcc lands on 65 VGPRs, one too many for the eighth wave per SIMD.  Capped at 64 the spills stay outside
-// the per-splat loop, yet the kernel gets slower (0.573 -> 0.627 ms): unlike the backward this one is bound by vector issue, not
-// by the latency of a wave, so an eighth wave buys nothing.  DNS_FWD_WAVES_PER_EU = 0 leaves the choice to the compiler.
+// the per-splat loop, yet the kernel gets slower (0.573 -> 0.627 ms): the SIMDs are 98 % busy with seven waves (PMC), an eighth
+// buys nothing.  DNS_FWD_WAVES_PER_EU = 0 leaves the choice to the compiler.
 #ifndef DNS_FWD_WAVES_PER_EU
 #define DNS_FWD_WAVES_PER_EU 0
 #endif

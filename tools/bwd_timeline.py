@@ -1,10 +1,9 @@
 """Per-work-unit timeline of raster_bwd on the benchmark frame (instrumented build, see tools/bwd_timeline.sh):
 waves in flight over time, unit duration against its start time and its list depth.
 
-What it showed at the end of round 1: a unit takes the same time whether 2816 or 50 waves are in flight — a wave is
-bound by its own instruction latency, not by sharing its SIMD — so the drain at the end of the kernel (nothing left to
-start, waves finishing one by one) is pure loss and lasts about one unit: 20 % of the kernel with whole-tile units,
-which is why a wave now owns half a tile."""
+What it showed at the end of round 1: with whole-tile units the chip stayed full for 1.4 ms and then drained for 0.66 ms at
+39 % occupancy (units take ~570 us and do not speed up much while their SIMDs empty), 20 % of the launch — which is why a wave
+now owns half a tile.  Read it together with the PMC pass (SIMDs 95 % busy with vector instructions while the chip is full)."""
 import os
 import sys
 
