@@ -133,6 +133,13 @@ __device__ __forceinline__ void row_wait(v4f &r0, v4f &r1, v4f &r2, f2 &done)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(done) : : "memory");
 }
 
+// acc += a * (b.x or b.y broadcast to both halves): v_pk_fma_f32 with op_sel picking one half of the b pair
+__device__ __forceinline__ void pk_fma_bcast(f2 &acc, f2 a, f2 b, int hi)
+{
+    if (hi) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(a), "v"(b));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(b));
+}
+
 __device__ __forceinline__ float dpp_wave_shr1(float from_prev, float lane0_value)
 {
     // lane l receives `from_prev` of lane l-1; lane 0 (no source) keeps `lane0_value`
@@ -454,9 +461,9 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
                     for (int k = 0; k < D; ++k) {
                         const f2 vk = (k & 1) ? __builtin_shufflevector(pp[k >> 1], pp[k >> 1], 1, 1)
                                               : __builtin_shufflevector(pp[k >> 1], pp[k >> 1], 0, 0);
-                        // two plain v_fmac: hipcc would materialise the broadcast pair for a packed FMA here
-                        g_ch[k].x = __builtin_fmaf(fac.x, vk.x, g_ch[k].x);
-                        g_ch[k].y = __builtin_fmaf(fac.y, vk.y, g_ch[k].y);
+                        // one packed FMA with the cotangent broadcast by operand selection (hipcc would copy the
+                        // broadcast pair into registers first, hence the inline instruction)
+                        pk_fma_bcast(g_ch[k], fac, pp[k >> 1], k & 1);
                         if (k < split) cva = __builtin_elementwise_fma(ch[k], vk, cva);
                         else cvb = __builtin_elementwise_fma(ch[k], vk, cvb);
                     }
