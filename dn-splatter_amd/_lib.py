@@ -165,6 +165,10 @@ def lib() -> ctypes.CDLL:
         L.dnsplat_dn_loss.argtypes = [ctypes.POINTER(DnLossArgs), c_void_p]
         L.dnsplat_camera_prepare.argtypes = [c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                              c_void_p]
+        L.dnsplat_sh_factors.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        for name in EXPORTS:
+            if name not in ("dnsplat_strerror", "dnsplat_bin_workspace_bytes"):
+                getattr(L, name).restype = ctypes.c_int
         if L.dnsplat_abi_version() != ABI_VERSION:
             raise DnsplatError(f"libdnsplat ABI {L.dnsplat_abi_version()} != binding {ABI_VERSION}; rebuild")
         _lib = L

@@ -125,8 +125,12 @@ def set_sh_exchange(exchange) -> None:
 
 
 def _grad_like(param: Tensor) -> Tensor:
+    """Where stage 5 writes the gradient of ``param``: its slice of the flat bucket, unless ``param.grad`` already IS that
+    slice (zero_grad(set_to_none=False), or a second camera accumulated into the same step).  In that case autograd will
+    run ``param.grad += new``: had the kernel written into the bucket, old and new gradient would be the same memory and
+    the sum would come out as 2 x new.  A fresh tensor keeps accumulation correct (the sum still lands in the bucket)."""
     a = GRAD_ARENA
-    if a is not None:
+    if a is not None and not a.holds(param.grad):
         t = a.take(param)
         if t is not None:
             return t.view(param.shape)
@@ -296,7 +300,11 @@ class _ProjectFn(torch.autograd.Function):
         g.v_means2d, g.v_depths, g.v_conics, g.v_compensations = _ptr(v_m2d), _ptr(v_dep), _ptr(v_con), _ptr(v_cmp)
         g.v_means, g.v_quats, g.v_scales, g.v_opacities = _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac)
         ex = SH_EXCHANGE
-        if ex is not None and ctx.layout in ("cat", "split") and sh_K == 16:
+        # only the model's own split layout (features_dc / features_rest as leaf parameters in the bucket): with the
+        # concatenated gsplat layout the coefficient gradient is an intermediate autograd tensor that
+        # dp.allreduce_gradients cannot reach, so the kernel writes the rows itself
+        if (ex is not None and ctx.layout == "split" and sh_K == 16 and GRAD_ARENA is not None
+                and GRAD_ARENA.holds(v_sh0) and GRAD_ARENA.holds(v_shN)):
             # The coefficient-gradient tensors are handed to autograd unwritten; dp.allreduce_gradients fills them.  The
             # factors come from their own small kernel so that their all-gather is already under way while the geometry
             # gradients are computed below.

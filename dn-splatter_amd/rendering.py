@@ -93,7 +93,7 @@ def rasterization(
                       K=Ks[0], cfg=cfg)
 
     holder: Dict = {}
-    bg = backgrounds[0] if backgrounds is not None else None
+    bg = _background_row(backgrounds, n_feat, with_depth, D)
     render, alphas = _ops.rasterize(pr["means2d"], pr["splats"], pr["depths"], pr["radii"], pr["tiles_per_gauss"],
                                     background=bg, width=width, height=height, tile_size=tile_size, D=D,
                                     ed_channel=ed_channel, absgrad=absgrad, holder=holder)
@@ -122,6 +122,25 @@ def rasterization(
     if pr["compensations"] is not None:
         meta["compensations"] = pr["compensations"]
     return render[None], alphas[None, ..., None], meta
+
+
+def _background_row(backgrounds: Optional[Tensor], n_feat: int, with_depth: bool, D: int) -> Optional[Tensor]:
+    """gsplat takes ``backgrounds`` [C, channels of ``colors``] and gives the depth channel of the RGB+D / RGB+ED / D / ED
+    modes a zero background itself (the call at dn_model.py:495-516 passes none).  The kernel reads ``background[k]`` for
+    every composited channel k < D, so the row handed to it must be exactly D wide."""
+    if backgrounds is None:
+        return None
+    if backgrounds.dim() != 2 or backgrounds.shape[0] != 1:
+        raise ValueError(f"backgrounds must be [C, channels] with C == 1, got {tuple(backgrounds.shape)}")
+    row = backgrounds[0]
+    if with_depth and n_feat == 0:
+        row = row.new_zeros(1)                      # "D" / "ED": gsplat replaces the background by zeros
+    elif with_depth and row.shape[0] == n_feat:
+        row = torch.cat([row, row.new_zeros(1)])
+    if row.shape[0] != D:
+        raise ValueError(f"backgrounds has {backgrounds.shape[-1]} channels; expected {n_feat} (the colour channels)"
+                         + (f" or {D} (colour channels + depth)" if with_depth else ""))
+    return row
 
 
 class _LazyIsectIds:

@@ -193,7 +193,9 @@ def isect_offset_encode(isect_ids, tile_width, tile_height):
 
 
 def rasterize_fwd(means2d, conics, colors, opacities, background, width, height, tile_size,
-                  isect_offsets, flatten_ids):
+                  isect_offsets, flatten_ids, borderline=None):
+    """``borderline``: optional uint8 [H,W] output, 1 where a hard decision of the rule set fell inside the fp32
+    rounding envelope (see orc_rasterize_fwd)."""
     N, D = colors.shape
     dt = colors.dtype
     render = torch.zeros(height, width, D, dtype=dt)
@@ -205,7 +207,7 @@ def rasterize_fwd(means2d, conics, colors, opacities, background, width, height,
        _p(background.contiguous() if background is not None else None),
        ctypes.c_int(width), ctypes.c_int(height), ctypes.c_int(tile_size),
        _p(isect_offsets.contiguous()), _p(flatten_ids.contiguous()), ctypes.c_int64(flatten_ids.shape[0]),
-       _p(render), _p(alphas), _p(last_ids))
+       _p(render), _p(alphas), _p(last_ids), _p(borderline))
     return render, alphas, last_ids
 
 
@@ -274,10 +276,10 @@ class _SphericalHarmonics(torch.autograd.Function):
 class _RasterizeToPixels(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, background, width, height, tile_size,
-                isect_offsets, flatten_ids, absgrad):
+                isect_offsets, flatten_ids, absgrad, borderline=None):
         # means2d may arrive as [1,N,2] (the tensor dn_model.py:517-519 retains grad on) or [N,2]
         render, alphas, last_ids = rasterize_fwd(means2d.reshape(-1, 2), conics, colors, opacities, background,
-                                                 width, height, tile_size, isect_offsets, flatten_ids)
+                                                 width, height, tile_size, isect_offsets, flatten_ids, borderline)
         ctx.save_for_backward(means2d, conics, colors, opacities, isect_offsets, flatten_ids, alphas, last_ids)
         ctx.background = background
         ctx.cfg = (width, height, tile_size, absgrad)
@@ -292,7 +294,7 @@ class _RasterizeToPixels(torch.autograd.Function):
             flatten_ids, alphas, last_ids, v_render, v_alphas, absgrad)
         if absgrad:
             means2d.absgrad = v_abs.reshape(means2d.shape)
-        return (v_means2d.reshape(means2d.shape), v_conics, v_colors, v_opac) + (None,) * 7
+        return (v_means2d.reshape(means2d.shape), v_conics, v_colors, v_opac) + (None,) * 8
 
 
 # --------------------------------------------------------------------------- gsplat-shaped API
@@ -339,9 +341,15 @@ def rasterization(
         cols = depths[:, None]
 
     bg = backgrounds[0] if backgrounds is not None else None
+    if bg is not None and render_mode in ("D", "ED"):
+        bg = bg.new_zeros(1)                        # gsplat replaces the background by zeros in the depth-only modes
+    elif bg is not None and bg.shape[0] == cols.shape[-1] - 1 and render_mode != "RGB":
+        bg = torch.cat([bg, bg.new_zeros(1)])      # gsplat appends a zero background for the depth channel
+    assert bg is None or bg.shape[0] == cols.shape[-1], (bg.shape, cols.shape)
     means2d_c = means2d[None]  # [1,N,2]: the object the caller retains grad / reads .absgrad on
+    borderline = torch.zeros(height, width, dtype=torch.uint8)
     render, alphas = _RasterizeToPixels.apply(means2d_c, conics, cols, opacities, bg, width, height,
-                                              tile_size, isect_offsets, flatten_ids, absgrad)
+                                              tile_size, isect_offsets, flatten_ids, absgrad, borderline)
     if render_mode in ("ED", "RGB+ED"):
         render = torch.cat([render[..., :-1], render[..., -1:] / alphas[..., None].clamp(min=1e-10)], dim=-1)
 
@@ -352,6 +360,8 @@ def rasterization(
         "tiles_per_gauss": tiles[None], "isect_ids": isect_ids, "flatten_ids": flatten_ids,
         "isect_offsets": isect_offsets[None], "width": width, "height": height, "tile_size": tile_size,
         "n_cameras": 1,
+        # not a gsplat key: pixels whose skip / stop / clamp decisions fell inside the fp32 rounding envelope
+        "borderline": borderline.bool(),
     }
     return render[None], alphas[None, ..., None], meta
 
@@ -372,6 +382,12 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
         out = torch.ones(img_height, img_width, colors.shape[-1], dtype=colors.dtype) * background
         return (out, torch.zeros(img_height, img_width, dtype=colors.dtype)) if return_alpha else out
     opac = opacity.reshape(-1)
+    global last_borderline
+    border = torch.zeros(img_height, img_width, dtype=torch.uint8)
     render, alphas = _RasterizeToPixels.apply(xys, conics, colors, opac, background, img_width, img_height,
-                                              block_width, offsets, flatten_ids, False)
+                                              block_width, offsets, flatten_ids, False, border)
+    last_borderline = border.bool()     # the legacy call returns no info dict: parity tests read the mask here
     return (render, alphas) if return_alpha else render
+
+
+last_borderline: Optional[Tensor] = None

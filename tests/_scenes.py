@@ -28,18 +28,50 @@ def rel_err(a, b) -> float:
     return (a - b).abs().max().item() / (scale + 1e-30)
 
 
-# The compositing rule has two hard cut-offs (skip a pair if alpha < 1/255; stop a pixel when T(1-alpha) <=
-# 1e-4).  Two fp32 implementations whose exp() differ in the last ulp (libm expf in the oracle,
-# v_exp_f32 on the GPU, ex2.approx in gsplat's CUDA) take the other side of a cut-off for a handful of
-# (pixel, splat) pairs per frame; each flip moves one pixel's contribution (up to ~1e-3 of the tensor scale
-# for faint, wide Gaussians).  Scenes with scattered opacities therefore allow a FLIP_FRACTION of entries to
-# exceed REL_TOL, bounded by FLIP_TOL; the BASELINE scenes (opacity 0.1 everywhere) are held to REL_TOL strictly.
-FLIP_FRACTION = 1e-3
-FLIP_TOL = 5e-3
+# The compositing rule has hard cut-offs (skip a pair if sigma < 0 or alpha < 1/255; stop a pixel when T(1-alpha) <=
+# 1e-4; pass no gradient through alpha where o vis > 0.999 — SURVEY.md A.6/A.7).  Two fp32 implementations whose exp()
+# differ in the last place (libm expf in the oracle, v_exp_f32 on the GPU, ex2.approx in gsplat's CUDA) take the other
+# side of a cut-off for a handful of (pixel, splat) pairs per frame.  The oracle therefore reports, per pixel, whether
+# any of its decisions fell inside the fp32 rounding envelope of its threshold (info["borderline"], see
+# orc_rasterize_fwd in oracle/oracle_impl.inc).  Only those pixels are set aside: images are compared on all other
+# pixels, and the cotangents fed to both backward passes are zero on them, so they contribute exactly nothing to any
+# gradient on either side.  Everything that is compared is held to REL_TOL with no allowance.
+EXCLUDED = []    # (what, n_borderline, n_pixels) of every masked comparison, printed by the tests
 
 
-def assert_close(a, b, what, tol=REL_TOL, atol=0.0, flips=0.0):
-    """max|a-b| <= tol * max|b| + atol for all entries (all but a fraction ``flips``, themselves <= FLIP_TOL).
+def keep_mask(borderline, what=""):
+    """bool [H,W] of the pixels that ARE compared; records and prints how many were set aside."""
+    b = borderline.reshape(borderline.shape[-2], borderline.shape[-1]).bool().cpu()
+    n, tot = int(b.sum()), b.numel()
+    EXCLUDED.append((what, n, tot))
+    print(f"[parity] {what}: {n} of {tot} pixels borderline ({100.0 * n / max(tot, 1):.4f} %), compared separately")
+    # a mask that swallowed a visible share of the image would make the comparison meaningless
+    assert n <= max(8, 0.01 * tot), f"{what}: {n} of {tot} pixels flagged borderline"
+    return ~b
+
+
+def image_pixels(t, keep):
+    """[..., H, W, C] or [..., H, W] image -> the rows of the kept pixels."""
+    H, W = keep.shape
+    t = t.detach().cpu()
+    if t.shape[-2:] == (H, W):
+        t = t.reshape(-1, H, W)[0][..., None]
+    else:
+        t = t.reshape(-1, H, W, t.shape[-1])[0]
+    return t[keep]
+
+
+def zero_borderline(v, keep):
+    """Cotangent image with the borderline pixels zeroed (same shape as ``v``)."""
+    H, W = keep.shape
+    k = keep.to(v.dtype)
+    if v.shape[-2:] == (H, W):
+        return v * k
+    return v * k[..., None]
+
+
+def assert_close(a, b, what, tol=REL_TOL, atol=0.0, keep=None):
+    """max|a-b| <= tol * max|b| + atol over all entries (over the pixels selected by ``keep`` for images).
     ``atol`` is only for tensors that are mathematically zero (e.g. the quaternion gradient of isotropic
     Gaussians), where both sides hold nothing but fp32 rounding noise."""
     a_ = a.detach().cpu()
@@ -49,14 +81,14 @@ def assert_close(a, b, what, tol=REL_TOL, atol=0.0, flips=0.0):
     if b_.numel() == 0:
         return
     scale = b_.double().abs().max().item()
+    if keep is not None:
+        a_, b_ = image_pixels(a_, keep), image_pixels(b_, keep)
     d = (a_.double() - b_.double()).abs().reshape(-1)
-    err = d.max().item()
-    if flips > 0.0:
+    err = d.max().item() if d.numel() else 0.0
+    if err > tol * scale + atol:
         n_bad = int((d > tol * scale + atol).sum())
-        assert n_bad <= max(1, int(flips * d.numel())), f"{what}: {n_bad} of {d.numel()} entries beyond {tol:.1e} * {scale:.3e}"
-        assert err <= FLIP_TOL * scale + atol, f"{what}: max abs error {err:.3e} > {FLIP_TOL:.1e} * scale {scale:.3e}"
-        return
-    assert err <= tol * scale + atol, f"{what}: max abs error {err:.3e} > {tol:.1e} * scale {scale:.3e} + {atol:.1e}"
+        raise AssertionError(f"{what}: max abs error {err:.3e} > {tol:.1e} * scale {scale:.3e} + {atol:.1e} "
+                             f"({n_bad} of {d.numel()} entries beyond it)")
 
 
 def assert_equal_int(a, b, what):

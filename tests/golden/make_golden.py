@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from _scenes import cotangents, gsplat_inputs, to_leaf  # noqa: E402
+from _scenes import cotangents, gsplat_inputs, keep_mask, to_leaf, zero_borderline  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 
@@ -26,10 +26,12 @@ def rasterization_case(path, N=3000, W=128, H=96, focal=90, seed=17, cot_seed=23
     r, a, info = orc.rasterization(**ci, viewmats=viewmat, Ks=K, width=W, height=H, packed=False, sh_degree=3,
                                    render_mode="RGB+ED", absgrad=True)
     v_r, v_a = cotangents([r.shape, a.shape], cot_seed)
+    keep = keep_mask(info["borderline"], "golden c1_small")     # borderline pixels carry no cotangent (tests/_scenes.py)
+    v_r, v_a = zero_borderline(v_r, keep), zero_borderline(v_a[..., 0], keep)[..., None]
     info["means2d"].retain_grad()
     ((r * v_r).sum() + (a * v_a).sum()).backward()
     out = dict(N=N, W=W, H=H, focal=focal, seed=seed, cot_seed=cot_seed,
-               render=r.detach().numpy(), alpha=a.detach().numpy(),
+               render=r.detach().numpy(), alpha=a.detach().numpy(), borderline=info["borderline"].numpy(),
                radii=info["radii"].numpy(), tiles_per_gauss=info["tiles_per_gauss"].numpy(),
                flatten_ids=info["flatten_ids"].numpy(), isect_offsets=info["isect_offsets"].numpy(),
                isect_ids=info["isect_ids"].numpy(),
@@ -54,12 +56,14 @@ def get_outputs_case(path, N=2000, W=96, H=64, focal=60.0, seed=29):
     m = dns.DNSplatterRenderer(params, fused=False, rasterization_fn=orc.rasterization,
                                rasterize_gaussians_fn=orc.rasterize_gaussians)
     out = m.get_outputs(cam)
+    border = m.last_info["borderline"] | orc.last_borderline
+    keep = keep_mask(border, "golden dn_outputs_small")
     gen = torch.Generator().manual_seed(31)
     loss = 0
     for k in ("rgb", "depth", "normal", "accumulation"):
-        loss = loss + (out[k] * (torch.rand(out[k].shape, generator=gen) * 2 - 1)).sum()
+        loss = loss + (out[k] * zero_borderline(torch.rand(out[k].shape, generator=gen) * 2 - 1, keep)).sum()
     loss.backward()
-    save = dict(N=N, W=W, H=H, focal=focal, seed=seed)
+    save = dict(N=N, W=W, H=H, focal=focal, seed=seed, borderline=border.numpy())
     for k, v in out.items():
         save["out_" + k] = v.detach().numpy()
     for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities"):

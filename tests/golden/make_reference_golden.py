@@ -8,6 +8,15 @@ nerfstudio is not installed):
                                dn_model.py:589-603 (c2w = identity, then @ diag(1,-1,-1) and (1 + n) / 2)
   * per-pixel loss terms       dn_splatter/losses.py:154-224 (L1, LogL1, EdgeAwareLogL1) and :279-295 (TVLoss), the terms
                                DNRegularization combines at regularization_strategy.py:146-199
+  * DNSplatterModel.get_outputs   dn_splatter/dn_model.py:404-612 ITSELF: the method's source text is cut out of the class
+                               with ``ast`` and executed as it stands.  The names it pulls from absent packages are
+                               supplied: the two gsplat raster calls by recording stand-ins that return seeded leaf tensors
+                               (so everything AROUND them — the activations handed to gsplat dn_model.py:496-499, the
+                               background blend / clamp / depth fill :526-537, the per-Gaussian normal derivation :543-560,
+                               the normalisation :577-578, the depth -> normal call :589-603 — is the reference's own
+                               arithmetic and autograd), gsplat's quat_to_rotmat and nerfstudio's get_viewmat by their
+                               published formulas (SURVEY.md A.1 / Appendix A conventions), normal_from_depth_image by
+                               the reference's real function.
 
 The module files are loaded by path from /root/reference (read-only); the package's __init__ (which pulls in nerfstudio
 data parsers) is bypassed by registering empty parent packages, and the imports losses.py makes but these classes never
@@ -105,7 +114,164 @@ def loss_case(los, path, W=72, H=48, seed=5):
     print(path, os.path.getsize(path) // 1024, "KiB", {k: float(v) for k, v in out.items() if np.ndim(v) == 0 and k not in ("W", "H")})
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# DNSplatterModel.get_outputs, executed from the reference's own text
+
+
+def extract_method(path, cls, name):
+    """Source text of ``cls.name`` in the file at ``path``, dedented so that it compiles as a free function."""
+    import ast
+    import textwrap
+
+    src = open(path).read()
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.ClassDef) and node.name == cls:
+            for item in node.body:
+                if isinstance(item, ast.FunctionDef) and item.name == name:
+                    return textwrap.dedent(ast.get_source_segment(src, item, padded=True))
+    raise KeyError(f"{cls}.{name} not found in {path}")
+
+
+class StubCameras:
+    """What get_outputs reads from nerfstudio.cameras.Cameras (dn_model.py:417-421, 474-479, 585-597)."""
+
+    def __init__(self, c2w, fx, fy, cx, cy, W, H):
+        self.camera_to_worlds = c2w                          # [1,3,4]
+        t = lambda v: torch.tensor([[float(v)]])             # noqa: E731
+        self.fx, self.fy, self.cx, self.cy = t(fx), t(fy), t(cx), t(cy)
+        self.width, self.height = torch.tensor([[W]]), torch.tensor([[H]])
+        self.shape = (1,)
+        self.metadata = None
+
+    def rescale_output_resolution(self, _f):
+        pass
+
+    def get_intrinsics_matrices(self):
+        K = torch.zeros(1, 3, 3)
+        K[0, 0, 0], K[0, 1, 1], K[0, 0, 2], K[0, 1, 2], K[0, 2, 2] = self.fx.item(), self.fy.item(), self.cx.item(), self.cy.item(), 1.0
+        return K
+
+
+def quat_to_rotmat_published(quat):
+    """gsplat.cuda_legacy._torch_impl.quat_to_rotmat (not vendored): wxyz, normalised first."""
+    w, x, y, z = torch.unbind(torch.nn.functional.normalize(quat, dim=-1), dim=-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=-1).reshape(quat.shape[:-1] + (3, 3))
+
+
+def get_viewmat_published(c2w):
+    """nerfstudio.models.splatfacto.get_viewmat (not vendored): flip y/z columns, analytic inverse."""
+    R = c2w[:, :3, :3] * torch.tensor([[[1.0, -1.0, -1.0]]])
+    T = c2w[:, :3, 3:4]
+    Rt = R.transpose(1, 2)
+    vm = torch.zeros(c2w.shape[0], 4, 4)
+    vm[:, 3, 3] = 1.0
+    vm[:, :3, :3] = Rt
+    vm[:, :3, 3:4] = -torch.bmm(Rt, T)
+    return vm
+
+
+def get_outputs_case(nrm, path, N=60, W=40, H=24, seed=11):
+    import types as _t
+
+    g = torch.Generator().manual_seed(seed)
+    rnd = lambda *shape: torch.rand(*shape, generator=g)        # noqa: E731
+    gauss = {
+        "means": (rnd(N, 3) - 0.5) * 4,
+        "scales": torch.log(rnd(N, 3) * 0.3 + 0.02),
+        "quats": torch.randn(N, 4, generator=g) * 1.7,           # deliberately un-normalised
+        "features_dc": rnd(N, 3),
+        "features_rest": torch.randn(N, 15, 3, generator=g) * 0.1,
+        "opacities": torch.randn(N, 1, generator=g),
+    }
+    gauss["scales"][3] = gauss["scales"][3, 0]                   # a tie for argmin(scales)
+    params = {k: v.clone().requires_grad_(True) for k, v in gauss.items()}
+    # camera: a rotation that is not axis aligned, looking roughly at the origin
+    ang = torch.tensor(0.7)
+    Ry = torch.tensor([[torch.cos(ang), 0, torch.sin(ang)], [0, 1, 0], [-torch.sin(ang), 0, torch.cos(ang)]])
+    ang2 = torch.tensor(-0.3)
+    Rx = torch.tensor([[1, 0, 0], [0, torch.cos(ang2), -torch.sin(ang2)], [0, torch.sin(ang2), torch.cos(ang2)]])
+    c2w = torch.cat([Ry @ Rx, torch.tensor([[1.5], [0.4], [5.0]])], dim=1)[None].contiguous()
+    fx, fy, cx, cy = 31.5, 29.0, 19.25, 12.5
+    camera = StubCameras(c2w, fx, fy, cx, cy, W, H)
+
+    # what the two stand-ins hand back: seeded "rendered" images (leaf tensors, so the reference's post-op autograd runs)
+    render = torch.cat([rnd(1, H, W, 3) * 1.6 - 0.3, rnd(1, H, W, 1) * 5 + 0.5], dim=-1)      # rgb beyond both clamp corners
+    alpha = rnd(1, H, W, 1)
+    alpha[0, :3, :5] = 0.0                                                                   # where(alpha > 0, depth, max)
+    render = render.requires_grad_(True)
+    alpha = alpha.requires_grad_(True)
+    mix = torch.randn(H * W, N, generator=g) * 0.3                                           # normals image = mix @ normals
+    calls = {}
+
+    def rasterization(**kw):
+        calls["rasterization"] = kw
+        info = {"means2d": (rnd(1, N, 2) * 30).requires_grad_(True), "radii": torch.ones(1, N, dtype=torch.int32),
+                "depths": rnd(1, N) + 1, "conics": rnd(1, N, 3), "tiles_per_gauss": torch.ones(1, N, dtype=torch.int32)}
+        return render, alpha, info
+
+    def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width, block_width,
+                            background=None, return_alpha=False):
+        colors.retain_grad()
+        calls["rasterize_gaussians"] = dict(xys=xys, colors=colors, opacity=opacity, img_height=img_height, img_width=img_width,
+                                            block_width=block_width, background=background, xys_requires_grad=xys.requires_grad)
+        return (mix @ colors).reshape(img_height, img_width, 3) + 0.2
+
+    cfg = _t.SimpleNamespace(use_binary_opacities=False, rasterize_mode="classic", sh_degree=3, sh_degree_interval=1000,
+                             predict_normals=True)
+    me = _t.SimpleNamespace(training=True, config=cfg, step=2500, crop_box=None, device=torch.device("cpu"),
+                            camera_optimizer=_t.SimpleNamespace(apply_to_camera=lambda cam: cam.camera_to_worlds),
+                            _get_downscale_factor=lambda: 1, gauss_params=dict(params),
+                            _get_background_color=lambda: torch.tensor([0.1490, 0.1647, 0.2157]),
+                            means=params["means"], scales=params["scales"], quats=params["quats"],
+                            features_dc=params["features_dc"], features_rest=params["features_rest"],
+                            opacities=params["opacities"])
+    from typing import Dict, List, Union
+    ns = dict(torch=torch, F=torch.nn.functional, Tensor=torch.Tensor, Dict=Dict, List=List, Union=Union, Cameras=StubCameras,
+              rasterization=rasterization, rasterize_gaussians=rasterize_gaussians, quat_to_rotmat=quat_to_rotmat_published,
+              get_viewmat=get_viewmat_published, normal_from_depth_image=nrm.normal_from_depth_image)
+    text = extract_method(os.path.join(REF, "dn_splatter/dn_model.py"), "DNSplatterModel", "get_outputs")
+    exec(compile(text, "dn_model.py::DNSplatterModel.get_outputs", "exec"), ns)
+    cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self           # dn_model.py:476 `.cuda()`: this container has no GPU
+    try:
+        out = ns["get_outputs"](me, camera)
+    finally:
+        torch.Tensor.cuda = cuda
+    cot = {k: rnd(*out[k].shape) * 2 - 1 for k in ("rgb", "depth", "normal", "accumulation")}
+    torch.autograd.backward([out[k] for k in cot], [cot[k] for k in cot])
+    kw = calls["rasterization"]
+    rg = calls["rasterize_gaussians"]
+    save = dict(N=N, W=W, H=H, fx=fx, fy=fy, cx=cx, cy=cy, c2w=c2w.numpy(), step=me.step,
+                render=render.detach().numpy(), alpha=alpha.detach().numpy(), mix=mix.numpy(),
+                # A0: what the reference hands to gsplat.rasterization (dn_model.py:495-513)
+                call_quats=kw["quats"].detach().numpy(), call_scales=kw["scales"].detach().numpy(),
+                call_opacities=kw["opacities"].detach().numpy(), call_colors=kw["colors"].detach().numpy(),
+                call_viewmats=kw["viewmats"].numpy(), call_Ks=kw["Ks"].numpy(), call_sh_degree=kw["sh_degree"],
+                call_scalars=np.array([kw["width"], kw["height"], kw["tile_size"], kw["near_plane"], kw["far_plane"]], dtype=np.float64),
+                call_flags=np.array([kw["packed"], kw["sparse_grad"], kw["absgrad"], kw["render_mode"] == "RGB+ED",
+                                     kw["rasterize_mode"] == "classic"]),
+                # A7: what it hands to the legacy rasterize_gaussians (dn_model.py:564-575) and stores at :558
+                normals_cam=rg["colors"].detach().numpy(), normals_world=me.gauss_params["normals"].detach().numpy(),
+                legacy_opacity=rg["opacity"].detach().numpy(), legacy_xys_requires_grad=rg["xys_requires_grad"],
+                legacy_background_is_none=rg["background"] is None, legacy_block_width=rg["block_width"],
+                v_normals_cam=rg["colors"].grad.numpy(),
+                # gradients of the seeded loss
+                v_render=render.grad.numpy(), v_alpha=alpha.grad.numpy(), v_quats=params["quats"].grad.numpy(),
+                grad_is_none=np.array([params[k].grad is None for k in ("means", "scales", "features_dc", "features_rest", "opacities")]))
+    for k, v in gauss.items():
+        save["param_" + k] = v.numpy()
+    for k, v in out.items():
+        save["out_" + k] = v.detach().numpy()
+    for k, v in cot.items():
+        save["cot_" + k] = v.numpy()
+    np.savez_compressed(path, **save)
+    print(path, os.path.getsize(path) // 1024, "KiB", "outputs", {k: tuple(v.shape) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     cam_mod, nrm_mod, los_mod = load_reference()
     depth_normal_case(nrm_mod, os.path.join(HERE, "reference_depth_normal.npz"))
     loss_case(los_mod, os.path.join(HERE, "reference_losses.npz"))
+    get_outputs_case(nrm_mod, os.path.join(HERE, "reference_get_outputs.npz"))

@@ -10,7 +10,7 @@ import os
 import pytest
 import torch
 
-from _scenes import FLIP_FRACTION, REL_TOL, assert_close, assert_equal_int, cotangents, gsplat_inputs, rel_err, to_leaf
+from _scenes import REL_TOL, assert_close, assert_equal_int, cotangents, gsplat_inputs, keep_mask, rel_err, to_leaf, zero_borderline
 
 pytestmark = pytest.mark.gpu
 
@@ -28,7 +28,15 @@ def _call_both(dns, orc, inp, viewmat, K, W, H, **kw):
     return (r_o, a_o, info_o, ci), (r_g, a_g, info_g, gi)
 
 
-def _check_forward(o, g, tol=REL_TOL, flips=0.0):
+def _keep(o, what="scene"):
+    """Pixels compared strictly: everything outside the oracle's borderline mask (_scenes.py)."""
+    info_o = o[2]
+    if "_keep" not in info_o:
+        info_o["_keep"] = keep_mask(info_o["borderline"], what)
+    return info_o["_keep"]
+
+
+def _check_forward(o, g, tol=REL_TOL, what="scene"):
     r_o, a_o, info_o, _ = o
     r_g, a_g, info_g, _ = g
     for k in INT_KEYS:
@@ -37,14 +45,18 @@ def _check_forward(o, g, tol=REL_TOL, flips=0.0):
     assert info_g["n_isects"] == info_o["flatten_ids"].shape[0]
     for k in FLOAT_KEYS:
         assert_close(info_g[k], info_o[k], k, tol)
-    assert_close(r_g, r_o, "render", tol, flips=flips)
-    assert_close(a_g, a_o, "alpha", tol, flips=flips)
+    keep = _keep(o, what)
+    assert_close(r_g, r_o, "render", tol, keep=keep)
+    assert_close(a_g, a_o, "alpha", tol, keep=keep)
 
 
-def _check_backward(o, g, tol=REL_TOL, seed=1, absgrad=True, quat_atol=0.0, flips=0.0):
+def _check_backward(o, g, tol=REL_TOL, seed=1, absgrad=True, quat_atol=0.0, what="scene"):
     r_o, a_o, info_o, ci = o
     r_g, a_g, info_g, gi = g
+    keep = _keep(o, what)
     v_r, v_a = cotangents([r_o.shape, a_o.shape], seed)
+    # borderline pixels get zero cotangents on BOTH sides: they contribute exactly nothing to any gradient
+    v_r, v_a = zero_borderline(v_r, keep), zero_borderline(v_a[..., 0], keep)[..., None]
     info_o["means2d"].retain_grad()
     info_g["means2d"].retain_grad()
     ((r_o * v_r).sum() + (a_o * v_a).sum()).backward()
@@ -54,10 +66,69 @@ def _check_backward(o, g, tol=REL_TOL, seed=1, absgrad=True, quat_atol=0.0, flip
         if ci[k].grad is None:          # e.g. colours in the depth-only render modes
             assert gi[k].grad is None or float(gi[k].grad.abs().max()) == 0.0, k
             continue
-        assert_close(gi[k].grad, ci[k].grad, "grad " + k, tol, atol=quat_atol if k == "quats" else 0.0, flips=flips)
-    assert_close(info_g["means2d"].grad, info_o["means2d"].grad, "means2d.grad", tol, flips=flips)
+        assert_close(gi[k].grad, ci[k].grad, "grad " + k, tol, atol=quat_atol if k == "quats" else 0.0)
+    assert_close(info_g["means2d"].grad, info_o["means2d"].grad, "means2d.grad", tol)
     if absgrad:
-        assert_close(info_g["means2d"].absgrad, info_o["means2d"].absgrad, "means2d.absgrad", tol, flips=flips)
+        assert_close(info_g["means2d"].absgrad, info_o["means2d"].absgrad, "means2d.absgrad", tol)
+
+
+GRAD_NAMES = ("means", "scales", "quats", "features_dc", "features_rest", "opacities")
+OUT_KEYS = ("rgb", "depth", "normal", "accumulation")
+
+
+def _mirror_pair(dns, orc, gp, cam, hip_kw, cot_seed=2, what="mirror"):
+    """DNSplatterModel.get_outputs (dn_model.py:404-612) twice: the reference's own op sequence with the oracle plugged in
+    for the two gsplat calls (CPU), and the product (GPU, ``hip_kw`` picks fused / two-call).  The oracle runs first: its
+    borderline mask (plus the pixels whose pre-clamp rgb sits within rounding of the clamp(0, 1) corners, where the
+    gradient gate of dn_model.py:528 may fall either way) selects the pixels that are compared and zeroes the cotangents of
+    the others on BOTH sides.  Returns ((out, params, renderer) for hip, the same for the oracle, keep)."""
+    captured = {}
+
+    def rasterization_spy(**kw):
+        r, a, info = orc.rasterization(**kw)
+        captured["render"], captured["alpha"], captured["info"] = r.detach(), a.detach(), info
+        return r, a, info
+
+    def leaves(device):
+        return {k: v.detach().to(device).clone().requires_grad_(k != "normals") for k, v in gp.items()}
+
+    p_o = leaves("cpu")
+    m_o = dns.DNSplatterRenderer(p_o, fused=False, rasterization_fn=rasterization_spy,
+                                 rasterize_gaussians_fn=orc.rasterize_gaussians)
+    out_o = m_o.get_outputs(cam)
+    border = captured["info"]["borderline"].clone()
+    if orc.last_borderline is not None and orc.last_borderline.shape == border.shape:
+        border |= orc.last_borderline                       # the second (legacy normal) pass
+    pre = captured["render"][0, ..., :3] + (1 - captured["alpha"][0]) * out_o["background"]
+    border |= ((pre.abs() < 4e-6) | ((pre - 1).abs() < 4e-6)).any(-1)
+    keep = keep_mask(border, what)
+    gen = torch.Generator().manual_seed(cot_seed)
+    cot = {k: zero_borderline(torch.rand(out_o[k].shape, generator=gen) * 2 - 1, keep) for k in OUT_KEYS}
+    torch.autograd.backward([out_o[k] for k in OUT_KEYS], [cot[k] for k in OUT_KEYS])
+
+    p_g = leaves(DEV)
+    m_g = dns.DNSplatterRenderer(p_g, **hip_kw)
+    out_g = m_g.get_outputs(cam.to(DEV))
+    torch.autograd.backward([out_g[k] for k in OUT_KEYS], [cot[k].to(DEV) for k in OUT_KEYS])
+    torch.cuda.synchronize()
+    return (out_g, p_g, m_g), (out_o, p_o, m_o), keep
+
+
+def _check_mirror(hip, ora, keep, what="mirror", quat_atol=0.0, ints=True):
+    out_g, p_g, m_g = hip
+    out_o, p_o, m_o = ora
+    if ints:
+        assert_equal_int(m_g.radii, m_o.radii, what + " radii")
+        assert_equal_int(m_g.num_tiles_hit.reshape(-1), m_o.num_tiles_hit.reshape(-1), what + " num_tiles_hit")
+        assert_equal_int(m_g.last_info["flatten_ids"], m_o.last_info["flatten_ids"], what + " flatten_ids")
+        assert_equal_int(m_g.last_info["isect_offsets"], m_o.last_info["isect_offsets"], what + " isect_offsets")
+    for k in OUT_KEYS:
+        assert out_g[k].shape == out_o[k].shape
+        assert_close(out_g[k], out_o[k], what + " " + k, keep=keep)
+    for k in GRAD_NAMES:
+        assert_close(p_g[k].grad, p_o[k].grad, what + " grad " + k, atol=quat_atol if k == "quats" else 0.0)
+    assert_close(m_g.xys.grad, m_o.xys.grad, what + " xys.grad (dn_model.py:517-519)")
+    assert_close(m_g.xys.absgrad, m_o.xys.absgrad, what + " xys.absgrad")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -70,42 +141,42 @@ def test_c1_rasterization_matches_oracle(dns, orc):
     fp32 noise there and that gradient is compared with an absolute tolerance."""
     inp, viewmat, K, _ = gsplat_inputs(10_000, 256, 256, focal=160.0, seed=0)
     o, g = _call_both(dns, orc, inp, viewmat, K, 256, 256, sh_degree=3, render_mode="RGB+ED", absgrad=True)
-    # observed on this scene: every tensor within 2e-5 of its scale; the cut-off flip allowance (see _scenes.py)
-    # only guards against a single (pixel, splat) threshold decision landing differently
-    _check_forward(o, g, flips=FLIP_FRACTION)
-    _check_backward(o, g, quat_atol=1e-4, flips=FLIP_FRACTION)
+    # every compared entry is held to 1e-4 of its tensor's scale; only the oracle-flagged borderline pixels (see
+    # _scenes.py) are set aside
+    _check_forward(o, g)
+    _check_backward(o, g, quat_atol=1e-4)
 
 
 def test_c1_anisotropic_rasterization_matches_oracle(dns, orc):
     """C1 sizes with anisotropic scales and spread opacities, so every gradient (quats included) is exercised."""
     inp, viewmat, K, _ = gsplat_inputs(10_000, 256, 256, focal=160.0, seed=1, anisotropic=True)
     o, g = _call_both(dns, orc, inp, viewmat, K, 256, 256, sh_degree=3, render_mode="RGB+ED", absgrad=True)
-    _check_forward(o, g, flips=FLIP_FRACTION)
-    _check_backward(o, g, flips=FLIP_FRACTION)
+    _check_forward(o, g)
+    _check_backward(o, g)
 
 
 @pytest.mark.parametrize("W,H", [(200, 120), (17, 33), (16, 16), (1, 1), (333, 95)])
 def test_ragged_image_sizes(dns, orc, W, H):
     inp, viewmat, K, _ = gsplat_inputs(3000, W, H, focal=0.6 * max(W, H), seed=4, anisotropic=True)
     o, g = _call_both(dns, orc, inp, viewmat, K, W, H, sh_degree=3, render_mode="RGB+ED", absgrad=True)
-    _check_forward(o, g, flips=FLIP_FRACTION)
-    _check_backward(o, g, flips=FLIP_FRACTION)
+    _check_forward(o, g)
+    _check_backward(o, g)
 
 
 @pytest.mark.parametrize("sh_degree", [0, 1, 2, 3])
 def test_sh_degrees(dns, orc, sh_degree):
     inp, viewmat, K, _ = gsplat_inputs(4000, 128, 96, focal=90.0, seed=5, sh_rest_std=0.3, anisotropic=True)
     o, g = _call_both(dns, orc, inp, viewmat, K, 128, 96, sh_degree=sh_degree, render_mode="RGB+ED", absgrad=True)
-    _check_forward(o, g, flips=FLIP_FRACTION)
-    _check_backward(o, g, flips=FLIP_FRACTION)
+    _check_forward(o, g)
+    _check_backward(o, g)
 
 
 @pytest.mark.parametrize("render_mode", ["RGB", "D", "ED", "RGB+D", "RGB+ED"])
 def test_render_modes(dns, orc, render_mode):
     inp, viewmat, K, _ = gsplat_inputs(3000, 96, 80, focal=70.0, seed=6, anisotropic=True)
     o, g = _call_both(dns, orc, inp, viewmat, K, 96, 80, sh_degree=3, render_mode=render_mode, absgrad=True)
-    _check_forward(o, g, flips=FLIP_FRACTION)
-    _check_backward(o, g, flips=FLIP_FRACTION)
+    _check_forward(o, g)
+    _check_backward(o, g)
 
 
 def test_direct_colors_and_background(dns, orc):
@@ -120,16 +191,16 @@ def test_direct_colors_and_background(dns, orc):
                                          render_mode="RGB+D", backgrounds=bg, absgrad=True)
     r_g, a_g, info_g = dns.rasterization(**gi, viewmats=viewmat.to(DEV), Ks=K.to(DEV), width=96, height=80,
                                          packed=False, render_mode="RGB+D", backgrounds=bg.to(DEV), absgrad=True)
-    _check_forward((r_o, a_o, info_o, ci), (r_g, a_g, info_g, gi), flips=FLIP_FRACTION)
-    _check_backward((r_o, a_o, info_o, ci), (r_g, a_g, info_g, gi), flips=FLIP_FRACTION)
+    _check_forward((r_o, a_o, info_o, ci), (r_g, a_g, info_g, gi))
+    _check_backward((r_o, a_o, info_o, ci), (r_g, a_g, info_g, gi))
 
 
 def test_antialiased_mode(dns, orc):
     inp, viewmat, K, _ = gsplat_inputs(4000, 128, 96, focal=90.0, seed=8, anisotropic=True)
     o, g = _call_both(dns, orc, inp, viewmat, K, 128, 96, sh_degree=3, render_mode="RGB+ED", absgrad=True,
                       rasterize_mode="antialiased")
-    _check_forward(o, g, flips=FLIP_FRACTION)
-    _check_backward(o, g, flips=FLIP_FRACTION)
+    _check_forward(o, g)
+    _check_backward(o, g)
 
 
 @pytest.mark.parametrize("near,far,radius_clip,eps2d", [(0.01, 1e10, 0.0, 0.3), (5.0, 9.0, 0.0, 0.3), (0.01, 1e10, 6.0, 0.3),
@@ -152,8 +223,8 @@ def test_culling_planes_and_extreme_geometry(dns, orc, near, far, radius_clip, e
               eps2d=eps2d)
     o, g = _call_both(dns, orc, inp, viewmat, K, W, H, **kw)
     assert int((o[2]["radii"] > 0).sum()) > 100
-    _check_forward(o, g, flips=FLIP_FRACTION)
-    _check_backward(o, g, flips=FLIP_FRACTION)
+    _check_forward(o, g)
+    _check_backward(o, g)
 
 
 def test_legacy_rasterize_gaussians_options(dns, orc):
@@ -169,8 +240,9 @@ def test_legacy_rasterize_gaussians_options(dns, orc):
     dev = lambda t: t.to(DEV)   # noqa: E731
     out_g, al_g = dns.rasterize_gaussians(dev(info["means2d"][0]), *[dev(t) for t in common], dev(cols),
                                           dev(inp["opacities"][:, None]), 64, 96, 16, background=dev(bg), return_alpha=True)
-    assert_close(out_g, out_o, "legacy render with background", flips=FLIP_FRACTION)
-    assert_close(al_g, al_o, "legacy alpha", flips=FLIP_FRACTION)
+    keep = keep_mask(orc.last_borderline, "legacy options")
+    assert_close(out_g, out_o, "legacy render with background", keep=keep)
+    assert_close(al_g, al_o, "legacy alpha", keep=keep)
     u8 = (cols[:, :3] * 255).to(torch.uint8)
     out_u8 = dns.rasterize_gaussians(dev(info["means2d"][0]), *[dev(t) for t in common], dev(u8), dev(inp["opacities"][:, None]),
                                      64, 96, 16)
@@ -238,29 +310,16 @@ def test_saturated_opacities_take_the_alpha_clamp(dns, orc):
     o, g = _call_both(dns, orc, inp, viewmat, K, 160, 128, sh_degree=3, render_mode="RGB+ED", absgrad=True)
     clamped = (o[2]["radii"][0] > 0) & (inp["opacities"] > 0.999)
     assert int(clamped.sum()) > 500
-    _check_forward(o, g, flips=FLIP_FRACTION)
-    _check_backward(o, g, flips=FLIP_FRACTION)
+    _check_forward(o, g)
+    _check_backward(o, g)
     # and the fused 7-channel pass (the instantiation the benchmark uses)
     from dn_splatter_amd import synthetic
     gp = synthetic.make_gauss_params(5000, sh_rest_std=0.2, seed=13)
     gp["opacities"] = gp["opacities"].detach().clone()
     gp["opacities"][::3] = 12.0                                   # sigmoid(12) = 0.999994
     cam = synthetic.orbit_camera(3, width=144, height=112, focal=100.0)
-    res = {}
-    for name, device, kw in (("hip", DEV, dict(fused=True)),
-                             ("oracle", "cpu", dict(fused=False, rasterization_fn=orc.rasterization,
-                                                    rasterize_gaussians_fn=orc.rasterize_gaussians))):
-        params = {k: v.detach().to(device).clone().requires_grad_(k != "normals") for k, v in gp.items()}
-        out = dns.DNSplatterRenderer(params, **kw).get_outputs(cam.to(device))
-        gen = torch.Generator().manual_seed(4)
-        keys = ("rgb", "depth", "normal", "accumulation")
-        torch.autograd.backward([out[k] for k in keys], [(torch.rand(out[k].shape, generator=gen) * 2 - 1).to(device) for k in keys])
-        res[name] = (out, params)
-    torch.cuda.synchronize()
-    for k in ("rgb", "depth", "normal", "accumulation"):
-        assert_close(res["hip"][0][k], res["oracle"][0][k], "clamped fused " + k, flips=FLIP_FRACTION)
-    for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities"):
-        assert_close(res["hip"][1][k].grad, res["oracle"][1][k].grad, "clamped fused grad " + k, flips=FLIP_FRACTION)
+    hip, ora, keep = _mirror_pair(dns, orc, gp, cam, dict(fused=True), cot_seed=4, what="clamped fused")
+    _check_mirror(hip, ora, keep, "clamped fused")
 
 
 def test_occluded_and_transparent_gaussians(dns, orc):
@@ -315,12 +374,14 @@ def test_rasterize_gaussians_legacy_dropin(dns, orc):
     out_g = dns.rasterize_gaussians(cg["xys"], info["depths"][0].to(DEV), info["radii"][0].to(DEV), cg["conics"],
                                     info["tiles_per_gauss"][0].to(DEV), cg["colors"], cg["opacity"], 112, 160, 16)
     assert out_g.shape == (112, 160, 3)
-    assert_close(out_g, out_o, "legacy render", flips=FLIP_FRACTION)
+    keep = keep_mask(orc.last_borderline, "legacy drop-in")
+    assert_close(out_g, out_o, "legacy render", keep=keep)
     (v,) = cotangents([out_o.shape], 4)
+    v = zero_borderline(v, keep)
     (out_o * v).sum().backward()
     (out_g * v.to(DEV)).sum().backward()
     for k in co:
-        assert_close(cg[k].grad, co[k].grad, "legacy grad " + k, flips=FLIP_FRACTION)
+        assert_close(cg[k].grad, co[k].grad, "legacy grad " + k)
 
 
 MODES = {"fused_hip_postops": dict(fused=True, fused_postops=True), "fused_torch_postops": dict(fused=True, fused_postops=False),
@@ -339,27 +400,13 @@ def test_get_outputs_mirror_matches_reference_sequence(dns, orc, mode):
     gp["scales"] = (gp["scales"].detach() + torch.randn(N, 3, generator=g_) * 0.5).requires_grad_(True)
     cam = synthetic.orbit_camera(3, width=W, height=H, focal=160.0)
 
-    def run(device, **kw):
-        params = {k: v.detach().to(device).clone().requires_grad_(k != "normals") for k, v in gp.items()}
-        m = dns.DNSplatterRenderer(params, **kw)
-        out = m.get_outputs(cam.to(device))
-        gen = torch.Generator().manual_seed(2)
-        loss = 0
-        for k in ("rgb", "depth", "normal", "accumulation"):
-            loss = loss + (out[k] * (torch.rand(out[k].shape, generator=gen) * 2 - 1).to(device)).sum()
-        loss.backward()
-        return out, params, m
-
-    out_g, p_g, m_g = run(DEV, **MODES[mode])
-    out_o, p_o, m_o = run("cpu", fused=False, rasterization_fn=orc.rasterization,
-                          rasterize_gaussians_fn=orc.rasterize_gaussians)
-    torch.cuda.synchronize()
+    hip, ora, keep = _mirror_pair(dns, orc, gp, cam, MODES[mode], what="mirror " + mode)
+    out_g, p_g, m_g = hip
+    out_o, p_o, m_o = ora
     assert set(out_g) == {"rgb", "depth", "normal", "surface_normal", "accumulation", "background"}
+    _check_mirror(hip, ora, keep, "mirror " + mode, ints=False)
     assert_equal_int(m_g.radii, m_o.radii, "radii")
     assert_equal_int(m_g.num_tiles_hit.reshape(-1), m_o.num_tiles_hit.reshape(-1), "num_tiles_hit")
-    for k in ("rgb", "depth", "normal", "accumulation"):
-        assert out_g[k].shape == out_o[k].shape
-        assert_close(out_g[k], out_o[k], k, flips=FLIP_FRACTION)
     # surface_normal is a finite-difference stencil of the depth image: depth noise is amplified by ~fx/d, so it
     # is compared on the 99.9 % quantile of the error; the border must be exactly the reference's 0.5
     d_sn = (out_g["surface_normal"].detach().cpu() - out_o["surface_normal"].detach()).abs().reshape(-1)
@@ -368,10 +415,6 @@ def test_get_outputs_mirror_matches_reference_sequence(dns, orc, mode):
     sn = out_g["surface_normal"].detach().cpu()
     assert torch.equal(sn[0], torch.full_like(sn[0], 0.5)) and torch.equal(sn[:, -1], torch.full_like(sn[:, -1], 0.5))
     assert_close(p_g["normals"], p_o["normals"], "gauss_params['normals'] (dn_model.py:558)", 1e-5)
-    for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities"):
-        assert_close(p_g[k].grad, p_o[k].grad, "grad " + k, flips=FLIP_FRACTION)
-    assert_close(m_g.xys.grad, m_o.xys.grad, "xys.grad (dn_model.py:517-519)", flips=FLIP_FRACTION)
-    assert_close(m_g.xys.absgrad, m_o.xys.absgrad, "xys.absgrad", flips=FLIP_FRACTION)
 
 
 def test_densify_stats_match_nerfstudio_after_train(dns):
@@ -614,50 +657,123 @@ def test_against_golden_fixture(dns):
                                    sh_degree=3, render_mode="RGB+ED", absgrad=True)
     for k in INT_KEYS:
         assert_equal_int(info[k], torch.from_numpy(gold[k]), "golden " + k)
-    assert_close(r, torch.from_numpy(gold["render"]), "golden render", flips=FLIP_FRACTION)
-    assert_close(a, torch.from_numpy(gold["alpha"]), "golden alpha", flips=FLIP_FRACTION)
+    keep = keep_mask(torch.from_numpy(gold["borderline"]), "golden c1_small")
+    assert_close(r, torch.from_numpy(gold["render"]), "golden render", keep=keep)
+    assert_close(a, torch.from_numpy(gold["alpha"]), "golden alpha", keep=keep)
     v_r, v_a = cotangents([r.shape, a.shape], int(gold["cot_seed"]))
+    v_r, v_a = zero_borderline(v_r, keep), zero_borderline(v_a[..., 0], keep)[..., None]
     ((r * v_r.to(DEV)).sum() + (a * v_a.to(DEV)).sum()).backward()
     for k in gi:
-        assert_close(gi[k].grad, torch.from_numpy(gold["grad_" + k]), "golden grad " + k, flips=FLIP_FRACTION)
+        assert_close(gi[k].grad, torch.from_numpy(gold["grad_" + k]), "golden grad " + k)
 
 
 # ------------------------------------------------------------------------------------------------
-# BASELINE config C2 at full size: size-independent properties (the oracle would take minutes here)
+# BASELINE configs at full size (C2: 1 M Gaussians 1920x1080; C3: 3 M 1600x1200; C5: 5 M 1600x1200 per GPU)
+
+FULL = {"c2": (1_000_000, 1920, 1080), "c3": (3_000_000, 1600, 1200), "c5": (5_000_000, 1600, 1200)}
 
 
-@pytest.fixture(scope="module")
-def c2(dns):
+def _oracle_threads():
+    # the oracle's gradient scatter uses omp atomics: beyond ~32 threads it only gets slower (bench.py cpu_baseline)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+
+
+@pytest.fixture(scope="module", params=sorted(FULL))
+def full_scene(request, dns):
     from dn_splatter_amd import synthetic
 
-    N, W, H = 1_000_000, 1920, 1080
+    N, W, H = FULL[request.param]
     gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=0, device=DEV)
     cam = synthetic.orbit_camera(0, width=W, height=H).to(DEV)
     m = dns.DNSplatterRenderer(gp, fused=True)
     out = m.get_outputs(cam)
-    return gp, cam, m, out
+    yield gp, cam, m, out
+    del gp, m, out
+    torch.cuda.empty_cache()
 
 
-def test_c2_scene_centre_crop_matches_oracle(dns, orc):
-    """The BASELINE C2 scene itself (1 M Gaussians, fx = fy = 1200, 1080p principal point), rendered through a
+def test_c2_full_frame_fused_pass_matches_oracle(dns, orc):
+    """The benchmark step itself: BASELINE C2 — all 1 M Gaussians, the whole 1920 x 1080 frame, fused colour + depth +
+    normal pass with the HIP post-ops — against the reference's two-call sequence (dn_model.py:495-578) run on the oracle.
+    Every integer output bit for bit, every image and every gradient within 1e-4 (borderline pixels set aside, count
+    printed).  The oracle needs about half a minute on 32 threads for its two forward and two backward passes."""
+    from dn_splatter_amd import synthetic
+
+    _oracle_threads()
+    N, W, H = FULL["c2"]
+    gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=0)
+    cam = synthetic.orbit_camera(0, width=W, height=H)
+    hip, ora, keep = _mirror_pair(dns, orc, gp, cam, dict(fused=True), cot_seed=1, what="C2 full frame")
+    assert hip[2].last_info["n_isects"] > 20_000_000
+    assert float(hip[0]["accumulation"].min()) > 0.999                # every pixel saturates, as in the benchmark
+    _check_mirror(hip, ora, keep, "C2 full frame", quat_atol=1e-4)    # isotropic init: d/d(quats) is rounding noise
+
+
+@pytest.mark.parametrize("workload,crop", [("c2", 384), ("c3", 384)])
+def test_full_scene_centre_crop_matches_oracle(dns, orc, workload, crop):
+    """The BASELINE C2 / C3 scenes (1 M Gaussians at 1080p, 3 M at 1600 x 1200; fx = fy = 1200), rendered through a
     384 x 384 window at the image centre so that the CPU oracle finishes in seconds: same Gaussians, same depth
-    complexity (~3000 entries per tile list, every pixel saturating) as the benchmark.  Both sides get the same
-    activated inputs, so every integer output is compared bit for bit."""
-    W, H, C = 1920, 1080, 384
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
-    inp, viewmat, K, _ = gsplat_inputs(1_000_000, W, H, focal=1200.0, seed=0)
+    complexity (thousands of entries per tile list, every pixel saturating) as the benchmark.  gsplat.rasterization as
+    dn-splatter calls it (RGB+ED, absgrad); both sides get the same activated inputs, so every integer output is compared
+    bit for bit."""
+    N, W, H = FULL[workload]
+    C = crop
+    _oracle_threads()
+    inp, viewmat, K, _ = gsplat_inputs(N, W, H, focal=1200.0, seed=0)
     K = K.clone()
     K[..., 0, 2] -= (W - C) // 2
     K[..., 1, 2] -= (H - C) // 2
     o, g = _call_both(dns, orc, inp, viewmat, K, C, C, sh_degree=3, render_mode="RGB+ED", absgrad=True)
     assert g[2]["n_isects"] > 1_000_000
     assert float(g[1].min()) > 0.999                            # saturating pixels, like the full frame
-    _check_forward(o, g, flips=FLIP_FRACTION)
-    _check_backward(o, g, quat_atol=1e-4, flips=FLIP_FRACTION)
+    _check_forward(o, g, what=workload + " centre crop")
+    _check_backward(o, g, quat_atol=1e-4, what=workload + " centre crop")
 
 
-def test_c2_full_size_binning_properties(dns, c2):
-    gp, cam, m, out = c2
+def test_c3_centre_crop_fused_pass_matches_oracle(dns, orc):
+    """BASELINE C3 (dn-splatter-big: 3 M Gaussians, 1600 x 1200) through the fused pass + HIP post-ops — the path the
+    C3 / C5 bench lines time — on a 384 x 384 centre window, against the reference sequence on the oracle."""
+    from dn_splatter_amd import synthetic
+    from dn_splatter_amd.model import Camera
+
+    _oracle_threads()
+    N, W, H = FULL["c3"]
+    C = 384
+    gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=0)
+    cam = synthetic.orbit_camera(0, width=W, height=H)
+    ccam = Camera(cam.camera_to_worlds, cam.fx, cam.fy, cam.cx - (W - C) // 2, cam.cy - (H - C) // 2, C, C)
+    hip, ora, keep = _mirror_pair(dns, orc, gp, ccam, dict(fused=True), cot_seed=3, what="C3 centre crop (fused)")
+    assert hip[2].last_info["n_isects"] > 1_000_000
+    _check_mirror(hip, ora, keep, "C3 centre crop (fused)", quat_atol=1e-4)
+
+
+@pytest.mark.parametrize("workload", ["c3", "c5"])
+def test_full_size_projection_and_binning_match_oracle(dns, orc, workload):
+    """C3 / C5 at FULL size, integer half of the path: projection (radii), tile counts, the sorted tile lists and the tile
+    offsets of all 3 M / 5 M Gaussians over the whole 1600 x 1200 frame, bit for bit against the oracle's projection +
+    isect_tiles + 64-bit stable sort (the single-threaded sort of ~10^8 pairs takes the oracle some ten seconds)."""
+    N, W, H = FULL[workload]
+    _oracle_threads()
+    inp, viewmat, K, _ = gsplat_inputs(N, W, H, focal=1200.0, seed=0)
+    with torch.no_grad():
+        gi = {k: v.to(DEV) for k, v in inp.items()}
+        _r, _a, info = dns.rasterization(**gi, viewmats=viewmat.to(DEV), Ks=K.to(DEV), width=W, height=H, packed=False,
+                                         sh_degree=3, render_mode="RGB+ED")
+        radii, means2d, depths, conics, _c, tiles = orc.project_fwd(inp["means"], inp["quats"], inp["scales"], viewmat[0], K[0], W, H)
+        tw, th = math.ceil(W / 16), math.ceil(H / 16)
+        _t, isect_ids, flatten_ids = orc.isect_tiles(means2d, radii, depths, 16, tw, th)
+        offsets = orc.isect_offset_encode(isect_ids, tw, th)
+    assert_equal_int(info["radii"][0], radii, workload + " radii")
+    assert_equal_int(info["tiles_per_gauss"][0], tiles, workload + " tiles_per_gauss")
+    assert info["n_isects"] == flatten_ids.shape[0] > 30_000_000
+    assert_equal_int(info["flatten_ids"], flatten_ids, workload + " flatten_ids")
+    assert_equal_int(info["isect_offsets"][0], offsets, workload + " isect_offsets")
+    for k, ref in (("means2d", means2d), ("depths", depths), ("conics", conics)):
+        assert_close(info[k][0], ref, workload + " " + k)
+
+
+def test_full_size_binning_properties(dns, full_scene):
+    gp, cam, m, out = full_scene
     info = m.last_info
     n = info["n_isects"]
     tiles = info["tiles_per_gauss"][0].long()
@@ -685,8 +801,8 @@ def test_c2_full_size_binning_properties(dns, c2):
     assert bool(inside.all())
 
 
-def test_c2_full_size_image_properties_and_linearity(dns, c2):
-    gp, cam, m, out = c2
+def test_full_size_image_properties_and_linearity(dns, full_scene):
+    gp, cam, m, out = full_scene
     acc = out["accumulation"]
     assert float(acc.min()) >= 0.0 and float(acc.max()) < 1.0
     for k in ("rgb", "depth", "normal"):

@@ -108,3 +108,151 @@ def test_hip_loss_kernels_equal_the_reference_terms():
     ea = tl.edge_aware_log_l1(pred.cpu(), gt.cpu(), rgb.cpu(), valid.cpu())
     want = 1.2 * float(ea) + float(g["tv_normal"]) + 1.0
     assert abs(float(loss) - want) < 2e-5 * want
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# DNSplatterModel.get_outputs executed from the reference's own text (reference_get_outputs.npz): pins A0 (what is
+# handed to gsplat.rasterization), A7 (per-Gaussian normals, dn_model.py:543-560) and A9 (the per-pixel post-ops,
+# dn_model.py:526-537, 577-578) — values and autograd gradients — to the reference instead of to our restatement.
+
+
+def _reference_frame():
+    from dn_splatter_amd.model import Camera
+
+    g = _load("reference_get_outputs.npz")
+    params = {k[6:]: torch.from_numpy(g[k]).clone() for k in g.files if k.startswith("param_")}
+    cam = Camera(torch.from_numpy(g["c2w"]), float(g["fx"]), float(g["fy"]), float(g["cx"]), float(g["cy"]), int(g["W"]), int(g["H"]))
+    return g, params, cam
+
+
+def test_host_mirror_equals_get_outputs_of_the_reference():
+    """model.DNSplatterRenderer.get_outputs(fused=False) around the same two stand-ins for the gsplat calls: every
+    argument it hands to them, every output image and every gradient equals what the reference's own method produced."""
+    import dn_splatter_amd as dns
+
+    g, params, cam = _reference_frame()
+    N, W, H = int(g["N"]), int(g["W"]), int(g["H"])
+    params = {k: v.requires_grad_(True) for k, v in params.items()}
+    render = torch.from_numpy(g["render"]).requires_grad_(True)
+    alpha = torch.from_numpy(g["alpha"]).requires_grad_(True)
+    mix = torch.from_numpy(g["mix"])
+    calls = {}
+
+    def rasterization(**kw):
+        calls["rasterization"] = kw
+        info = {"means2d": torch.zeros(1, N, 2, requires_grad=True), "radii": torch.ones(1, N, dtype=torch.int32),
+                "depths": torch.ones(1, N), "conics": torch.ones(1, N, 3), "tiles_per_gauss": torch.ones(1, N, dtype=torch.int32)}
+        return render, alpha, info
+
+    def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width, block_width,
+                            background=None, return_alpha=False):
+        colors.retain_grad()
+        calls["legacy"] = dict(xys=xys, colors=colors, opacity=opacity, background=background, block_width=block_width)
+        return (mix @ colors).reshape(img_height, img_width, 3) + 0.2
+
+    m = dns.DNSplatterRenderer(params, fused=False, rasterization_fn=rasterization, rasterize_gaussians_fn=rasterize_gaussians)
+    m.step = int(g["step"])
+    out = m.get_outputs(cam)
+    kw = calls["rasterization"]
+    close = lambda a, b, tol=2e-6: float((torch.as_tensor(a).detach() - torch.from_numpy(np.asarray(b))).abs().max()) <= tol * max(1.0, float(np.abs(b).max()))  # noqa: E731
+    # A0: the activations and the call arguments (dn_model.py:495-513)
+    for key in ("quats", "scales", "opacities", "colors", "viewmats", "Ks"):
+        assert kw[key].shape == g["call_" + key].shape, key
+        assert close(kw[key], g["call_" + key]), "rasterization argument " + key
+    assert kw["sh_degree"] == int(g["call_sh_degree"])
+    assert [kw["width"], kw["height"], kw["tile_size"], kw["near_plane"], kw["far_plane"]] == list(g["call_scalars"])
+    assert [kw["packed"], kw["sparse_grad"], kw["absgrad"], kw["render_mode"] == "RGB+ED", kw["rasterize_mode"] == "classic"] == list(g["call_flags"])
+    # A7: the per-Gaussian normals handed to the legacy pass and stored in gauss_params (dn_model.py:543-575)
+    lg = calls["legacy"]
+    assert close(lg["colors"], g["normals_cam"]) and close(params["normals"], g["normals_world"])
+    assert close(lg["opacity"], g["legacy_opacity"])
+    assert lg["xys"].requires_grad == bool(g["legacy_xys_requires_grad"]) and (lg["background"] is None) == bool(g["legacy_background_is_none"])
+    assert lg["block_width"] == int(g["legacy_block_width"])
+    # A9 / A12: the output dict (dn_model.py:605-612)
+    for k in ("rgb", "depth", "normal", "surface_normal", "accumulation", "background"):
+        assert out[k].shape == g["out_" + k].shape, k
+        assert close(out[k], g["out_" + k]), k
+    keys = ("rgb", "depth", "normal", "accumulation")
+    torch.autograd.backward([out[k] for k in keys], [torch.from_numpy(g["cot_" + k]) for k in keys])
+    assert close(render.grad, g["v_render"]) and close(alpha.grad, g["v_alpha"])
+    assert close(lg["colors"].grad, g["v_normals_cam"]) and close(params["quats"].grad, g["v_quats"], 1e-5)
+    for k, none in zip(("means", "scales", "features_dc", "features_rest", "opacities"), g["grad_is_none"]):
+        assert (params[k].grad is None) == bool(none), k
+
+
+@pytest.mark.gpu
+def test_hip_gaussian_normals_equal_the_reference():
+    """A7 in the projection kernels: normals_world (dn_model.py:558) and the camera-frame normal channels of the splat
+    records == what the reference's text derived, and dnsplat_project_bwd turns the reference's cotangent of those normals
+    into the reference's quaternion gradient (visible Gaussians: the real second pass gives culled ones no gradient)."""
+    from dn_splatter_amd import _ops, fused
+    from dn_splatter_amd._ops import ProjCfg
+
+    g, params, cam = _reference_frame()
+    dev = "cuda:0"
+    N, W, H = int(g["N"]), int(g["W"]), int(g["H"])
+    p = {k: v.to(dev).requires_grad_(True) for k, v in params.items()}
+    c2w = cam.camera_to_worlds.to(dev)
+    viewmat, K, nf = _ops.camera_prepare(c2w[0], cam.fx, cam.fy, cam.cx, cam.cy)
+    assert float((viewmat.cpu() - torch.from_numpy(g["call_viewmats"][0])).abs().max()) < 2e-6
+    assert float((K.cpu() - torch.from_numpy(g["call_Ks"][0])).abs().max()) < 2e-6
+    assert float((nf.cpu() - fused.normal_frame_from_c2w(c2w[0]).cpu()).abs().max()) < 1e-6
+    cfg = ProjCfg(width=W, height=H, scales_are_log=True, opacities_are_logit=True, sh_degree=int(g["call_sh_degree"]),
+                  with_depth=True, with_normals=True, want_normals_world=True)
+    pr = _ops.project(p["means"], p["quats"], p["scales"], p["opacities"].reshape(N), sh0=p["features_dc"], shN=p["features_rest"],
+                      viewmat=viewmat, K=K, normal_frame=nf, cfg=cfg)
+    vis = (pr["radii"] > 0).cpu()
+    assert 40 <= int(vis.sum()) < N
+    assert float((pr["normals_world"].cpu() - torch.from_numpy(g["normals_world"])).abs().max()) < 2e-6
+    rec = pr["splats"].detach().cpu()
+    assert float((rec[vis][:, 10:13] - torch.from_numpy(g["normals_cam"])[vis]).abs().max()) < 2e-6
+    # A0 inside the kernel: opacity column = sigmoid(logit) as the reference hands it to gsplat
+    assert float((rec[vis][:, 5] - torch.from_numpy(g["call_opacities"])[vis]).abs().max()) < 2e-6
+    # backward: only the normal channels carry a cotangent
+    v = torch.zeros(N, 16, device=dev)
+    v[:, 10:13] = torch.from_numpy(g["v_normals_cam"]).to(dev)
+    pr["splats"].backward(v)
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(g["v_quats"])
+    got = p["quats"].grad.cpu()
+    assert float((got[vis] - ref[vis]).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+    assert float(got[~vis].abs().max()) == 0.0
+    for k in ("means", "scales", "opacities"):
+        assert float(p[k].grad.abs().max()) == 0.0, k      # argmin / flip are not differentiable, means are detached (dn_model.py:551)
+
+
+@pytest.mark.gpu
+def test_hip_postops_equal_the_reference_pinned_torch_postops():
+    """A9 in the compositing kernels: the HIP epilogue / backward prologue (fused_postops=True) against the torch post-ops
+    of the host mirror — the code test_host_mirror_equals_get_outputs_of_the_reference pins to the reference's text — on
+    the SAME raw composite (same fused pass, same GPU), values and gradients."""
+    import dn_splatter_amd as dns
+    from dn_splatter_amd import synthetic
+
+    dev = "cuda:0"
+    N, W, H = 20_000, 320, 240
+    gp = synthetic.make_gauss_params(N, sh_rest_std=0.3, seed=4)
+    gp["features_dc"] = gp["features_dc"].detach() * 3 - 1          # colours beyond both corners of clamp(rgb, 0, 1)
+    gp["scales"] = gp["scales"].detach() + torch.randn(N, 3, generator=torch.Generator().manual_seed(5)) * 0.5
+    gp["scales"][: N // 2] -= 1.5                                   # leaves holes: alpha == 0 pixels take the depth fill
+    cam = synthetic.orbit_camera(2, width=W, height=H, focal=200.0).to(dev)
+    keys = ("rgb", "depth", "normal", "accumulation")
+    gen = torch.Generator().manual_seed(6)
+    cot = None
+    res = {}
+    for mode in (False, True):
+        p = {k: v.detach().to(dev).clone().requires_grad_(k != "normals") for k, v in gp.items()}
+        out = dns.DNSplatterRenderer(p, fused=True, fused_postops=mode).get_outputs(cam)
+        if cot is None:
+            cot = {k: (torch.rand(out[k].shape, generator=gen) * 2 - 1).to(dev) for k in keys}
+        torch.autograd.backward([out[k] for k in keys], [cot[k] for k in keys])
+        res[mode] = (out, p)
+    torch.cuda.synchronize()
+    acc = res[False][0]["accumulation"]
+    assert float((acc == 0).float().mean()) > 0.01 and float((res[False][0]["rgb"] == 1).float().mean()) > 0.001
+    for k in keys + ("surface_normal",):
+        a, b = res[True][0][k], res[False][0][k]
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max())), k
+    for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities"):
+        a, b = res[True][1][k].grad, res[False][1][k].grad
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()), k
