@@ -14,7 +14,8 @@ from ctypes import c_float, c_int32, c_int64, c_size_t, c_void_p
 from pathlib import Path
 
 _PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = _PKG_DIR / "libdnsplat.so"
+# DNSPLAT_LIB: load another build of the same library (kernel A/B runs, tools/ab_libs.sh); never a fallback
+LIB_PATH = Path(os.environ["DNSPLAT_LIB"]).resolve() if os.environ.get("DNSPLAT_LIB") else _PKG_DIR / "libdnsplat.so"
 CSRC_DIR = _PKG_DIR / "csrc"
 
 ABI_VERSION = 4
@@ -127,6 +128,8 @@ _lib = None
 def build(force: bool = False) -> Path:
     """Compile the HIP sources for gfx950 into ``libdnsplat.so`` next to this file (hipcc cross-compiles
     without a GPU)."""
+    if os.environ.get("DNSPLAT_LIB"):
+        return LIB_PATH
     srcs = list(CSRC_DIR.glob("*.hip")) + list(CSRC_DIR.glob("*.h")) + list((_PKG_DIR.parent / "include").glob("*.h"))
     stale = force or not LIB_PATH.exists() or any(s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs)
     if stale:

@@ -300,11 +300,10 @@ class _ProjectFn(torch.autograd.Function):
         g.v_means2d, g.v_depths, g.v_conics, g.v_compensations = _ptr(v_m2d), _ptr(v_dep), _ptr(v_con), _ptr(v_cmp)
         g.v_means, g.v_quats, g.v_scales, g.v_opacities = _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac)
         ex = SH_EXCHANGE
-        # only the model's own split layout (features_dc / features_rest as leaf parameters in the bucket): with the
-        # concatenated gsplat layout the coefficient gradient is an intermediate autograd tensor that
-        # dp.allreduce_gradients cannot reach, so the kernel writes the rows itself
-        if (ex is not None and ctx.layout == "split" and sh_K == 16 and GRAD_ARENA is not None
-                and GRAD_ARENA.holds(v_sh0) and GRAD_ARENA.holds(v_shN)):
+        # Only the model's own split layout (features_dc / features_rest are the leaf parameters dp.allreduce_gradients
+        # rebuilds into).  With the concatenated gsplat layout the coefficient gradient is an intermediate autograd tensor
+        # that nobody could fill in afterwards, so the kernel writes the rows itself.
+        if ex is not None and ctx.layout == "split" and sh_K == 16:
             # The coefficient-gradient tensors are handed to autograd unwritten; dp.allreduce_gradients fills them.  The
             # factors come from their own small kernel so that their all-gather is already under way while the geometry
             # gradients are computed below.

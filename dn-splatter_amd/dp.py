@@ -90,6 +90,10 @@ class ShFactorExchange:
     def begin(self, N, device, sh_degree, sh_K, v_coeffs=None, v_sh0=None, v_shN=None) -> Tensor:
         """Called by the projection backward: returns the [N,6] buffer the factors go to and remembers the shape of the
         gradients to rebuild."""
+        if self.meta is not None:
+            raise RuntimeError("ShFactorExchange: the factors of the previous backward were never rebuilt — with set_sh_exchange() "
+                               "active every backward must be followed by dp.allreduce_gradients(..., exchange=...) (or "
+                               "exchange.finish()); until then features_dc.grad / features_rest.grad are unwritten")
         if self.mine is None or self.mine.shape[0] != N or self.mine.device != device:
             self.mine = torch.empty(N, 6, dtype=torch.float32, device=device)
         # no tensor references are kept here: autograd only adopts the returned gradient tensors as .grad (instead of

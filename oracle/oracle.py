@@ -128,6 +128,20 @@ def project_fwd(means, quats, scales, viewmat, K, width, height, eps2d=0.3, near
     return radii, means2d, depths, conics, comp, tiles
 
 
+def project_edge(means, quats, scales, viewmat, K, width, height, eps2d=0.3, near_plane=0.01, far_plane=1e10,
+                 radius_clip=0.0, tile_size=16):
+    """bool [N]: Gaussians whose integer outputs hinge on a comparison inside the fp32 rounding envelope of the activated
+    inputs (orc_project_edge).  Only needed by parity tests that hand both sides RAW parameters."""
+    N = means.shape[0]
+    edge = torch.zeros(N, dtype=torch.uint8)
+    fn = getattr(lib(), "orc_project_edge_" + _suffix(means))
+    fn(ctypes.c_int(N), _p(means.contiguous()), _p(quats.contiguous()), _p(scales.contiguous()),
+       _p(viewmat.contiguous()), _p(K.contiguous()), ctypes.c_int(width), ctypes.c_int(height),
+       _real(means, eps2d), _real(means, near_plane), _real(means, far_plane), _real(means, radius_clip),
+       ctypes.c_int(tile_size), _p(edge))
+    return edge.bool()
+
+
 def project_bwd(means, quats, scales, viewmat, K, width, height, eps2d, near_plane, far_plane,
                 radius_clip, radii, v_means2d, v_depths, v_conics, v_compensations=None):
     N = means.shape[0]
@@ -360,8 +374,11 @@ def rasterization(
         "tiles_per_gauss": tiles[None], "isect_ids": isect_ids, "flatten_ids": flatten_ids,
         "isect_offsets": isect_offsets[None], "width": width, "height": height, "tile_size": tile_size,
         "n_cameras": 1,
-        # not a gsplat key: pixels whose skip / stop / clamp decisions fell inside the fp32 rounding envelope
+        # not gsplat keys: pixels whose skip / stop / clamp decisions fell inside the fp32 rounding envelope, and
+        # Gaussians whose integer outputs hinge on the last place of the activated inputs
         "borderline": borderline.bool(),
+        "edge_gaussians": project_edge(means.detach(), quats.detach(), scales.detach(), viewmat, K, width, height, eps2d,
+                                       near_plane, far_plane, radius_clip, tile_size),
     }
     return render[None], alphas[None, ..., None], meta
 

@@ -1,0 +1,22 @@
+#!/usr/bin/env bash
+# Cross-compiles a VARIANT of libdnsplat.so (extra -D flags) into gpurun_ab/lib_<name>.so, here in the CPU container;
+# gpurun_ab/ travels with the snapshot, so a GPU call only has to time the libraries (tools/ab_libs.sh).
+#   tools/build_variant.sh base ""            tools/build_variant.sh sym "-DDNS_EXP_SYM=1"
+set -euo pipefail
+NAME=$1; FLAGS=${2:-}
+cd "$(dirname "$0")/../dn-splatter_amd/csrc"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $FLAGS"
+O=../../gpurun_ab/_obj_$NAME; mkdir -p $O
+pids=()
+$HIPCC $COMMON -ffp-contract=off -c project.hip    -o $O/project.o & pids+=($!)
+$HIPCC $COMMON                   -c binning.hip    -o $O/binning.o & pids+=($!)
+$HIPCC $COMMON                   -c raster_fwd.hip -o $O/raster_fwd.o & pids+=($!)
+$HIPCC $COMMON -fno-slp-vectorize -c raster_bwd.hip -o $O/raster_bwd.o & pids+=($!)
+$HIPCC $COMMON                   -c c_api.hip      -o $O/c_api.o & pids+=($!)
+$HIPCC $COMMON -ffp-contract=off -c postops.hip    -o $O/postops.o & pids+=($!)
+$HIPCC $COMMON                   -c losses.hip     -o $O/losses.o & pids+=($!)
+for p in "${pids[@]}"; do wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC $O/*.o -o ../../gpurun_ab/lib_$NAME.so
+rm -rf $O
+echo "built gpurun_ab/lib_$NAME.so ($FLAGS)"
