@@ -18,7 +18,7 @@ _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["DNSPLAT_LIB"]).resolve() if os.environ.get("DNSPLAT_LIB") else _PKG_DIR / "libdnsplat.so"
 CSRC_DIR = _PKG_DIR / "csrc"
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 RECORD_FLOATS = 16
 MAX_CHANNELS = 8
 
@@ -59,7 +59,7 @@ class ProjOut(ctypes.Structure):
 
 class BinArgs(ctypes.Structure):
     _fields_ = [
-        ("N", c_int32), ("width", c_int32), ("height", c_int32), ("tile_size", c_int32),
+        ("N", c_int32), ("n_cameras", c_int32), ("width", c_int32), ("height", c_int32), ("tile_size", c_int32),
         ("means2d", c_void_p), ("radii", c_void_p), ("depths", c_void_p), ("tiles_per_gauss", c_void_p),
         ("isect_capacity", c_int64),
         ("flatten_ids", c_void_p), ("tile_offsets", c_void_p),
@@ -73,6 +73,18 @@ class DnPost(ctypes.Structure):
         ("background_rgb", c_void_p), ("rgb", c_void_p), ("depth", c_void_p), ("normal", c_void_p),
         ("depth_max", c_void_p),
         ("v_rgb", c_void_p), ("v_depth", c_void_p), ("v_normal", c_void_p), ("v_accumulation", c_void_p),
+    ]
+
+
+class DensifyArgs(ctypes.Structure):
+    _fields_ = [
+        ("N", c_int32), ("scales", c_void_p), ("opacities", c_void_p), ("xys_grad_norm", c_void_p), ("vis_counts", c_void_p),
+        ("max_2Dsize", c_void_p),
+        ("do_densify", c_int32), ("screen_rules", c_int32), ("cull_big", c_int32),
+        ("max_image_side", c_float),
+        ("densify_grad_thresh", c_float), ("densify_size_thresh", c_float), ("split_screen_size", c_float),
+        ("cull_alpha_thresh", c_float), ("cull_scale_thresh", c_float), ("cull_screen_size", c_float),
+        ("flags", c_void_p),
     ]
 
 
@@ -96,6 +108,7 @@ class RasterArgs(ctypes.Structure):
         ("xy_split", c_int32),
         ("v_splats", c_void_p),
         ("dn", ctypes.POINTER(DnPost)),
+        ("n_cameras", c_int32), ("pair_counters", c_void_p),
     ]
 
 
@@ -118,7 +131,8 @@ EXPORTS = [
     "dnsplat_project_fwd", "dnsplat_pack_splats",
     "dnsplat_bin_workspace_bytes", "dnsplat_bin_prepare", "dnsplat_bin_emit_sort", "dnsplat_bin_isect_ids",
     "dnsplat_raster_fwd", "dnsplat_raster_bwd",
-    "dnsplat_dn_depth_normals", "dnsplat_camera_prepare", "dnsplat_densify_stats", "dnsplat_dn_loss", "dnsplat_sh_grads_from_factors", "dnsplat_sh_factors",
+    "dnsplat_dn_depth_normals", "dnsplat_camera_prepare", "dnsplat_densify_stats", "dnsplat_densify_classify",
+    "dnsplat_densify_split", "dnsplat_dn_loss", "dnsplat_sh_grads_from_factors", "dnsplat_sh_factors",
     "dnsplat_project_bwd",
 ]
 
@@ -157,7 +171,10 @@ def lib() -> ctypes.CDLL:
         L.dnsplat_pack_splats.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]
         L.dnsplat_bin_prepare.argtypes = [ctypes.POINTER(BinArgs), c_void_p]
         L.dnsplat_bin_emit_sort.argtypes = [ctypes.POINTER(BinArgs), c_void_p]
-        L.dnsplat_bin_isect_ids.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
+        L.dnsplat_bin_isect_ids.argtypes = [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
+        L.dnsplat_densify_classify.argtypes = [ctypes.POINTER(DensifyArgs), c_void_p]
+        L.dnsplat_densify_split.argtypes = [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p]
         L.dnsplat_raster_fwd.argtypes = [ctypes.POINTER(RasterArgs), c_void_p]
         L.dnsplat_raster_bwd.argtypes = [ctypes.POINTER(RasterArgs), c_void_p]
         L.dnsplat_dn_depth_normals.argtypes = [c_int32, c_int32, c_float, c_float, c_float, c_float, c_void_p, c_void_p,

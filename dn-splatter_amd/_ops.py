@@ -213,24 +213,34 @@ class _ProjectFn(torch.autograd.Function):
         if normal_frame is not None:
             normal_frame = _f32c(normal_frame, "normal_frame")
 
-        radii = torch.empty(N, dtype=torch.int32, device=dev)
-        tiles = torch.empty(N, dtype=torch.int32, device=dev)
-        means2d = torch.empty(1, N, 2, dtype=torch.float32, device=dev)
-        depths = torch.empty(1, N, dtype=torch.float32, device=dev)
-        conics = torch.empty(1, N, 3, dtype=torch.float32, device=dev)
-        comp = torch.empty(1, N, dtype=torch.float32, device=dev) if cfg.antialiased else None
-        splats = torch.empty(N, RECORD_FLOATS, dtype=torch.float32, device=dev)
-        nworld = torch.empty(N, 3, dtype=torch.float32, device=dev) if cfg.want_normals_world else None
+        # one launch per camera of the batch (C = 1 in training, dn_model.py:421; C > 1 for the batched render loops of the
+        # offline consumers): per-camera outputs are the rows of [C,N,...] tensors, the records of camera c are rows
+        # c*N .. (c+1)*N of one [C*N,16] buffer — the layout dnsplat_bin_* / dnsplat_raster_* take for a batch
+        viewmat = viewmat.reshape(-1, 4, 4)
+        K = K.reshape(-1, 3, 3)
+        C = viewmat.shape[0]
+        if normal_frame is not None:
+            normal_frame = normal_frame.reshape(-1, 12)
+        radii = torch.empty(C, N, dtype=torch.int32, device=dev)
+        tiles = torch.empty(C, N, dtype=torch.int32, device=dev)
+        means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
+        depths = torch.empty(C, N, dtype=torch.float32, device=dev)
+        conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
+        comp = torch.empty(C, N, dtype=torch.float32, device=dev) if cfg.antialiased else None
+        splats = torch.empty(C * N, RECORD_FLOATS, dtype=torch.float32, device=dev)
+        nworld = torch.empty(C, N, 3, dtype=torch.float32, device=dev) if cfg.want_normals_world else None
 
         scene = _scene_struct(N, means, quats, scales, opacities, cfg, p_sh0, s0, p_shN, sN, sh_K, colors)
-        cam = _camera_struct(viewmat, K, normal_frame, cfg)
-        out = ProjOut()
-        out.radii, out.means2d, out.depths, out.conics = _ptr(radii), _ptr(means2d), _ptr(depths), _ptr(conics)
-        out.compensations, out.tiles_per_gauss, out.splats = _ptr(comp), _ptr(tiles), _ptr(splats)
-        out.normals_world = _ptr(nworld)
-        out.with_depth_channel = int(cfg.with_depth)
-        out.with_normal_channels = int(cfg.with_normals)
-        _lib.run("dnsplat_project_fwd", _lib.lib().dnsplat_project_fwd, ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(out), _stream())
+        for c in range(C):
+            cam = _camera_struct(viewmat[c], K[c], None if normal_frame is None else normal_frame[c], cfg)
+            out = ProjOut()
+            out.radii, out.means2d, out.depths, out.conics = _ptr(radii[c]), _ptr(means2d[c]), _ptr(depths[c]), _ptr(conics[c])
+            out.compensations = _ptr(comp[c]) if comp is not None else None
+            out.tiles_per_gauss, out.splats = _ptr(tiles[c]), _ptr(splats[c * N:])
+            out.normals_world = _ptr(nworld[c]) if nworld is not None else None
+            out.with_depth_channel = int(cfg.with_depth)
+            out.with_normal_channels = int(cfg.with_normals)
+            _lib.run("dnsplat_project_fwd", _lib.lib().dnsplat_project_fwd, ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(out), _stream())
 
         ctx.cfg = cfg
         ctx.sh_K = sh_K
@@ -249,9 +259,10 @@ class _ProjectFn(torch.autograd.Function):
         means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, radii, splats_fwd = ctx.saved_tensors
         cfg: ProjCfg = ctx.cfg
         N = means.shape[0]
+        C = viewmat.shape[0]
         dev = means.device
         if v_splats is None:
-            v_splats = torch.zeros(N, RECORD_FLOATS, dtype=torch.float32, device=dev)
+            v_splats = torch.zeros(C * N, RECORD_FLOATS, dtype=torch.float32, device=dev)
         v_splats = v_splats.contiguous()
         # means2d's gradient normally IS columns 0-1 of the record (see _RasterFn.backward); only when the
         # caller hung extra terms on info["means2d"] does a separate tensor arrive.
@@ -259,71 +270,82 @@ class _ProjectFn(torch.autograd.Function):
         if v_means2d is not None:
             same = (v_means2d.data_ptr() == v_splats.data_ptr() and v_means2d.stride()[-2:] == (RECORD_FLOATS, 1))
             if not same:
-                v_m2d = v_means2d.reshape(N, 2).contiguous()
-        v_dep = v_depths.reshape(N).contiguous() if v_depths is not None else None
-        v_con = v_conics.reshape(N, 3).contiguous() if v_conics is not None else None
-        v_cmp = v_comp.reshape(N).contiguous() if (v_comp is not None and cfg.antialiased) else None
-
-        v_means = _grad_like(means)
-        v_quats = _grad_like(quats)
-        v_scales = _grad_like(scales)
-        v_opac = _grad_like(opacities)
+                v_m2d = v_means2d.reshape(C, N, 2).contiguous()
+        v_dep = v_depths.reshape(C, N).contiguous() if v_depths is not None else None
+        v_con = v_conics.reshape(C, N, 3).contiguous() if v_conics is not None else None
+        v_cmp = v_comp.reshape(C, N).contiguous() if (v_comp is not None and cfg.antialiased) else None
         sh_K = ctx.sh_K
-        p_sh0 = p_shN = None
-        s0 = sN = 0
-        g = ProjGrads()
-        v_coeffs = v_sh0 = v_shN = v_colors = None
-        if ctx.layout == "cat":
-            p_sh0, s0 = coeffs, 3 * sh_K
-            p_shN, sN = coeffs.view(-1)[3:], 3 * sh_K
-            v_coeffs = torch.empty_like(coeffs)
-            g.v_sh0, g.v_sh0_stride = _ptr(v_coeffs), 3 * sh_K
-            g.v_shN, g.v_shN_stride = _ptr(v_coeffs.view(-1)[3:]), 3 * sh_K
-        elif ctx.layout == "split":
-            p_sh0, s0 = sh0, 3
-            v_sh0 = _grad_like(sh0)
-            g.v_sh0, g.v_sh0_stride = _ptr(v_sh0), 3
-            if sh_K > 1:
-                p_shN, sN = shN, 3 * (sh_K - 1)
-                v_shN = _grad_like(shN)
-                g.v_shN, g.v_shN_stride = _ptr(v_shN), 3 * (sh_K - 1)
-        elif colors is not None:
-            v_colors = torch.empty_like(colors)
-            g.v_colors = _ptr(v_colors)
-
-        scene = _scene_struct(N, means, quats, scales, opacities, cfg, p_sh0, s0, p_shN, sN, sh_K, colors)
-        cam = _camera_struct(viewmat, K, normal_frame, cfg)
-        fwd = ProjOut()
-        fwd.with_depth_channel = int(cfg.with_depth)
-        fwd.with_normal_channels = int(cfg.with_normals)
-        g.radii, g.v_splats = _ptr(radii), _ptr(v_splats)
-        g.v_means2d, g.v_depths, g.v_conics, g.v_compensations = _ptr(v_m2d), _ptr(v_dep), _ptr(v_con), _ptr(v_cmp)
-        g.v_means, g.v_quats, g.v_scales, g.v_opacities = _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac)
-        ex = SH_EXCHANGE
-        # Only the model's own split layout (features_dc / features_rest are the leaf parameters dp.allreduce_gradients
-        # rebuilds into).  With the concatenated gsplat layout the coefficient gradient is an intermediate autograd tensor
-        # that nobody could fill in afterwards, so the kernel writes the rows itself.
-        if ex is not None and ctx.layout == "split" and sh_K == 16:
-            # The coefficient-gradient tensors are handed to autograd unwritten; dp.allreduce_gradients fills them.  The
-            # factors come from their own small kernel so that their all-gather is already under way while the geometry
-            # gradients are computed below.
-            fac = ex.begin(N, dev, cfg.sh_degree, sh_K)
-            _lib.run("dnsplat_sh_factors", _lib.lib().dnsplat_sh_factors, N, _ptr(means), _ptr(radii), _ptr(viewmat), _ptr(splats_fwd),
-                     _ptr(v_splats), _ptr(fac), _stream())
-            ex.launch()
-            g.sh_grads_skip = 1
-        _lib.run("dnsplat_project_bwd", _lib.lib().dnsplat_project_bwd, ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(fwd),
-                                                  ctypes.byref(g), _stream())
         need = ctx.needs_input_grad
-        return (v_means if need[0] else None, v_quats if need[1] else None, v_scales if need[2] else None,
-                v_opac if need[3] else None, v_coeffs if need[4] else None, v_sh0 if need[5] else None,
-                v_shN if need[6] else None, v_colors if need[7] else None, None, None, None, None)
+        total = None      # running sum over the cameras of a batch (C > 1); a single camera writes its outputs directly
+
+        for c in range(C):
+            v_means = _grad_like(means) if C == 1 else torch.empty_like(means)
+            v_quats = _grad_like(quats) if C == 1 else torch.empty_like(quats)
+            v_scales = _grad_like(scales) if C == 1 else torch.empty_like(scales)
+            v_opac = _grad_like(opacities) if C == 1 else torch.empty_like(opacities)
+            p_sh0 = p_shN = None
+            s0 = sN = 0
+            g = ProjGrads()
+            v_coeffs = v_sh0 = v_shN = v_colors = None
+            if ctx.layout == "cat":
+                p_sh0, s0 = coeffs, 3 * sh_K
+                p_shN, sN = coeffs.view(-1)[3:], 3 * sh_K
+                v_coeffs = torch.empty_like(coeffs)
+                g.v_sh0, g.v_sh0_stride = _ptr(v_coeffs), 3 * sh_K
+                g.v_shN, g.v_shN_stride = _ptr(v_coeffs.view(-1)[3:]), 3 * sh_K
+            elif ctx.layout == "split":
+                p_sh0, s0 = sh0, 3
+                v_sh0 = _grad_like(sh0) if C == 1 else torch.empty_like(sh0)
+                g.v_sh0, g.v_sh0_stride = _ptr(v_sh0), 3
+                if sh_K > 1:
+                    p_shN, sN = shN, 3 * (sh_K - 1)
+                    v_shN = _grad_like(shN) if C == 1 else torch.empty_like(shN)
+                    g.v_shN, g.v_shN_stride = _ptr(v_shN), 3 * (sh_K - 1)
+            elif colors is not None:
+                v_colors = torch.empty_like(colors)
+                g.v_colors = _ptr(v_colors)
+
+            scene = _scene_struct(N, means, quats, scales, opacities, cfg, p_sh0, s0, p_shN, sN, sh_K, colors)
+            cam = _camera_struct(viewmat[c], K[c], None if normal_frame is None else normal_frame[c], cfg)
+            fwd = ProjOut()
+            fwd.with_depth_channel = int(cfg.with_depth)
+            fwd.with_normal_channels = int(cfg.with_normals)
+            vs_c = v_splats[c * N:(c + 1) * N]
+            g.radii, g.v_splats = _ptr(radii[c]), _ptr(vs_c)
+            g.v_means2d = _ptr(v_m2d[c]) if v_m2d is not None else None
+            g.v_depths = _ptr(v_dep[c]) if v_dep is not None else None
+            g.v_conics = _ptr(v_con[c]) if v_con is not None else None
+            g.v_compensations = _ptr(v_cmp[c]) if v_cmp is not None else None
+            g.v_means, g.v_quats, g.v_scales, g.v_opacities = _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac)
+            ex = SH_EXCHANGE
+            # Only the model's own split layout (features_dc / features_rest are the leaf parameters dp.allreduce_gradients
+            # rebuilds into), one camera per rank.  With the concatenated gsplat layout the coefficient gradient is an
+            # intermediate autograd tensor that nobody could fill in afterwards, so the kernel writes the rows itself.
+            if ex is not None and ctx.layout == "split" and sh_K == 16 and C == 1:
+                # The coefficient-gradient tensors are handed to autograd unwritten; dp.allreduce_gradients fills them.  The
+                # factors come from their own small kernel so that their all-gather is already under way while the geometry
+                # gradients are computed below.
+                fac = ex.begin(N, dev, cfg.sh_degree, sh_K)
+                _lib.run("dnsplat_sh_factors", _lib.lib().dnsplat_sh_factors, N, _ptr(means), _ptr(radii[c]), _ptr(viewmat[c]),
+                         _ptr(splats_fwd), _ptr(vs_c), _ptr(fac), _stream())
+                ex.launch()
+                g.sh_grads_skip = 1
+            _lib.run("dnsplat_project_bwd", _lib.lib().dnsplat_project_bwd, ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(fwd),
+                     ctypes.byref(g), _stream())
+            outs = [v_means, v_quats, v_scales, v_opac, v_coeffs, v_sh0, v_shN, v_colors]
+            if total is None:
+                total = outs
+            else:
+                for acc, t in zip(total, outs):
+                    if acc is not None:
+                        acc.add_(t)
+        return tuple(t if (t is not None and need[i]) else None for i, t in enumerate(total)) + (None, None, None, None)
 
 
 def project(means, quats, scales, opacities, *, coeffs=None, sh0=None, shN=None, colors=None, viewmat, K,
             normal_frame=None, cfg: ProjCfg):
-    """-> dict(means2d[1,N,2], depths[1,N], conics[1,N,3], compensations, splats[N,16], radii[N], tiles[N],
-    normals_world)"""
+    """``viewmat`` [4,4] or [C,4,4] (``K``, ``normal_frame`` alike) -> dict(means2d[C,N,2], depths[C,N], conics[C,N,3],
+    compensations[C,N] | None, splats[C*N,16], radii[C,N], tiles_per_gauss[C,N], normals_world[C,N,3] | None)"""
     m2d, dep, con, comp, splats, radii, tiles, nworld = _ProjectFn.apply(
         means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, cfg)
     return dict(means2d=m2d, depths=dep, conics=con, compensations=comp if comp.numel() else None, splats=splats,
@@ -336,23 +358,24 @@ def project(means, quats, scales, opacities, *, coeffs=None, sh0=None, shN=None,
 
 @dataclass
 class Binning:
-    flatten_ids: Tensor      # [capacity] int32 (first n_isects valid)
-    tile_offsets: Tensor     # [T+1] int32
+    flatten_ids: Tensor      # [capacity] int32 (first n_isects valid); entry = camera * N + gaussian
+    tile_offsets: Tensor     # [C*T+1] int32
     n_isects: int
     tile_width: int
     tile_height: int
+    n_cameras: int = 1
 
 
 def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, width: int, height: int,
-              tile_size: int, after_emit=None) -> Binning:
-    """Stage 2.  ``after_emit(binning)`` (optional) is called right after the emit/sort kernels are
-    enqueued and BEFORE any host wait, so the caller can queue the compositing kernel behind them; in
-    "capacity" mode it is called again if the capacity guess turned out too small."""
+              tile_size: int, after_emit=None, n_cameras: int = 1) -> Binning:
+    """Stage 2 over ``n_cameras`` stacked projections (inputs flattened to [C*N, ...]).  ``after_emit(binning)`` (optional)
+    is called right after the emit/sort kernels are enqueued and BEFORE any host wait, so the caller can queue the
+    compositing kernel behind them; in "capacity" mode it is called again if the capacity guess turned out too small."""
     lib = _lib.lib()
     dev = means2d.device
-    N = radii.shape[0]
+    N = radii.numel()
     tw, th = math.ceil(width / tile_size), math.ceil(height / tile_size)
-    T = tw * th
+    T = tw * th * n_cameras
     n_dev = torch.empty(1, dtype=torch.int64, device=dev)
     n_host = BUFFERS.pinned_i64(dev)
     key = (dev, N, width, height)
@@ -361,7 +384,7 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
         nbytes = lib.dnsplat_bin_workspace_bytes(N, capacity, T)
         ws = BUFFERS.workspace(dev, nbytes)
         a = BinArgs()
-        a.N, a.width, a.height, a.tile_size = N, width, height, tile_size
+        a.N, a.n_cameras, a.width, a.height, a.tile_size = N, n_cameras, width, height, tile_size
         a.means2d, a.radii, a.depths, a.tiles_per_gauss = _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(tiles)
         a.isect_capacity = capacity
         a.flatten_ids, a.tile_offsets = _ptr(flatten_ids), _ptr(tile_offsets)
@@ -380,7 +403,7 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
         ev = torch.cuda.Event()
         ev.record()
         _lib.run("dnsplat_bin_emit_sort", _lib.lib().dnsplat_bin_emit_sort, ctypes.byref(args), _stream())
-        b = Binning(flatten_ids, tile_offsets, -1, tw, th)
+        b = Binning(flatten_ids, tile_offsets, -1, tw, th, n_cameras)
         if after_emit is not None:
             after_emit(b)
         ev.synchronize()  # waits for the (early) depth sort only; compositing keeps running
@@ -404,17 +427,17 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
     if ws1.data_ptr() != ws0.data_ptr():
         _lib.run("dnsplat_bin_prepare", _lib.lib().dnsplat_bin_prepare, ctypes.byref(args), _stream())
     _lib.run("dnsplat_bin_emit_sort", _lib.lib().dnsplat_bin_emit_sort, ctypes.byref(args), _stream())
-    b = Binning(flatten_ids, tile_offsets, n, tw, th)
+    b = Binning(flatten_ids, tile_offsets, n, tw, th, n_cameras)
     if after_emit is not None:
         after_emit(b)
     return b
 
 
 def isect_ids(b: Binning, depths: Tensor) -> Tensor:
-    """gsplat's 64-bit sorted keys (tile << 32 | depth bits), rebuilt on demand for the info dict."""
+    """gsplat's 64-bit sorted keys (camera | tile << 32 | depth bits), rebuilt on demand for the info dict."""
     out = torch.empty(max(b.n_isects, 1), dtype=torch.int64, device=depths.device)
-    _lib.run("dnsplat_bin_isect_ids", _lib.lib().dnsplat_bin_isect_ids, b.tile_width * b.tile_height, _ptr(b.tile_offsets), _ptr(b.flatten_ids),
-                                                _ptr(depths.reshape(-1)), _ptr(out), b.n_isects, _stream())
+    _lib.run("dnsplat_bin_isect_ids", _lib.lib().dnsplat_bin_isect_ids, b.tile_width * b.tile_height, b.n_cameras, _ptr(b.tile_offsets),
+             _ptr(b.flatten_ids), _ptr(depths.reshape(-1).contiguous()), _ptr(out), b.n_isects, _stream())
     return out[: b.n_isects]
 
 
@@ -431,13 +454,15 @@ class _RasterFn(torch.autograd.Function):
     def forward(ctx, means2d, splats, depths, radii, tiles, background, width, height, tile_size, D, ed_channel,
                 xy_split, absgrad, holder):
         dev = splats.device
-        render = torch.empty(height, width, D, dtype=torch.float32, device=dev)
-        alphas = torch.empty(height, width, dtype=torch.float32, device=dev)
-        last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
+        C = means2d.shape[0] if means2d.dim() == 3 else 1      # cameras of the batch: means2d [C,N,2], splats [C*N,16]
+        render = torch.empty(C, height, width, D, dtype=torch.float32, device=dev)
+        alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
+        last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
         bg = _f32c(background, "background") if background is not None else None
 
         def composite(b: Binning):
             a = RasterArgs()
+            a.n_cameras = C
             a.width, a.height, a.tile_size, a.D = width, height, tile_size, D
             a.splats, a.flatten_ids, a.tile_offsets = _ptr(splats), _ptr(b.flatten_ids), _ptr(b.tile_offsets)
             a.background = _ptr(bg)
@@ -445,21 +470,21 @@ class _RasterFn(torch.autograd.Function):
             a.render, a.alphas, a.last_ids = _ptr(render), _ptr(alphas), _ptr(last_ids)
             _lib.run("dnsplat_raster_fwd", _lib.lib().dnsplat_raster_fwd, ctypes.byref(a), _stream())
 
-        b = bin_tiles(means2d.detach().reshape(-1, 2), radii, depths.detach().reshape(-1), tiles, width, height,
-                      tile_size, after_emit=composite)
+        b = bin_tiles(means2d.detach().reshape(-1, 2), radii.reshape(-1), depths.detach().reshape(-1), tiles.reshape(-1), width,
+                      height, tile_size, after_emit=composite, n_cameras=C)
         if holder is not None:
             holder["binning"] = b
         ctx.save_for_backward(means2d, splats, b.flatten_ids, b.tile_offsets, render, alphas, last_ids)
         ctx.bg = bg
-        ctx.cfg = (width, height, tile_size, D, ed_channel, xy_split, absgrad)
+        ctx.cfg = (width, height, tile_size, D, ed_channel, xy_split, absgrad, C)
         ctx.set_materialize_grads(False)
         return render, alphas
 
     @staticmethod
     def backward(ctx, v_render, v_alphas):
         means2d, splats, flatten_ids, tile_offsets, render, alphas, last_ids = ctx.saved_tensors
-        width, height, tile_size, D, ed_channel, xy_split, absgrad = ctx.cfg
-        N = splats.shape[0]
+        width, height, tile_size, D, ed_channel, xy_split, absgrad, C = ctx.cfg
+        N = splats.shape[0]                      # records of the whole batch (cameras x Gaussians)
         dev = splats.device
         v_splats = torch.zeros(N, RECORD_FLOATS, dtype=torch.float32, device=dev)
         if v_render is None and v_alphas is None:
@@ -469,6 +494,7 @@ class _RasterFn(torch.autograd.Function):
         v_render = v_render.contiguous()
         v_alphas = v_alphas.contiguous() if v_alphas is not None else None
         a = RasterArgs()
+        a.n_cameras = C
         a.width, a.height, a.tile_size, a.D = width, height, tile_size, D
         a.splats, a.flatten_ids, a.tile_offsets = _ptr(splats), _ptr(flatten_ids), _ptr(tile_offsets)
         a.background = _ptr(ctx.bg)
@@ -486,6 +512,7 @@ class _RasterFn(torch.autograd.Function):
 
 def rasterize(means2d, splats, depths, radii, tiles, *, background=None, width, height, tile_size=16, D,
               ed_channel=-1, xy_split=None, absgrad=False, holder=None):
+    """-> render [C,H,W,D], alphas [C,H,W] for the C cameras of ``means2d`` [C,N,2] / ``splats`` [C*N,16]."""
     if tile_size != 16:
         raise NotImplementedError("libdnsplat composites 16x16 tiles (dn_model.py:470-472 uses BLOCK_WIDTH = 16)")
     if xy_split is None:
@@ -516,42 +543,47 @@ class _RasterDnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, splats, depths, radii, tiles, bg_rgb, width, height, intr, absgrad, holder):
         dev = splats.device
+        C = means2d.shape[0]                     # cameras of the batch; intr = [(fx, fy, cx, cy)] * C
         f32 = dict(dtype=torch.float32, device=dev)
-        render = torch.empty(height, width, 7, **f32)
-        alphas = torch.empty(height, width, **f32)
-        last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
-        rgb = torch.empty(height, width, 3, **f32)
-        depth_raw = torch.empty(height, width, **f32)
-        normal = torch.empty(height, width, 3, **f32)
-        depth_max = torch.zeros(1, **f32)
-        depth_out = torch.empty(height, width, 1, **f32)
-        surface_normal = torch.empty(height, width, 3, **f32)
+        render = torch.empty(C, height, width, 7, **f32)
+        alphas = torch.empty(C, height, width, **f32)
+        last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
+        rgb = torch.empty(C, height, width, 3, **f32)
+        depth_raw = torch.empty(C, height, width, **f32)
+        normal = torch.empty(C, height, width, 3, **f32)
+        depth_max = torch.zeros(C, **f32)
+        depth_out = torch.empty(C, height, width, 1, **f32)
+        surface_normal = torch.empty(C, height, width, 3, **f32)
         bg_rgb = _f32c(bg_rgb, "background")
         bg7 = _bg7(dev)
         dn = DnPost()
         dn.background_rgb, dn.rgb, dn.depth, dn.normal = _ptr(bg_rgb), _ptr(rgb), _ptr(depth_raw), _ptr(normal)
         dn.depth_max = _ptr(depth_max)
+        counters = holder.get("pair_counters") if holder is not None else None
 
         def composite(b: Binning):
             depth_max.zero_()
             a = RasterArgs()
+            a.n_cameras = C
             a.width, a.height, a.tile_size, a.D = width, height, 16, 7
             a.splats, a.flatten_ids, a.tile_offsets = _ptr(splats), _ptr(b.flatten_ids), _ptr(b.tile_offsets)
             a.background = _ptr(bg7)
             a.ed_channel = 3
             a.render, a.alphas, a.last_ids = _ptr(render), _ptr(alphas), _ptr(last_ids)
             a.dn = ctypes.pointer(dn)
+            a.pair_counters = _ptr(counters)
             _lib.run("dnsplat_raster_fwd", _lib.lib().dnsplat_raster_fwd, ctypes.byref(a), _stream())
 
-        b = bin_tiles(means2d.detach().reshape(-1, 2), radii, depths.detach().reshape(-1), tiles, width, height, 16,
-                      after_emit=composite)
-        fx, fy, cx, cy = intr
-        _lib.run("dnsplat_dn_depth_normals", _lib.lib().dnsplat_dn_depth_normals, width, height, fx, fy, cx, cy,
-                 _ptr(depth_raw), _ptr(alphas), _ptr(depth_max), _ptr(depth_out), _ptr(surface_normal), _stream())
+        b = bin_tiles(means2d.detach().reshape(-1, 2), radii.reshape(-1), depths.detach().reshape(-1), tiles.reshape(-1), width,
+                      height, 16, after_emit=composite, n_cameras=C)
+        for c in range(C):
+            fx, fy, cx, cy = intr[c]
+            _lib.run("dnsplat_dn_depth_normals", _lib.lib().dnsplat_dn_depth_normals, width, height, fx, fy, cx, cy,
+                     _ptr(depth_raw[c]), _ptr(alphas[c]), _ptr(depth_max[c:]), _ptr(depth_out[c]), _ptr(surface_normal[c]), _stream())
         if holder is not None:
             holder["binning"] = b
         ctx.save_for_backward(means2d, splats, b.flatten_ids, b.tile_offsets, render, alphas, last_ids, bg_rgb)
-        ctx.cfg = (width, height, absgrad)
+        ctx.cfg = (width, height, absgrad, C, counters)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(surface_normal)
         return rgb, depth_out, normal, alphas.unsqueeze(-1), surface_normal
@@ -559,20 +591,21 @@ class _RasterDnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_rgb, v_depth, v_normal, v_acc, _v_sn):
         means2d, splats, flatten_ids, tile_offsets, render, alphas, last_ids, bg_rgb = ctx.saved_tensors
-        width, height, absgrad = ctx.cfg
+        width, height, absgrad, C, counters = ctx.cfg
         N = splats.shape[0]
         dev = splats.device
         v_splats = torch.zeros(N, RECORD_FLOATS, dtype=torch.float32, device=dev)
         none = (None,) * 9
         if v_rgb is None and v_depth is None and v_normal is None and v_acc is None:
             return (v_splats[:, 0:2].view(means2d.shape), v_splats) + none
-        z = lambda t, c: torch.zeros(height, width, c, dtype=torch.float32, device=dev) if t is None else t.contiguous()  # noqa: E731
+        z = lambda t, c: torch.zeros(C, height, width, c, dtype=torch.float32, device=dev) if t is None else t.contiguous()  # noqa: E731
         v_rgb, v_depth, v_normal = z(v_rgb, 3), z(v_depth, 1), z(v_normal, 3)
         v_acc = v_acc.contiguous() if v_acc is not None else None
         dn = DnPost()
         dn.background_rgb = _ptr(bg_rgb)
         dn.v_rgb, dn.v_depth, dn.v_normal, dn.v_accumulation = _ptr(v_rgb), _ptr(v_depth), _ptr(v_normal), _ptr(v_acc)
         a = RasterArgs()
+        a.n_cameras = C
         a.width, a.height, a.tile_size, a.D = width, height, 16, 7
         a.splats, a.flatten_ids, a.tile_offsets = _ptr(splats), _ptr(flatten_ids), _ptr(tile_offsets)
         a.background = _ptr(_bg7(dev))
@@ -581,6 +614,7 @@ class _RasterDnFn(torch.autograd.Function):
         a.xy_split = 4
         a.v_splats = _ptr(v_splats)
         a.dn = ctypes.pointer(dn)
+        a.pair_counters = _ptr(counters)
         _lib.run("dnsplat_raster_bwd", _lib.lib().dnsplat_raster_bwd, ctypes.byref(a), _stream())
         if absgrad:
             means2d.absgrad = v_splats[:, 14:16].reshape(means2d.shape)
@@ -589,8 +623,13 @@ class _RasterDnFn(torch.autograd.Function):
 
 def rasterize_dn(means2d, splats, depths, radii, tiles, *, background_rgb, width, height, intrinsics, absgrad=True,
                  holder=None):
-    """-> rgb[H,W,3], depth[H,W,1], normal[H,W,3], accumulation[H,W,1], surface_normal[H,W,3]"""
-    return _RasterDnFn.apply(means2d, splats, depths, radii, tiles, background_rgb, width, height, intrinsics, absgrad,
+    """``intrinsics``: one (fx, fy, cx, cy) per camera of ``means2d`` [C,N,2].
+    -> rgb[C,H,W,3], depth[C,H,W,1], normal[C,H,W,3], accumulation[C,H,W,1], surface_normal[C,H,W,3].
+    ``holder["pair_counters"]`` (optional uint64 [8] device tensor) switches both compositing kernels to their measurement
+    instantiation (bench.py's VALU roofline)."""
+    if isinstance(intrinsics[0], (int, float)):
+        intrinsics = [tuple(intrinsics)]
+    return _RasterDnFn.apply(means2d, splats, depths, radii, tiles, background_rgb, width, height, list(intrinsics), absgrad,
                              holder)
 
 
@@ -604,6 +643,16 @@ def camera_prepare(c2w: Tensor, fx: float, fy: float, cx: float, cy: float, with
     _lib.run("dnsplat_camera_prepare", _lib.lib().dnsplat_camera_prepare, _ptr(c2w), fx, fy, cx, cy, _ptr(viewmat), _ptr(K),
              _ptr(nf) if with_normal_frame else None, _stream())
     return viewmat.view(4, 4), K.view(3, 3), (nf if with_normal_frame else None)
+
+
+def camera_prepare_batch(cameras, with_normal_frame: bool = True):
+    """camera_prepare for a list of camera records (``camera_to_worlds`` [1,3,4], fx, fy, cx, cy) ->
+    viewmats[C,4,4], Ks[C,3,3], normal_frames[C,12] | None."""
+    parts = [camera_prepare(c.camera_to_worlds, float(c.fx), float(c.fy), float(c.cx), float(c.cy), with_normal_frame) for c in cameras]
+    vm = torch.stack([p[0] for p in parts])
+    K = torch.stack([p[1] for p in parts])
+    nf = torch.stack([p[2] for p in parts]) if with_normal_frame else None
+    return vm, K, nf
 
 
 class _PackFn(torch.autograd.Function):

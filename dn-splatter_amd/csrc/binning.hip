@@ -319,7 +319,7 @@ __global__ __launch_bounds__(SC_THREADS) void scan_final_kernel(int N, const uin
 // than a wave), hence two per round and a float reciprocal instead of the integer division for (row, column):
 // floor((t + 0.5) / bw) is exact in fp32 for t < 2^16 tiles and bw <= 256 tile columns, far inside the 0.5 / bw margin.
 template <typename K>
-__global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__restrict__ order,
+__global__ __launch_bounds__(256) void emit_kernel(int N, int n_per_cam, const uint32_t *__restrict__ order,
                                                    const uint32_t *__restrict__ cum,
                                                    const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                                                    int tile_size, int tw, int th, uint32_t cap,
@@ -337,9 +337,12 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, const uint32_t *__rest
             int x1, y1;
             dns_tile_bbox(means2d[2 * gid], means2d[2 * gid + 1], (float)radii[gid], tile_size, tw, th, x0, y0, x1, y1);
             bw = x1 - x0;
+            // batch of cameras: entry gid belongs to camera gid / n_per_cam, whose tile grid is stacked below the previous
+            // cameras' (tile id = camera * tw * th + row * tw + column) — folded into the first tile row of the box
+            if (n_per_cam < N) y0 += (int)(gid / (uint32_t)n_per_cam) * th;
         }
     }
-    const bool exact = tw <= 256 && tw * th <= 65536;      // the fp32 reciprocal route is exact
+    const bool exact = tw <= 256 && (N / n_per_cam) * tw * th <= 65536;      // the fp32 reciprocal route is exact
     uint64_t todo = dns_ballot(end > start);
     const uint32_t half = lane >> 5, hl = lane & 31;
     while (todo) {
@@ -408,17 +411,19 @@ __global__ __launch_bounds__(TO_THREADS) void tile_offsets_fill_kernel(int n_til
     }
 }
 
-__global__ __launch_bounds__(256) void isect_ids_kernel(int n_tiles, const int32_t *__restrict__ offsets,
+__global__ __launch_bounds__(256) void isect_ids_kernel(int n_tiles, int tile_bits, const int32_t *__restrict__ offsets,
                                                         const int32_t *__restrict__ flatten_ids,
                                                         const float *__restrict__ depths, int64_t *__restrict__ isect_ids,
                                                         int64_t cap)
 {
-    // one workgroup per tile
+    // one workgroup per (camera, tile); gsplat key = camera << (32 + tile_bits) | tile << 32 | depth bits
     const int t = blockIdx.x;
+    const int64_t cam = t / n_tiles, local = t % n_tiles;
+    const int64_t hi = (cam << (32 + tile_bits)) | (local << 32);
     const int s = offsets[t], e = offsets[t + 1];
     for (int i = s + threadIdx.x; i < e && i < cap; i += blockDim.x) {
         const uint32_t bits = __float_as_uint(depths[flatten_ids[i]]);
-        isect_ids[i] = ((int64_t)t << 32) | (int64_t)bits;
+        isect_ids[i] = hi | (int64_t)bits;
     }
 }
 
@@ -502,13 +507,15 @@ void radix_pass(hipStream_t stream, const K *ka, const uint32_t *va, K *kb, uint
 }
 
 // emission + stable sort of the (tile, gaussian) pairs by tile id + tile offsets
+// n_tiles = tiles of the whole batch (cameras x tiles per image)
 template <typename K>
 void emit_and_sort(hipStream_t stream, const dnsplat_bin_args *a, const BinWs &w, int tw, int th, int n_tiles, uint32_t cap)
 {
     K *ka = reinterpret_cast<K *>(w.tkey_a), *kb = reinterpret_cast<K *>(w.tkey_b);
     uint32_t *va = w.tval_a, *vb = w.tval_b;
-    hipLaunchKernelGGL(emit_kernel<K>, dim3((a->N + 255) / 256), dim3(256), 0, stream, a->N, w.val_a, w.cum, a->means2d,
-                       a->radii, a->tile_size, tw, th, cap, ka, va);
+    const int n_cam = a->n_cameras > 1 ? a->n_cameras : 1;
+    hipLaunchKernelGGL(emit_kernel<K>, dim3((a->N + 255) / 256), dim3(256), 0, stream, a->N, a->N / n_cam, w.val_a, w.cum,
+                       a->means2d, a->radii, a->tile_size, tw, th, cap, ka, va);
     const int bits = tile_bits(n_tiles);
     const int passes = (bits + 7) / 8;
     hipLaunchKernelGGL(tile_first_init_kernel, dim3((n_tiles + 1 + 255) / 256), dim3(256), 0, stream, w.total, cap, n_tiles,
@@ -547,6 +554,7 @@ static int check_bin(const dnsplat_bin_args *a)
 {
     if (!a) return DNSPLAT_ERR_INVALID_ARG;
     if (a->N < 0 || a->width <= 0 || a->height <= 0 || a->tile_size <= 0) return DNSPLAT_ERR_INVALID_ARG;
+    if (a->n_cameras < 0 || (a->n_cameras > 1 && a->N % a->n_cameras != 0)) return DNSPLAT_ERR_INVALID_ARG;
     if (a->isect_capacity < 0 || a->isect_capacity > 0x7fffffffLL) return DNSPLAT_ERR_INVALID_ARG;
     if (!a->n_isects || !a->workspace) return DNSPLAT_ERR_INVALID_ARG;
     if (a->N > 0 && (!a->means2d || !a->radii || !a->depths || !a->tiles_per_gauss)) return DNSPLAT_ERR_INVALID_ARG;
@@ -599,7 +607,9 @@ extern "C" int dnsplat_bin_emit_sort(const dnsplat_bin_args *a, dnsplat_stream_t
     hipStream_t stream = (hipStream_t)stream_;
     BinWs w = carve(a->workspace, a->N, a->isect_capacity);
     const int tw = dns_tiles_w(a->width, a->tile_size), th = dns_tiles_h(a->height, a->tile_size);
-    const int n_tiles = tw * th;
+    const int64_t n_tiles64 = (int64_t)tw * th * (a->n_cameras > 1 ? a->n_cameras : 1);
+    if (n_tiles64 > 0x7fffffffLL) return DNSPLAT_ERR_UNSUPPORTED;
+    const int n_tiles = (int)n_tiles64;
     const uint32_t cap = (uint32_t)a->isect_capacity;
     if (a->N == 0 || cap == 0) {
         if (hipMemsetAsync(a->tile_offsets, 0, sizeof(int32_t) * (size_t)(n_tiles + 1), stream) != hipSuccess)
@@ -612,14 +622,17 @@ extern "C" int dnsplat_bin_emit_sort(const dnsplat_bin_args *a, dnsplat_stream_t
     return DNSPLAT_OK;
 }
 
-extern "C" int dnsplat_bin_isect_ids(int32_t n_tiles, const int32_t *tile_offsets, const int32_t *flatten_ids,
-                                     const float *depths, int64_t *isect_ids, int64_t capacity,
+extern "C" int dnsplat_bin_isect_ids(int32_t n_tiles, int32_t n_cameras, const int32_t *tile_offsets,
+                                     const int32_t *flatten_ids, const float *depths, int64_t *isect_ids, int64_t capacity,
                                      dnsplat_stream_t stream)
 {
-    if (n_tiles <= 0 || !tile_offsets || !isect_ids) return DNSPLAT_ERR_INVALID_ARG;
+    if (n_tiles <= 0 || n_cameras < 0 || !tile_offsets || !isect_ids) return DNSPLAT_ERR_INVALID_ARG;
     if (capacity == 0) return DNSPLAT_OK;
     if (!flatten_ids || !depths) return DNSPLAT_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(isect_ids_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, n_tiles, tile_offsets,
+    const int n_cam = n_cameras > 1 ? n_cameras : 1;
+    int tb = 0;                                  // floor(log2(n_tiles)) + 1
+    while ((n_tiles >> tb) != 0) ++tb;
+    hipLaunchKernelGGL(isect_ids_kernel, dim3(n_tiles * n_cam), dim3(256), 0, (hipStream_t)stream, n_tiles, tb, tile_offsets,
                        flatten_ids, depths, isect_ids, capacity);
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;

@@ -99,7 +99,110 @@ __global__ __launch_bounds__(256) void densify_stats_kernel(int N, const int32_t
     max2d[g] = fmaxf(max2d[g], (float)r * inv_max_size);
 }
 
+// ---- densification decisions, one lane per Gaussian --------------------------------------------------
+// refinement_after (dn_model.py:271-386) with the helpers it inherits from nerfstudio's SplatfactoModel (cull_gaussians):
+// which Gaussians are split, duplicated, and which of {original, split child, duplicate} survive the cull.  Every rank of a
+// data-parallel job evaluates this kernel on identical (all-reduced) statistics and identical parameters, so all replicas take
+// the same decisions bit for bit.
+__global__ __launch_bounds__(256) void densify_classify_kernel(dnsplat_densify_args a)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.N) return;
+    const float s0 = a.scales[3 * g], s1 = a.scales[3 * g + 1], s2 = a.scales[3 * g + 2];
+    const float smax = fmaxf(fmaxf(expf(s0), expf(s1)), expf(s2));                       // scales.exp().max(dim=-1)
+    const float z = a.max_2Dsize ? a.max_2Dsize[g] : 0.f;
+    // a split child holds log(exp(s) / 1.6) (split_gaussians); whoever looks at it later exponentiates that again
+    const float c0 = expf(logf(expf(s0) / 1.6f)), c1 = expf(logf(expf(s1) / 1.6f)), c2 = expf(logf(expf(s2) / 1.6f));
+    const float smax_child = fmaxf(fmaxf(c0, c1), c2);
+    float smax_dup = smax;
+    uint8_t f = 0;
+    if (a.do_densify) {
+        // avg_grad_norm = (xys_grad_norm / vis_counts) * 0.5 * max(H, W)                  dn_model.py:293-297
+        const float avg = (a.xys_grad_norm[g] / a.vis_counts[g]) * 0.5f * a.max_image_side;
+        const bool high = avg > a.densify_grad_thresh;
+        bool split = smax > a.densify_size_thresh;
+        if (a.screen_rules) split = split || (z > a.split_screen_size);
+        split = split && high;
+        // split_gaussians shrinks the parents' scales IN PLACE before the duplicate mask is formed (dn_model.py:309-315): a
+        // split parent whose shrunk scale falls under the threshold is duplicated as well, with the shrunk scale
+        if (split) smax_dup = smax_child;
+        const bool dup = (smax_dup <= a.densify_size_thresh) && high;
+        if (split) f |= DNSPLAT_DENSIFY_SPLIT;
+        if (dup) f |= DNSPLAT_DENSIFY_DUP;
+    }
+    // cull_gaussians: sigmoid(opacity) < cull_alpha_thresh, plus "too big" once past the first opacity reset
+    const float alpha = 1.f / (1.f + expf(-a.opacities[g]));
+    const bool low = alpha < a.cull_alpha_thresh;
+    bool big = false, big_child = false, big_dup = false;
+    if (a.cull_big) {
+        big = smax > a.cull_scale_thresh;
+        big_dup = smax_dup > a.cull_scale_thresh;           // appended entries start with max_2Dsize = 0 (dn_model.py:324-332)
+        if (a.screen_rules && a.max_2Dsize) big = big || (z > a.cull_screen_size);
+        big_child = smax_child > a.cull_scale_thresh;
+    }
+    if ((f & DNSPLAT_DENSIFY_SPLIT) || low || big) f |= DNSPLAT_DENSIFY_CULL;      // a split parent is pruned (dn_model.py:338-352)
+    if (low || big_child) f |= DNSPLAT_DENSIFY_CULL_CHILD;
+    if (low || big_dup) f |= DNSPLAT_DENSIFY_CULL_DUP;
+    a.flags[g] = f;
+}
+
+// New means / scales of the split children (nerfstudio split_gaussians): child j of parent p = parents[j % n_parents] takes
+//     mean  = mean_p + R(q_p / |q_p|) (exp(scale_p) * noise_j),    scale = log(exp(scale_p) / 1.6)
+// noise [n_children,3] ~ N(0,1) is drawn by the caller (identically on every rank).
+__global__ __launch_bounds__(256) void densify_split_kernel(int n_children, int n_parents, const int32_t *__restrict__ parents,
+                                                            const float *__restrict__ noise, const float *__restrict__ means,
+                                                            const float *__restrict__ scales, const float *__restrict__ quats,
+                                                            float *__restrict__ new_means, float *__restrict__ new_scales)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_children) return;
+    const int p = parents[j % n_parents];
+    float q[4];
+    float n2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { q[i] = quats[4 * p + i]; n2 += q[i] * q[i]; }
+    const float inv = 1.f / sqrtf(n2);
+    const float w = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
+    const float R[9] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y - w * z), 2.f * (x * z + w * y),
+                        2.f * (x * y + w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - w * x),
+                        2.f * (x * z - w * y), 2.f * (y * z + w * x), 1.f - 2.f * (x * x + y * y)};
+    float v[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float e = expf(scales[3 * p + i]);
+        v[i] = e * noise[3 * j + i];
+        new_scales[3 * j + i] = logf(e / 1.6f);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        new_means[3 * j + i] = (R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2]) + means[3 * p + i];
+}
+
 }  // namespace
+
+extern "C" int dnsplat_densify_classify(const dnsplat_densify_args *a, dnsplat_stream_t stream)
+{
+    if (!a || a->N < 0) return DNSPLAT_ERR_INVALID_ARG;
+    if (a->N == 0) return DNSPLAT_OK;
+    if (!a->scales || !a->opacities || !a->flags) return DNSPLAT_ERR_INVALID_ARG;
+    if (a->do_densify && (!a->xys_grad_norm || !a->vis_counts)) return DNSPLAT_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(densify_classify_kernel, dim3((a->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}
+
+extern "C" int dnsplat_densify_split(int32_t n_children, int32_t n_parents, const int32_t *parents, const float *noise,
+                                     const float *means, const float *scales, const float *quats, float *new_means,
+                                     float *new_scales, dnsplat_stream_t stream)
+{
+    if (n_children < 0 || n_parents < 0) return DNSPLAT_ERR_INVALID_ARG;
+    if (n_children == 0) return DNSPLAT_OK;
+    if (n_parents == 0 || !parents || !noise || !means || !scales || !quats || !new_means || !new_scales) return DNSPLAT_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(densify_split_kernel, dim3((n_children + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_children,
+                       n_parents, parents, noise, means, scales, quats, new_means, new_scales);
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}
 
 extern "C" int dnsplat_densify_stats(int32_t N, const int32_t *radii, const float *xy_grads, int32_t grad_stride,
                                      float inv_max_size, float *xys_grad_norm, float *vis_counts, float *max_2Dsize,

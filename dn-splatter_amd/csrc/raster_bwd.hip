@@ -67,6 +67,24 @@ constexpr int TILE = 16;
 #else
 #define DNS_BWD_OCCUPANCY
 #endif
+// pixel coordinates from an LDS table read one step ahead (1) or recomputed from the pixel counter every step (0).
+// Measured (paired A/B, tools/ab_kernels.py): the table is not faster — the six integer / convert instructions it removes were
+// not on the kernel's critical resource.
+#ifndef DNS_BWD_COORD_TABLE
+#define DNS_BWD_COORD_TABLE 0
+#endif
+// "did this lane's splat meet any valid pixel" as two per-step bool accumulations (1), or derived at the flush from the
+// partial sums themselves (0): a record whose 16 sums are all exactly zero need not be added to anything.  The bools are
+// live across the step's one branch (the park store of lane 63), where hipcc merges each with three scalar instructions
+// per step; the scalar unit is shared by the 12 waves of a CU.
+#ifndef DNS_BWD_TOUCH_FLAGS
+#define DNS_BWD_TOUCH_FLAGS 0
+#endif
+// wave-uniform loop bounds moved to scalar registers explicitly (readfirstlane): left alone, hipcc keeps the step counter in a
+// VGPR with a per-lane exit mask (v_add, v_cmp, s_or, s_andn2 exec per step)
+#ifndef DNS_BWD_SCALAR_LOOP
+#define DNS_BWD_SCALAR_LOOP 1
+#endif
 constexpr int ROWS = DNS_BWD_ROWS;
 constexpr int PARTS = TILE / ROWS;              // waves (workgroups) per tile
 constexpr int NPIX = TILE * ROWS;
@@ -81,10 +99,18 @@ constexpr int NGROUP = DNS_WAVE / GROUP;
 #endif
 constexpr int FLUSH_REC = DNS_BWD_FLUSH_REC;    // gradient records staged in LDS per round of the transposed flush
 constexpr int PERIOD = NPIX + GROUP - 1;        // steps from one bucket to the next: 256 pixels + GROUP - 1 idle slots
+// the step loop accumulates the mean gradient in units of the half-gradients of the exponent (splat_common.h)
+#if DNS_EXP_SYM
+constexpr float XY_SCALE = -2.f / DNS_LOG2E;
+#else
+constexpr float XY_SCALE = 1.f;
+#endif
 
 
 struct BwdArgs {
-    int width, height, tw, n_tiles;
+    int width, height, tw, n_tiles;            // n_tiles: per camera; the launch covers n_tiles x cameras stacked tile grids
+    unsigned long long *counters;              // measurement instantiation only (dnsplat_raster_args.pair_counters)
+    int n_cameras;
     const float4 *__restrict__ splats;
     const int32_t *__restrict__ flatten_ids;
     const int32_t *__restrict__ tile_offsets;
@@ -109,6 +135,7 @@ struct BwdArgs {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 zero2_init() { f2 z = {0.f, 0.f}; return z; }
 
 // One pixel row (48 bytes) of the LDS table as three ds_read_b128.  Left to itself hipcc scalarises the
 // row (its fields are carried across the loop back-edge one by one) and re-merges it into
@@ -133,6 +160,17 @@ __device__ __forceinline__ void row_wait(v4f &r0, v4f &r1, v4f &r2, f2 &done)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(done) : : "memory");
 }
 
+// Pixel-centre coordinates of the NEXT step's pixel from the per-wave table (one ds_read_b64, conflict-free at an 8-byte lane
+// stride), requested together with the row and completed by the same wait: replaces and / cvt / add / shift / cvt / add per step.
+__device__ __forceinline__ void coord_issue(uint32_t byte_addr, f2 &nxt, int &token)
+{
+    asm volatile("ds_read_b64 %0, %2" : "=&v"(nxt), "+v"(token) : "v"(byte_addr) : "memory");
+}
+__device__ __forceinline__ void row_wait(v4f &r0, v4f &r1, v4f &r2, f2 &nxt, f2 &done)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(nxt), "+v"(done) : : "memory");
+}
+
 // acc += a * (b.x or b.y broadcast to both halves): v_pk_fma_f32 with op_sel picking one half of the b pair
 __device__ __forceinline__ void pk_fma_bcast(f2 &acc, f2 a, f2 b, int hi)
 {
@@ -148,7 +186,9 @@ __device__ __forceinline__ float dpp_wave_shr1(float from_prev, float lane0_valu
 }
 
 // SPLIT >= 0: compile-time split; SPLIT < 0: run-time a.xy_split
-template <int D, int SPLIT, bool DN>
+// COUNT: measurement build of the fused pass (bench.py's VALU roofline): tallies the (pixel, splat) slots the stream issues and
+// the pairs it replays into a.counters[4..5]; never the instantiation that is timed.
+template <int D, int SPLIT, bool DN, bool COUNT = false>
 __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(BwdArgs a)
 {
     __shared__ float4 pix[NPIX][3];            // [p][0..1] = v_k, [p][2] = (T, S_a, S_b, bin_final)
@@ -157,13 +197,21 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
     // live.  13.5 KiB per wave = 12 tiles in flight per CU (3 waves per SIMD, the VGPR limit) instead of 11.
     __shared__ int32_t queue[BUCKET + DNS_WAVE];
     __shared__ float4 flush[FLUSH_REC][4];
+#if DNS_BWD_COORD_TABLE
+    __shared__ float2 coord[NPIX];             // pixel-centre coordinates of the half tile, row-major
+#endif
 
-    const int tile = dns_tile_of_block(blockIdx.x / PARTS, a.n_tiles, a.tw);
+    // batch of cameras: unit u = blockIdx / PARTS works on tile u % n_tiles of camera u / n_tiles (stacked images and lists)
+    const int unit = blockIdx.x / PARTS;
+    const int cam = unit / a.n_tiles;
+    const int tile = dns_tile_of_block(unit - cam * a.n_tiles, a.n_tiles, a.tw);
+    const size_t img = (size_t)cam * a.width * a.height;
     const int part = blockIdx.x % PARTS;
     const int lane = threadIdx.x;
-    const int range_start = a.tile_offsets[tile];
-    const int range_end = a.tile_offsets[tile + 1];
+    const int range_start = a.tile_offsets[cam * a.n_tiles + tile];
+    const int range_end = a.tile_offsets[cam * a.n_tiles + tile + 1];
     if (range_end <= range_start) return;
+    [[maybe_unused]] unsigned long long n_slots = 0, n_pairs = 0;
 #ifdef DNS_BWD_TIMELINE
     // instrumented build (tools/bwd_timeline.sh): per work unit (start, end) of the 100 MHz wall clock and the list depth, written
     // through the v_alphas pointer, which the fused (DN) pass does not use
@@ -187,7 +235,7 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
         if (DN && xi < a.width && yi < a.height) {
             // cotangents of the dn-splatter images -> cotangents of the raw composite (backward of
             // dn_model.py:526-537, 577-578; forward twin: dn_epilogue in raster_fwd.hip)
-            const size_t pid = (size_t)yi * a.width + xi;
+            const size_t pid = img + (size_t)yi * a.width + xi;
             const float al = a.alphas[pid];
             T_final = 1.f - al;
             bin_final = a.last_ids[pid];
@@ -223,7 +271,7 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
             sb = T_final * (v[4] + v[5] + v[6]);      // the legacy normal pass composites over ones
             if (al <= 0.f) bin_final = -1;
         } else if (xi < a.width && yi < a.height) {
-            const size_t pid = (size_t)yi * a.width + xi;
+            const size_t pid = img + (size_t)yi * a.width + xi;
 #pragma unroll
             for (int k = 0; k < D; ++k) v[k] = a.v_render[pid * D + k];
             const float al = a.alphas[pid];
@@ -255,6 +303,9 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
             // a pixel nothing was blended into walks no list entry at all
             if (al <= 0.f) bin_final = -1;
         }
+#if DNS_BWD_COORD_TABLE
+        coord[p] = make_float2((float)xi + 0.5f, (float)yi + 0.5f);
+#endif
         pix[p][0] = make_float4(v[0], v[1], v[2], v[3]);
         pix[p][1] = make_float4(v[4], v[5], v[6], v[7]);
         pix[p][2] = make_float4(T_final, sa, sb, __int_as_float(bin_final));
@@ -273,19 +324,24 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
     int cursor = hi;  // next (highest) list index not yet examined
     int qn = 0;       // entries waiting in the queue beyond the current bucket (wave-uniform)
     const uint32_t pix_base = (uint32_t)(uintptr_t)&pix[0][0];   // LDS byte address of the table
+#if DNS_BWD_COORD_TABLE
+    const uint32_t coord_base = (uint32_t)(uintptr_t)&coord[0];
+    f2 pxy = zero2_init();                                       // centre of the pixel the lane works on in the coming step
+#endif
 
     // ---- per-lane state of the stream: two splats (x = A, farther; y = B, nearer), their partial sums, the
     // pixel counter of the lane's current bucket and the pixel state handed to the next lane --------------------
     const f2 zero2 = {0.f, 0.f};
     int gid_a = 0, gid_b = 0;
     int cmp_a = 0x7fffffff, cmp_b = 0x7fffffff;   // list index of the lane's splats; "none" lies above every bin_final
-    f2 sx = zero2, sy = zero2, ca = zero2, cb = zero2, cc = zero2, opac = zero2, na = zero2, nb = zero2, nc = zero2;
+    [[maybe_unused]] f2 ca = zero2, cb = zero2, cc = zero2;      // the unscaled conic: only the DNS_EXP_SYM = 0 loop reads it
+    f2 sx = zero2, sy = zero2, opac = zero2, na = zero2, nb = zero2, nc = zero2;
     f2 ch[8];
     f2 g_x = zero2, g_y = zero2, g_ca = zero2, g_cb = zero2, g_cc = zero2, g_o = zero2, g_ax = zero2, g_ay = zero2;
     f2 g_ch[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { ch[k] = zero2; g_ch[k] = zero2; }
-    bool touched_a = false, touched_b = false;
+    [[maybe_unused]] bool touched_a = false, touched_b = false;
     int p = -(1 << 20);                           // negative = not started; a group's switch sets it to -(lane % GROUP)
     float T_out = 0.f, SA_out = 0.f, SB_out = 0.f;
 
@@ -335,7 +391,17 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
             //    atomic instruction covering 4 complete 64-byte records.
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
+#if DNS_BWD_TOUCH_FLAGS
                 const uint64_t tmask = dns_ballot(half ? touched_b : touched_a) & gmask;
+#else
+                uint32_t any_bits = 0;      // OR of the 16 partial sums' bit patterns; << 1 drops the sign of a -0.0
+#define BITS(v) (uint32_t)__float_as_int(half ? (v).y : (v).x)
+                any_bits = BITS(g_x) | BITS(g_y) | BITS(g_ca) | BITS(g_cb) | BITS(g_cc) | BITS(g_o) | BITS(g_ax) | BITS(g_ay);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) any_bits |= BITS(g_ch[k]);
+#undef BITS
+                const uint64_t tmask = dns_ballot((any_bits << 1) != 0u) & gmask;
+#endif
                 if (tmask == 0) continue;                                    // wave-uniform
                 const int gid = half ? gid_b : gid_a;
 #define SEL(v) (half ? (v).y : (v).x)
@@ -344,10 +410,10 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
                     if (((tmask >> (GROUP * grp + FLUSH_REC * sub)) & ((1ull << FLUSH_REC) - 1ull)) == 0) continue;   // wave-uniform
                     if (mine && (lane % GROUP) / FLUSH_REC == sub) {
                         const int r = lane % FLUSH_REC;
-                        flush[r][0] = make_float4(SEL(g_x), SEL(g_y), 0.5f * SEL(g_ca), SEL(g_cb));
+                        flush[r][0] = make_float4(XY_SCALE * SEL(g_x), XY_SCALE * SEL(g_y), 0.5f * SEL(g_ca), SEL(g_cb));
                         flush[r][1] = make_float4(0.5f * SEL(g_cc), SEL(g_o) / SEL(opac), SEL(g_ch[0]), SEL(g_ch[1]));
                         flush[r][2] = make_float4(SEL(g_ch[2]), SEL(g_ch[3]), SEL(g_ch[4]), SEL(g_ch[5]));
-                        flush[r][3] = make_float4(SEL(g_ch[6]), SEL(g_ch[7]), SEL(g_ax), SEL(g_ay));
+                        flush[r][3] = make_float4(SEL(g_ch[6]), SEL(g_ch[7]), -XY_SCALE * SEL(g_ax), -XY_SCALE * SEL(g_ay));
                     }
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -396,12 +462,18 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
                 for (int k = 0; k < 8; ++k) g_ch[k] = zero2;
                 touched_a = false; touched_b = false;
                 p = -(lane % GROUP);
+#if DNS_BWD_COORD_TABLE
+                { const float2 c = coord[p & (NPIX - 1)]; pxy = f2{c.x, c.y}; }
+#endif
             }
             int nsteps = grp < NGROUP - 1 ? GROUP : PERIOD - GROUP * (NGROUP - 1);
             if (last) {
                 if (2 * GROUP * (grp + 1) >= prev_take) break;           // that was the last group with anything to flush
                 nsteps = GROUP;
             }
+#if DNS_BWD_SCALAR_LOOP
+            nsteps = __builtin_amdgcn_readfirstlane(nsteps);
+#endif
 
             // ==== the stream: nsteps steps, one pixel per lane per step ===========================================
             // The pixel row of the step is requested first and waited for only after the row-independent part
@@ -421,13 +493,29 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
                 int pcur = p & (NPIX - 1);
                 v4f c0, c1, cst;
                 row_issue(pix_base + pcur * 48, c0, c1, cst, pcur);
-
+#if DNS_BWD_COORD_TABLE
+                f2 pxy_next;
+                coord_issue(coord_base + (((p + 1) & (NPIX - 1)) << 3), pxy_next, pcur);
+                const float px = pxy.x, py = pxy.y;
+#else
                 const float px = fx0 + (float)(pcur & 15), py = fy0 + (float)(pcur >> 4);
+#endif
                 const f2 dx = sx - px, dy = sy - py;
                 // same fused-multiply-add sequence as dns_exponent(), two splats at a time (v_pk_*_f32)
+#if DNS_EXP_SYM
+                const f2 hu = __builtin_elementwise_fma(nb, dy, na * dx);     // -log2e/2 d sigma / d dx
+                const f2 hw = __builtin_elementwise_fma(nc, dy, nb * dx);     // -log2e/2 d sigma / d dy
+                const f2 e = __builtin_elementwise_fma(dx, hu, dy * hw);
+#else
                 const f2 e = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(na, dx, nb * dy), (nc * dy) * dy);
+#endif
                 f2 vis = {dns_exp2(e.x), dns_exp2(e.y)};
+#if DNS_BWD_COORD_TABLE
+                row_wait(c0, c1, cst, pxy_next, vis);
+                pxy = pxy_next;
+#else
                 row_wait(c0, c1, cst, vis);
+#endif
                 const f2 ov = opac * vis;
                 const float al_a = CLAMP ? fminf((float)DNS_ALPHA_MAX, ov.x) : ov.x;
                 const float al_b = CLAMP ? fminf((float)DNS_ALPHA_MAX, ov.y) : ov.y;
@@ -438,8 +526,11 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
                 const int bin_final = __float_as_int(cst.w);
                 const bool valid_a = active && cmp_a <= bin_final && e.x <= 0.f && al_a >= (float)DNS_ALPHA_MIN;
                 const bool valid_b = active && cmp_b <= bin_final && e.y <= 0.f && al_b >= (float)DNS_ALPHA_MIN;
+                if (COUNT) n_pairs += __popcll(dns_ballot(valid_a)) + __popcll(dns_ballot(valid_b));
                 {   // straight-line: an idle step costs the same as a busy one, but no phi copies at a join
+#if DNS_BWD_TOUCH_FLAGS
                     touched_a |= valid_a; touched_b |= valid_b;
+#endif
                     // an invalid pair takes alpha = 0 (=> 1/(1-alpha) = 1, weight 0: state and sums unchanged) and m = 0
                     const f2 alpha = {valid_a ? al_a : 0.f, valid_b ? al_b : 0.f};
                     // opacity x vis where the pair is valid and alpha is not clamped, else 0: the weight of d/d(sigma)
@@ -483,8 +574,12 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
                     g_ca = __builtin_elementwise_fma(hx, dx, g_ca);      // x 1/2 at the flush
                     g_cb = __builtin_elementwise_fma(hx, dy, g_cb);
                     g_cc = __builtin_elementwise_fma(hy, dy, g_cc);
+#if DNS_EXP_SYM
+                    const f2 gx = vs_a * hu, gy = vs_a * hw;             // x -2 / log2e at the flush
+#else
                     const f2 gx = vs_a * (ca * dx + cb * dy);
                     const f2 gy = vs_a * (cb * dx + cc * dy);
+#endif
                     g_x += gx; g_y += gy;
                     // |.| as a source modifier of a plain add: cheaper than masking the sign bits and a packed add
                     g_ax.x += __builtin_fabsf(gx.x); g_ax.y += __builtin_fabsf(gx.y);
@@ -498,12 +593,14 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
                 ++p;
             }
             };
+            if (COUNT) n_slots += (unsigned long long)nsteps * BUCKET;
             if (dns_ballot(opac.x > (float)DNS_ALPHA_MAX || opac.y > (float)DNS_ALPHA_MAX) != 0ull) step_loop(std::true_type{});
             else step_loop(std::false_type{});
         }
         if (last) break;
         prev_take = take;
     }
+    if (COUNT && lane == 0 && a.counters) { atomicAdd(a.counters + 4, n_slots); atomicAdd(a.counters + 5, n_pairs); }
 #ifdef DNS_BWD_TIMELINE
     if (dbg_tl && lane == 0) {
         dbg_tl[3 * blockIdx.x] = tl_t0;
@@ -513,10 +610,10 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
 #endif
 }
 
-template <int D, int SPLIT, bool DN = false>
+template <int D, int SPLIT, bool DN = false, bool COUNT = false>
 int launch_bwd(const BwdArgs &ba, hipStream_t stream)
 {
-    hipLaunchKernelGGL((raster_bwd_kernel<D, SPLIT, DN>), dim3(ba.n_tiles * PARTS), dim3(DNS_WAVE), 0, stream, ba);
+    hipLaunchKernelGGL((raster_bwd_kernel<D, SPLIT, DN, COUNT>), dim3(ba.n_tiles * ba.n_cameras * PARTS), dim3(DNS_WAVE), 0, stream, ba);
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;
 }
@@ -555,6 +652,9 @@ extern "C" int dnsplat_raster_bwd(const dnsplat_raster_args *a, dnsplat_stream_t
     ba.xy_split = a->xy_split;
     ba.v_splats = a->v_splats;
     ba.bg_rgb = ba.dn_v_rgb = ba.dn_v_depth = ba.dn_v_normal = ba.dn_v_acc = nullptr;
+    if (a->n_cameras < 0) return DNSPLAT_ERR_INVALID_ARG;
+    ba.n_cameras = a->n_cameras > 1 ? a->n_cameras : 1;
+    ba.counters = reinterpret_cast<unsigned long long *>(a->pair_counters);
     hipStream_t stream = (hipStream_t)stream_;
     if (a->dn) {
         const dnsplat_dn_post *dn = a->dn;
@@ -562,6 +662,7 @@ extern "C" int dnsplat_raster_bwd(const dnsplat_raster_args *a, dnsplat_stream_t
         if (!dn->background_rgb || !dn->v_rgb || !dn->v_depth || !dn->v_normal || !a->render) return DNSPLAT_ERR_INVALID_ARG;
         ba.bg_rgb = dn->background_rgb; ba.dn_v_rgb = dn->v_rgb; ba.dn_v_depth = dn->v_depth;
         ba.dn_v_normal = dn->v_normal; ba.dn_v_acc = dn->v_accumulation;
+        if (ba.counters) return launch_bwd<7, 4, true, true>(ba, stream);
         return launch_bwd<7, 4, true>(ba, stream);
     }
     switch (a->D) {

@@ -29,7 +29,8 @@ constexpr int FWD_WAVES = 2;  // waves per workgroup == half tiles per tile
 constexpr int FWD_THREADS = FWD_WAVES * DNS_WAVE;
 
 struct FwdArgs {
-    int width, height, tw, n_tiles;
+    int width, height, tw, n_tiles;            // n_tiles: per camera; the launch covers n_tiles x cameras stacked tile grids
+    unsigned long long *counters;              // measurement instantiation only (dnsplat_raster_args.pair_counters)
     const float4 *__restrict__ splats;
     const int32_t *__restrict__ flatten_ids;
     const int32_t *__restrict__ tile_offsets;
@@ -88,14 +89,22 @@ __device__ __forceinline__ float sel0(uint64_t mask, float a)
     return r;
 }
 
-template <int D, bool DN>
+// COUNT: measurement build of the fused pass — also tallies list entries examined, splats walked, live (pixel, splat) pairs
+// evaluated and pairs blended into a.counters (bench.py's VALU roofline); never the instantiation that is timed.
+template <int D, bool DN, bool COUNT = false>
 __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kernel(FwdArgs a)
 {
     // one 64-record slice per wave: [wave][splat][4 x float4]
     __shared__ float4 lds[FWD_WAVES][DNS_WAVE][4];
 
-    const int tile = dns_tile_of_block(blockIdx.x, a.n_tiles, a.tw);
+    // batch of cameras: block b works on tile b % n_tiles of camera b / n_tiles; its lists are tile_offsets[b .. b + 1] and its
+    // pixels live in image `cam` of the stacked [C,H,W,.] outputs
+    const int cam = blockIdx.x / a.n_tiles;
+    const int tile = dns_tile_of_block(blockIdx.x - cam * a.n_tiles, a.n_tiles, a.tw);
+    const size_t img = (size_t)cam * a.width * a.height;
+    const int list = cam * a.n_tiles + tile;
     const int wave = threadIdx.x / DNS_WAVE;
+    [[maybe_unused]] unsigned long long n_entries = 0, n_walked = 0, n_live = 0, n_blend = 0;
     const int lane = threadIdx.x & (DNS_WAVE - 1);
     const int tile_x = tile % a.tw, tile_y = tile / a.tw;
     const int px_i = tile_x * TILE + (lane & 15);
@@ -106,8 +115,8 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
     const bool in0 = px_i < a.width && py_i0 < a.height;
     const bool in1 = px_i < a.width && py_i1 < a.height;
 
-    const int range_start = a.tile_offsets[tile];
-    const int range_end = a.tile_offsets[tile + 1];
+    const int range_start = a.tile_offsets[list];
+    const int range_end = a.tile_offsets[list + 1];
 
     float T0 = 1.f, T1 = 1.f;
     float acc0[D], acc1[D];
@@ -141,6 +150,7 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
         const bool keep = (batch_start + lane < range_end) &&
                           !dns_cull_rect(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rxl, rxh, ryl, ryh);
         uint64_t todo = dns_ballot(keep);
+        if (COUNT) n_entries += min(DNS_WAVE, range_end - batch_start);
         // stage the prefetched records (waits for the gather here) with the conic pre-scaled for exp2,
         // then start the next gather
         {
@@ -178,8 +188,15 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
             q.na = g0.z; q.nb = g0.w; q.nc = g1.x;
             const float dx = g0.x - px;
             const float dy0 = g0.y - py0, dy1 = g0.y - py1;
+#if DNS_EXP_SYM
+            // dns_exponent() for both pixels of the lane, with the two products that only depend on dx formed once
+            const float adx = q.na * dx, bdx = q.nb * dx;
+            const float e0 = __builtin_fmaf(dx, __builtin_fmaf(q.nb, dy0, adx), dy0 * __builtin_fmaf(q.nc, dy0, bdx));
+            const float e1 = __builtin_fmaf(dx, __builtin_fmaf(q.nb, dy1, adx), dy1 * __builtin_fmaf(q.nc, dy1, bdx));
+#else
             const float e0 = dns_exponent(q, dx, dy0);
             const float e1 = dns_exponent(q, dx, dy1);
+#endif
             const float alpha0 = fminf((float)DNS_ALPHA_MAX, g1.y * dns_exp2(e0));
             const float alpha1 = fminf((float)DNS_ALPHA_MAX, g1.y * dns_exp2(e1));
             const uint64_t valid0 = dns_ballot(e0 <= 0.f) & dns_ballot(alpha0 >= (float)DNS_ALPHA_MIN) & ~done0;
@@ -190,6 +207,11 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
             done0 |= stop0;
             done1 |= stop1;
             const uint64_t c0 = valid0 & ~stop0, c1 = valid1 & ~stop1;
+            if (COUNT) {
+                n_walked += 1;
+                n_live += __popcll(~(done0 & ~stop0)) + __popcll(~(done1 & ~stop1));   // pixels still open when the splat arrived
+                n_blend += __popcll(c0) + __popcll(c1);
+            }
             float ch[8];
             ch[0] = g1.z; ch[1] = g1.w;
             if (D > 2) { ch[2] = g2.x; ch[3] = g2.y; ch[4] = g2.z; ch[5] = g2.w; }
@@ -209,7 +231,7 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
     // epilogue: background, expected-depth normalisation, stores
     float dmax = 0.f;
     if (in0) {
-        const size_t pid = (size_t)py_i0 * a.width + px_i;
+        const size_t pid = img + (size_t)py_i0 * a.width + px_i;
         const float al = 1.f - T0;
         a.alphas[pid] = al;
         a.last_ids[pid] = __float_as_int(last0);
@@ -225,7 +247,7 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
         if (DN) dmax = fmaxf(dmax, dn_epilogue(a, pid, raw, al));
     }
     if (in1) {
-        const size_t pid = (size_t)py_i1 * a.width + px_i;
+        const size_t pid = img + (size_t)py_i1 * a.width + px_i;
         const float al = 1.f - T1;
         a.alphas[pid] = al;
         a.last_ids[pid] = __float_as_int(last1);
@@ -245,14 +267,18 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
         // so their bit patterns order like the floats and one integer atomicMax per wave suffices
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, DNS_WAVE));
-        if (lane == 0 && dmax > 0.f) atomicMax(reinterpret_cast<int *>(a.dn_depth_max), __float_as_int(dmax));
+        if (lane == 0 && dmax > 0.f) atomicMax(reinterpret_cast<int *>(a.dn_depth_max) + cam, __float_as_int(dmax));
+    }
+    if (COUNT && lane == 0 && a.counters) {
+        atomicAdd(a.counters + 0, n_entries); atomicAdd(a.counters + 1, n_walked);
+        atomicAdd(a.counters + 2, n_live); atomicAdd(a.counters + 3, n_blend);
     }
 }
 
-template <int D, bool DN = false>
-int launch_fwd(const FwdArgs &fa, hipStream_t stream)
+template <int D, bool DN = false, bool COUNT = false>
+int launch_fwd(const FwdArgs &fa, int n_cameras, hipStream_t stream)
 {
-    hipLaunchKernelGGL((raster_fwd_kernel<D, DN>), dim3(fa.n_tiles), dim3(FWD_THREADS), 0, stream, fa);
+    hipLaunchKernelGGL((raster_fwd_kernel<D, DN, COUNT>), dim3(fa.n_tiles * n_cameras), dim3(FWD_THREADS), 0, stream, fa);
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;
 }
@@ -279,6 +305,9 @@ extern "C" int dnsplat_raster_fwd(const dnsplat_raster_args *a, dnsplat_stream_t
     fa.ed_channel = a->ed_channel;
     fa.render = a->render; fa.alphas = a->alphas; fa.last_ids = a->last_ids;
     fa.bg_rgb = nullptr; fa.dn_rgb = fa.dn_depth = fa.dn_normal = fa.dn_depth_max = nullptr;
+    fa.counters = reinterpret_cast<unsigned long long *>(a->pair_counters);
+    if (a->n_cameras < 0) return DNSPLAT_ERR_INVALID_ARG;
+    const int C = a->n_cameras > 1 ? a->n_cameras : 1;
     hipStream_t stream = (hipStream_t)stream_;
     if (a->dn) {
         const dnsplat_dn_post *dn = a->dn;
@@ -286,17 +315,18 @@ extern "C" int dnsplat_raster_fwd(const dnsplat_raster_args *a, dnsplat_stream_t
         if (!dn->background_rgb || !dn->rgb || !dn->depth || !dn->normal || !dn->depth_max) return DNSPLAT_ERR_INVALID_ARG;
         fa.bg_rgb = dn->background_rgb; fa.dn_rgb = dn->rgb; fa.dn_depth = dn->depth; fa.dn_normal = dn->normal;
         fa.dn_depth_max = dn->depth_max;
-        return launch_fwd<7, true>(fa, stream);
+        if (fa.counters) return launch_fwd<7, true, true>(fa, C, stream);
+        return launch_fwd<7, true>(fa, C, stream);
     }
     switch (a->D) {
-        case 1: return launch_fwd<1>(fa, stream);
-        case 2: return launch_fwd<2>(fa, stream);
-        case 3: return launch_fwd<3>(fa, stream);
-        case 4: return launch_fwd<4>(fa, stream);
-        case 5: return launch_fwd<5>(fa, stream);
-        case 6: return launch_fwd<6>(fa, stream);
-        case 7: return launch_fwd<7>(fa, stream);
-        case 8: return launch_fwd<8>(fa, stream);
+        case 1: return launch_fwd<1>(fa, C, stream);
+        case 2: return launch_fwd<2>(fa, C, stream);
+        case 3: return launch_fwd<3>(fa, C, stream);
+        case 4: return launch_fwd<4>(fa, C, stream);
+        case 5: return launch_fwd<5>(fa, C, stream);
+        case 6: return launch_fwd<6>(fa, C, stream);
+        case 7: return launch_fwd<7>(fa, C, stream);
+        case 8: return launch_fwd<8>(fa, C, stream);
     }
     return DNSPLAT_ERR_UNSUPPORTED;
 }

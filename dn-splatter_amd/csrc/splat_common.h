@@ -108,25 +108,50 @@ __device__ __forceinline__ int dns_tile_of_block(int b, int n_tiles, int tw)
 // cannot make the two kernels round differently.
 #define DNS_LOG2E 1.4426950408889634f
 
+// DNS_EXP_SYM = 1: the quadratic form is evaluated through its two half-gradients,
+//     u = na dx + hb dy,  w = hb dx + nc dy,  e = dx u + dy w        (na, hb, nc = -log2e/2 * (a, b, c)),
+// which are exactly what the backward needs for d sigma / d(dx, dy) = -(2 / log2e) (u, w): the mean gradient costs one
+// multiply per component instead of rebuilding a dx + b dy from the unscaled conic (3 packed instructions less per
+// step, and the unscaled conic leaves the backward's registers).  The forward shares na dx and hb dx between the two
+// pixels of a lane, so it pays nothing for the sixth operation.  DNS_EXP_SYM = 0 keeps the 5-operation Horner form.
+#ifndef DNS_EXP_SYM
+#define DNS_EXP_SYM 1
+#endif
+
 struct DnsConicE {
-    float na, nb, nc;  // -log2e/2 * a, -log2e * b, -log2e/2 * c
+    float na, nb, nc;  // -log2e/2 * a, [SYM: -log2e/2 * b (= hb) | else: -log2e * b], -log2e/2 * c
 };
 
 __device__ __forceinline__ DnsConicE dns_conic_e(float ca, float cb, float cc)
 {
     DnsConicE q;
     q.na = (-0.5f * DNS_LOG2E) * ca;
+#if DNS_EXP_SYM
+    q.nb = (-0.5f * DNS_LOG2E) * cb;
+#else
     q.nb = (-DNS_LOG2E) * cb;
+#endif
     q.nc = (-0.5f * DNS_LOG2E) * cc;
     return q;
 }
 
-// e = -log2e * sigma  (<= 0 for a valid pair)
+// e = -log2e * sigma  (<= 0 for a valid pair).  The operation sequence below is THE definition both compositing kernels
+// follow instruction for instruction (the backward in packed form), so that they take bit-identical skip decisions.
+#if DNS_EXP_SYM
+__device__ __forceinline__ float dns_half_grad_u(const DnsConicE &q, float dx, float dy) { return __builtin_fmaf(q.nb, dy, q.na * dx); }
+__device__ __forceinline__ float dns_half_grad_w(const DnsConicE &q, float dx, float dy) { return __builtin_fmaf(q.nc, dy, q.nb * dx); }
+__device__ __forceinline__ float dns_exponent(const DnsConicE &q, float dx, float dy)
+{
+    const float u = dns_half_grad_u(q, dx, dy), w = dns_half_grad_w(q, dx, dy);
+    return __builtin_fmaf(dx, u, dy * w);
+}
+#else
 __device__ __forceinline__ float dns_exponent(const DnsConicE &q, float dx, float dy)
 {
     const float u = __builtin_fmaf(q.na, dx, q.nb * dy);
     return __builtin_fmaf(dx, u, (q.nc * dy) * dy);
 }
+#endif
 
 __device__ __forceinline__ float dns_exp2(float e) { return __builtin_amdgcn_exp2f(e); }
 

@@ -82,12 +82,13 @@ def render_dn(
                                  xy_split=4, absgrad=absgrad, holder=holder)
     b = holder["binning"]
     info = {
-        "means2d": pr["means2d"], "radii": pr["radii"][None], "depths": pr["depths"], "conics": pr["conics"],
-        "tiles_per_gauss": pr["tiles_per_gauss"][None], "normals_world": pr["normals_world"],
+        "means2d": pr["means2d"], "radii": pr["radii"], "depths": pr["depths"], "conics": pr["conics"],
+        "tiles_per_gauss": pr["tiles_per_gauss"], "normals_world": None if pr["normals_world"] is None else pr["normals_world"][-1],
         "flatten_ids": b.flatten_ids[: b.n_isects], "isect_offsets": b.tile_offsets[:-1].reshape(1, b.tile_height, b.tile_width),
         "n_isects": b.n_isects, "tile_width": b.tile_width, "tile_height": b.tile_height,
         "width": width, "height": height, "tile_size": 16, "n_cameras": 1,
     }
+    out, alphas = out[0], alphas[0]
     normals = out[..., 4:7] if predict_normals else None
     return out[..., :4], alphas[..., None], normals, info
 
@@ -97,29 +98,55 @@ def render_dn_outputs(
     camera_to_world: Tensor,  # [3,4] nerfstudio (OpenGL) c2w on the GPU
     fx: float, fy: float, cx: float, cy: float, width: int, height: int, sh_degree: int, background_rgb: Tensor,
     near_plane: float = 0.01, far_plane: float = 1e10, eps2d: float = 0.3, absgrad: bool = True,
+    pair_counters: Optional[Tensor] = None,
 ) -> Tuple[Dict[str, Tensor], Dict]:
     """The whole replaced part of ``get_outputs`` (classic mode, predict_normals=True) in six launches:
     camera prepare, fused projection, binning, compositing with the dn-splatter epilogue, depth fill +
     depth->normal stencil; backward = compositing backward (taking the image cotangents directly) + fused
     projection backward.  Returns ``(outputs, info)`` with the output keys of dn_model.py:605-612 minus
     ``background``."""
-    N = means.shape[0]
     viewmat, K, nf = _ops.camera_prepare(camera_to_world, fx, fy, cx, cy)
+    outs, info = _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest, viewmat[None], K[None], nf[None],
+                                  [(fx, fy, cx, cy)], width, height, sh_degree, background_rgb, near_plane, far_plane, eps2d,
+                                  absgrad, pair_counters)
+    return {k: v[0] for k, v in outs.items()}, info
+
+
+def render_dn_outputs_batch(
+    means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, features_dc: Tensor, features_rest: Tensor,
+    cameras, width: int, height: int, sh_degree: int, background_rgb: Tensor,
+    near_plane: float = 0.01, far_plane: float = 1e10, eps2d: float = 0.3, absgrad: bool = True,
+) -> Tuple[Dict[str, Tensor], Dict]:
+    """``render_dn_outputs`` for C cameras (records with camera_to_worlds [1,3,4], fx, fy, cx, cy; one image size) in ONE
+    binning pass and ONE compositing launch: outputs are [C,H,W,.] stacks whose slices equal the
+    per-camera results bit for bit."""
+    viewmats, Ks, nfs = _ops.camera_prepare_batch(cameras)
+    intr = [(float(c.fx), float(c.fy), float(c.cx), float(c.cy)) for c in cameras]
+    return _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest, viewmats, Ks, nfs, intr, width, height,
+                            sh_degree, background_rgb, near_plane, far_plane, eps2d, absgrad, None)
+
+
+def _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest, viewmats, Ks, nfs, intr, width, height,
+                     sh_degree, background_rgb, near_plane, far_plane, eps2d, absgrad, pair_counters):
+    N = means.shape[0]
+    C = viewmats.shape[0]
     cfg = ProjCfg(width=width, height=height, tile_size=16, eps2d=eps2d, near_plane=near_plane, far_plane=far_plane,
                   antialiased=False, scales_are_log=True, opacities_are_logit=True, sh_degree=int(sh_degree),
                   with_depth=True, with_normals=True, want_normals_world=True)
-    pr = _ops.project(means, quats, scales, opacities.reshape(N), sh0=features_dc, shN=features_rest, viewmat=viewmat,
-                      K=K, normal_frame=nf, cfg=cfg)
+    pr = _ops.project(means, quats, scales, opacities.reshape(N), sh0=features_dc, shN=features_rest, viewmat=viewmats,
+                      K=Ks, normal_frame=nfs, cfg=cfg)
     holder: Dict = {}
+    if pair_counters is not None:
+        holder["pair_counters"] = pair_counters
     rgb, depth, normal, acc, surface_normal = _ops.rasterize_dn(
         pr["means2d"], pr["splats"], pr["depths"], pr["radii"], pr["tiles_per_gauss"], background_rgb=background_rgb,
-        width=width, height=height, intrinsics=(fx, fy, cx, cy), absgrad=absgrad, holder=holder)
+        width=width, height=height, intrinsics=intr, absgrad=absgrad, holder=holder)
     b = holder["binning"]
     info = {
-        "means2d": pr["means2d"], "radii": pr["radii"][None], "depths": pr["depths"], "conics": pr["conics"],
-        "tiles_per_gauss": pr["tiles_per_gauss"][None], "normals_world": pr["normals_world"],
-        "flatten_ids": b.flatten_ids[: b.n_isects], "isect_offsets": b.tile_offsets[:-1].reshape(1, b.tile_height, b.tile_width),
+        "means2d": pr["means2d"], "radii": pr["radii"], "depths": pr["depths"], "conics": pr["conics"],
+        "tiles_per_gauss": pr["tiles_per_gauss"], "normals_world": pr["normals_world"][-1],      # dn_model.py:558 keeps the last camera's
+        "flatten_ids": b.flatten_ids[: b.n_isects], "isect_offsets": b.tile_offsets[:-1].reshape(C, b.tile_height, b.tile_width),
         "n_isects": b.n_isects, "tile_width": b.tile_width, "tile_height": b.tile_height,
-        "width": width, "height": height, "tile_size": 16, "n_cameras": 1,
+        "width": width, "height": height, "tile_size": 16, "n_cameras": C,
     }
     return {"rgb": rgb, "depth": depth, "normal": normal, "surface_normal": surface_normal, "accumulation": acc}, info

@@ -114,7 +114,6 @@ class DNSplatterRenderer:
         self.fused = fused
         self.fused_postops = fused_postops   # also run dn_model.py:526-537,577-603 inside the HIP kernels
         self._bg_cache: Dict = {}
-        self._stream_pool: Dict = {}
         self.step = 10 ** 9  # all SH bands active unless the trainer says otherwise (dn_model.py:488-490)
         self._rasterization = rasterization_fn or rasterization
         self._rasterize_gaussians = rasterize_gaussians_fn or rasterize_gaussians
@@ -123,38 +122,52 @@ class DNSplatterRenderer:
         self.last_info: Dict = {}
 
     @torch.no_grad()
-    def get_outputs_batch(self, cameras, n_streams: int = 2):
-        """Forward-only rendering of several cameras (the render loops of the offline consumers —
-        export_mesh.py:965-1017, dn_pipeline.py:194-214, scripts/render_model.py:47-69 — call get_outputs once per
-        camera, one after the other).  The frames are independent, so they are issued round-robin on ``n_streams`` HIP
-        streams: the tail of one frame's compositing kernel (its last, partly empty round of waves) and its
-        bandwidth-bound binning overlap with the next frame's VALU-bound kernels.  The C ABI is re-entrant across
-        streams (no global state); the Python scratch buffers are kept per stream.  Returns one output dict per camera,
-        identical to what get_outputs returns for it."""
+    def get_outputs_batch(self, cameras, max_batch: int = 8):
+        """Forward-only rendering of several cameras of one image size (the render loops of the offline
+        consumers — export_mesh.py:960-1017, dn_pipeline.py:199-214, scripts/render_model.py:47-69 — call get_outputs once per
+        camera, one after the other).  Up to ``max_batch`` cameras go through ONE launch sequence: their projections are
+        stacked, binned with (camera, tile, depth) keys in one pass and composited by one launch over all their tile grids,
+        so the bandwidth-bound binning of the batch and the tails of the compositing kernels are paid once.  Returns one
+        output dict per camera, bit-identical to what get_outputs returns for it.  Renderer state (xys, radii, last_info,
+        gauss_params["normals"]) is left as after the LAST camera, as a sequential loop would leave it."""
+        gp = self.gauss_params
+        cfg = self.config
+        fused_ok = (self.fused and self.fused_postops and cfg.sh_degree > 0 and cfg.predict_normals and cfg.rasterize_mode == "classic")
+        same = all((int(c.width), int(c.height)) == (int(cameras[0].width), int(cameras[0].height)) for c in cameras)
+        if not (fused_ok and same) or len(cameras) == 1:
+            was_training, self.training = self.training, False
+            try:
+                return [self.get_outputs(c) for c in cameras]
+            finally:
+                self.training = was_training
         dev = cameras[0].camera_to_worlds.device
-        cur = torch.cuda.current_stream(dev)
-        want = max(1, min(n_streams, len(cameras)))
-        pool = self._stream_pool.setdefault(dev, [])       # reuse the same streams: scratch buffers are kept per stream
-        while len(pool) < want:
-            pool.append(torch.cuda.Stream(device=dev))
-        streams = pool[:want]
-        for s in streams:
-            s.wait_stream(cur)
+        background = self._background(dev)
+        W, H = int(cameras[0].width), int(cameras[0].height)
         outs = []
-        was_training = self.training
-        self.training = False
-        try:
-            for i, cam in enumerate(cameras):
-                with torch.cuda.stream(streams[i % len(streams)]):
-                    out = self.get_outputs(cam)
-                    for v in out.values():
-                        v.record_stream(cur)        # handed over to the caller's stream below
-                    outs.append(out)
-        finally:
-            self.training = was_training
-        for s in streams:
-            cur.wait_stream(s)
+        for i in range(0, len(cameras), max_batch):
+            chunk = cameras[i:i + max_batch]
+            out, info = _fused.render_dn_outputs_batch(
+                gp["means"], gp["quats"], gp["scales"], gp["opacities"], gp["features_dc"], gp["features_rest"], chunk, W, H,
+                sh_degree=self._sh_degree_to_use(), background_rgb=background, absgrad=False)
+            for c in range(len(chunk)):
+                d = {k: v[c] for k, v in out.items()}
+                d["background"] = background
+                outs.append(d)
+        gp["normals"] = info["normals_world"]
+        self.xys = info["means2d"][-1:]
+        self.radii = info["radii"][-1]
+        self.depths = info["depths"][-1:]
+        self.conics = info["conics"][-1:]
+        self.num_tiles_hit = info["tiles_per_gauss"][-1:]
+        self.last_info = info
         return outs
+
+    def _background(self, device):
+        background = self._bg_cache.get(device)
+        if background is None:
+            background = torch.tensor(self.config.background_color, dtype=torch.float32, device=device)
+            self._bg_cache[device] = background
+        return background
 
     def _sh_degree_to_use(self):
         c = self.config
@@ -167,10 +180,7 @@ class DNSplatterRenderer:
             raise ValueError("Unknown rasterize_mode: %s", cfg.rasterize_mode)
         c2w = camera.camera_to_worlds
         W, H = int(camera.width), int(camera.height)
-        background = self._bg_cache.get(c2w.device)
-        if background is None:
-            background = torch.tensor(cfg.background_color, dtype=torch.float32, device=c2w.device)
-            self._bg_cache[c2w.device] = background
+        background = self._background(c2w.device)
 
         means, scales, quats = gp["means"], gp["scales"], gp["quats"]
         features_dc, features_rest, opacities = gp["features_dc"], gp["features_rest"], gp["opacities"]

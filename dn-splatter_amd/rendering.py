@@ -46,15 +46,18 @@ def rasterization(
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterize 3D Gaussians to one image (see module docstring for the contract).
 
-    Differences from gsplat 1.0.0, all outside what dn-splatter exercises: one camera per call
-    (``dn_model.py:421`` asserts a single camera), ``packed`` is accepted and ignored (the info dict is
-    always the dense ``[C, N, ...]`` layout dn-splatter asks for with ``packed=False``), at most 8
-    feature channels, ``sparse_grad`` unsupported.
+    ``viewmats`` [C,4,4] / ``Ks`` [C,3,3]: C = 1 is the training call (``dn_model.py:421`` asserts a single camera); C > 1
+    renders the batch in ONE launch sequence — one binning pass over (camera, tile, depth) keys and one compositing launch
+    over all C tile grids (the render loops of export_mesh.py:960-1017, dn_pipeline.py:199-214,
+    scripts/render_model.py:47-69), with the same results, bit for bit, as C separate calls.
+
+    Differences from gsplat 1.0.0, all outside what dn-splatter exercises: ``packed`` is accepted and ignored (the info
+    dict is always the dense ``[C, N, ...]`` layout dn-splatter asks for with ``packed=False``), at most 8 feature
+    channels, one background row shared by the batch, ``sparse_grad`` unsupported.
     """
     N = means.shape[0]
     C = viewmats.shape[0]
-    if C != 1 or Ks.shape[0] != 1:
-        raise NotImplementedError("dn-splatter renders one camera per call (dn_model.py:421); got C=%d" % C)
+    assert viewmats.shape == (C, 4, 4) and Ks.shape == (C, 3, 3), (viewmats.shape, Ks.shape)
     assert means.shape == (N, 3), means.shape
     assert quats.shape == (N, 4), quats.shape
     assert scales.shape == (N, 3), scales.shape
@@ -89,8 +92,7 @@ def rasterization(
     cfg = ProjCfg(width=width, height=height, tile_size=tile_size, eps2d=eps2d, near_plane=near_plane,
                   far_plane=far_plane, radius_clip=radius_clip, antialiased=(rasterize_mode == "antialiased"),
                   sh_degree=-1 if sh_degree is None else int(sh_degree), with_depth=with_depth)
-    pr = _ops.project(means, quats, scales, opacities, coeffs=coeffs, colors=direct, viewmat=viewmats[0],
-                      K=Ks[0], cfg=cfg)
+    pr = _ops.project(means, quats, scales, opacities, coeffs=coeffs, colors=direct, viewmat=viewmats, K=Ks, cfg=cfg)
 
     holder: Dict = {}
     bg = _background_row(backgrounds, n_feat, with_depth, D)
@@ -102,26 +104,26 @@ def rasterization(
     meta = {
         "camera_ids": None,
         "gaussian_ids": None,
-        "radii": pr["radii"][None],
+        "radii": pr["radii"],
         "means2d": pr["means2d"],
         "depths": pr["depths"],
         "conics": pr["conics"],
-        "opacities": pr["splats"][:, 5][None],
+        "opacities": pr["splats"][:, 5].reshape(C, N),
         "tile_width": tw,
         "tile_height": th,
-        "tiles_per_gauss": pr["tiles_per_gauss"][None],
+        "tiles_per_gauss": pr["tiles_per_gauss"],
         "isect_ids": _LazyIsectIds(b, pr["depths"]),
         "flatten_ids": b.flatten_ids[: b.n_isects],
-        "isect_offsets": b.tile_offsets[:-1].reshape(1, th, tw),
+        "isect_offsets": b.tile_offsets[:-1].reshape(C, th, tw),
         "width": width,
         "height": height,
         "tile_size": tile_size,
-        "n_cameras": 1,
+        "n_cameras": C,
         "n_isects": b.n_isects,
     }
     if pr["compensations"] is not None:
         meta["compensations"] = pr["compensations"]
-    return render[None], alphas[None, ..., None], meta
+    return render, alphas[..., None], meta
 
 
 def _background_row(backgrounds: Optional[Tensor], n_feat: int, with_depth: bool, D: int) -> Optional[Tensor]:
@@ -130,8 +132,10 @@ def _background_row(backgrounds: Optional[Tensor], n_feat: int, with_depth: bool
     every composited channel k < D, so the row handed to it must be exactly D wide."""
     if backgrounds is None:
         return None
-    if backgrounds.dim() != 2 or backgrounds.shape[0] != 1:
-        raise ValueError(f"backgrounds must be [C, channels] with C == 1, got {tuple(backgrounds.shape)}")
+    if backgrounds.dim() != 2:
+        raise ValueError(f"backgrounds must be [C, channels], got {tuple(backgrounds.shape)}")
+    if backgrounds.shape[0] > 1 and not bool((backgrounds == backgrounds[:1]).all()):
+        raise NotImplementedError("per-camera backgrounds: the batch shares one background row")
     row = backgrounds[0]
     if with_depth and n_feat == 0:
         row = row.new_zeros(1)                      # "D" / "ED": gsplat replaces the background by zeros

@@ -21,7 +21,8 @@
  *   - All floats are fp32, row-major, layouts as in the reference tensors:
  *     means[N,3], quats[N,4] (wxyz), scales[N,3], opacities[N], SH coefficients
  *     [N,K,3] (or split band-0 / rest, dn_model.py:466-468), viewmat[4,4] world->camera
- *     OpenCV, K[3,3].  One camera per call (dn_model.py:421).
+ *     OpenCV, K[3,3].  Projection takes one camera per call (dn_model.py:421); binning and compositing also take
+ *     batches of cameras (n_cameras).
  *   - The library keeps no global mutable state; calls are re-entrant across streams.
  *
  * Splat record.  Stage 1 packs what the compositing kernels gather per tile
@@ -40,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DNSPLAT_ABI_VERSION 4
+#define DNSPLAT_ABI_VERSION 5
 #define DNSPLAT_RECORD_FLOATS 16
 #define DNSPLAT_MAX_CHANNELS 8
 
@@ -124,7 +125,8 @@ int dnsplat_pack_splats(int32_t N, const float *means2d, const float *conics, co
 size_t dnsplat_bin_workspace_bytes(int32_t N, int64_t isect_capacity, int32_t n_tiles);
 
 typedef struct dnsplat_bin_args {
-    int32_t N;
+    int32_t N;                       /* entries = n_cameras x Gaussians; entry cam * (N / n_cameras) + g is Gaussian g seen by camera cam */
+    int32_t n_cameras;               /* >= 1; images of one batch share width / height (gsplat rasterization with C cameras) */
     int32_t width, height, tile_size;
     const float *means2d;            /* [N,2] */
     const int32_t *radii;            /* [N] */
@@ -132,7 +134,7 @@ typedef struct dnsplat_bin_args {
     const int32_t *tiles_per_gauss;  /* [N] */
     int64_t isect_capacity;          /* entries flatten_ids can hold */
     int32_t *flatten_ids;            /* out [isect_capacity]: Gaussian index per sorted intersection */
-    int32_t *tile_offsets;           /* out [n_tiles+1]: first sorted index per tile; [n_tiles] = n_isects */
+    int32_t *tile_offsets;           /* out [n_cameras*n_tiles+1]: first sorted index per (camera, tile); last = n_isects */
     int64_t *n_isects;               /* out device scalar: true number of intersections (may exceed capacity) */
     int64_t *n_isects_host;          /* optional pinned host mirror, written by an async D2H copy; NULL to skip */
     void *workspace;
@@ -146,9 +148,10 @@ int dnsplat_bin_prepare(const dnsplat_bin_args *args, dnsplat_stream_t stream);
  * capacity is written and tile_offsets are clamped: the caller must re-run with
  * a larger capacity (it detects this from n_isects). */
 int dnsplat_bin_emit_sort(const dnsplat_bin_args *args, dnsplat_stream_t stream);
-/* Reconstructs gsplat's 64-bit isect_ids (tile << 32 | depth bits) for the
- * sorted list — only needed to populate the `isect_ids` entry of the info dict. */
-int dnsplat_bin_isect_ids(int32_t n_tiles, const int32_t *tile_offsets, const int32_t *flatten_ids,
+/* Reconstructs gsplat's 64-bit isect_ids (camera << (32 + tile bits) | tile << 32 | depth bits, tile bits =
+ * floor(log2(n_tiles)) + 1) for the sorted list — only needed to populate the `isect_ids` entry of the info
+ * dict.  n_tiles = tiles per camera. */
+int dnsplat_bin_isect_ids(int32_t n_tiles, int32_t n_cameras, const int32_t *tile_offsets, const int32_t *flatten_ids,
                           const float *depths, int64_t *isect_ids, int64_t capacity, dnsplat_stream_t stream);
 
 /* ------------------------------------------------------------------ stage 3/4
@@ -169,7 +172,7 @@ typedef struct dnsplat_dn_post {
     float *rgb;                  /* out [H,W,3] */
     float *depth;                /* out [H,W] expected depth, unfilled */
     float *normal;               /* out [H,W,3] */
-    float *depth_max;            /* device scalar, caller zero-fills; receives max over the image of `depth` */
+    float *depth_max;            /* device [n_cameras], caller zero-fills; receives max over each image of `depth` */
     const float *v_rgb;          /* backward: [H,W,3] */
     const float *v_depth;        /* backward: [H,W] cotangent of the FILLED depth image (masked by alpha > 0 inside) */
     const float *v_normal;       /* backward: [H,W,3] */
@@ -194,6 +197,12 @@ typedef struct dnsplat_raster_args {
                                            them with xys.detach() (dn_model.py:562). Use D for "all feed". */
     float *v_splats;                    /* [N,16] gradient records, accumulated into (caller zero-fills) */
     const dnsplat_dn_post *dn;          /* NULL, or the fused dn-splatter epilogue (then v_render / v_alphas are unused) */
+    int32_t n_cameras;                  /* 0 or 1: one image.  C > 1: images [C,H,W,.] stacked, tile_offsets [C*n_tiles+1], splat /
+                                           gradient records [C*N,16] (record cam*N + g), as produced by a dnsplat_bin_args batch */
+    uint64_t *pair_counters;            /* NULL, or device [8] (measurement builds of the fused pass, bench.py's VALU roofline), added to:
+                                           forward  [0] list entries examined  [1] splats walked (kept by the rectangle test)
+                                                    [2] live (pixel, splat) pairs evaluated  [3] pairs blended
+                                           backward [4] (pixel, splat) slots issued (steps x 128)  [5] pairs replayed */
 } dnsplat_raster_args;
 
 int dnsplat_raster_fwd(const dnsplat_raster_args *args, dnsplat_stream_t stream);
@@ -242,6 +251,37 @@ int dnsplat_sh_factors(int32_t N, const float *means, const int32_t *radii, cons
  * records in place: pass v_splats + 14). */
 int dnsplat_densify_stats(int32_t N, const int32_t *radii, const float *xy_grads, int32_t grad_stride, float inv_max_size,
                           float *xys_grad_norm, float *vis_counts, float *max_2Dsize, dnsplat_stream_t stream);
+
+/* Densification decisions of refinement_after (dn_model.py:271-386; cull rules of the inherited nerfstudio
+ * SplatfactoModel.cull_gaussians), one flag byte per Gaussian.  do_densify = the `do_densification` branch is active;
+ * screen_rules = step < stop_screen_size_at; cull_big = step > refine_every * reset_alpha_every.  Appended entries (split
+ * children, duplicates) enter the cull with max_2Dsize = 0, children with scales log(exp(s) / 1.6). */
+#define DNSPLAT_DENSIFY_SPLIT 1       /* split into n_split_samples children; the parent is then pruned */
+#define DNSPLAT_DENSIFY_DUP 2         /* duplicated once */
+#define DNSPLAT_DENSIFY_CULL 4        /* the original entry is removed */
+#define DNSPLAT_DENSIFY_CULL_CHILD 8  /* its split children would be removed right away */
+#define DNSPLAT_DENSIFY_CULL_DUP 16   /* its duplicate would be removed right away */
+typedef struct dnsplat_densify_args {
+    int32_t N;
+    const float *scales;        /* [N,3] log-scales */
+    const float *opacities;     /* [N] logits */
+    const float *xys_grad_norm; /* [N] accumulated by dnsplat_densify_stats (all-reduced over the ranks when data parallel) */
+    const float *vis_counts;    /* [N] */
+    const float *max_2Dsize;    /* [N] or NULL */
+    int32_t do_densify, screen_rules, cull_big;
+    float max_image_side;       /* max(H, W) of the last rendered frame (dn_model.py:296) */
+    float densify_grad_thresh, densify_size_thresh, split_screen_size;
+    float cull_alpha_thresh, cull_scale_thresh, cull_screen_size;
+    uint8_t *flags;             /* out [N] */
+} dnsplat_densify_args;
+int dnsplat_densify_classify(const dnsplat_densify_args *args, dnsplat_stream_t stream);
+
+/* Means and log-scales of the split children (nerfstudio split_gaussians): child j belongs to parent parents[j % n_parents]
+ * (samples are laid out sample-major, as `repeat(samps, 1)` does):
+ *     mean = mean_p + R(q_p / |q_p|) (exp(scale_p) * noise_j),   scale = log(exp(scale_p) / 1.6). */
+int dnsplat_densify_split(int32_t n_children, int32_t n_parents, const int32_t *parents, const float *noise /* [n_children,3] */,
+                          const float *means, const float *scales, const float *quats, float *new_means /* [n_children,3] */,
+                          float *new_scales /* [n_children,3] */, dnsplat_stream_t stream);
 
 /* dn-splatter's per-pixel training loss and its gradient w.r.t. the rendered images in two launches:
  *   loss = (1 - l) mean|rgb - gt| + l (1 - SSIM(rgb, gt))                       nerfstudio splatfacto RGB term, l = ssim_lambda

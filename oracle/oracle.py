@@ -324,8 +324,12 @@ def rasterization(
 ) -> Tuple[Tensor, Tensor, Dict]:
     """CPU restatement of ``gsplat.rendering.rasterization`` as called at
     ``dn_splatter/dn_model.py:495-516`` (single camera, packed=False)."""
-    assert viewmats.shape[0] == 1 and Ks.shape[0] == 1, "oracle renders one camera per call"
     assert render_mode in ("RGB", "D", "ED", "RGB+D", "RGB+ED"), render_mode
+    if viewmats.shape[0] > 1:
+        return _rasterization_batch(means, quats, scales, opacities, colors, viewmats, Ks, width, height, near_plane=near_plane,
+                                    far_plane=far_plane, radius_clip=radius_clip, eps2d=eps2d, sh_degree=sh_degree, packed=packed,
+                                    tile_size=tile_size, backgrounds=backgrounds, render_mode=render_mode, sparse_grad=sparse_grad,
+                                    absgrad=absgrad, rasterize_mode=rasterize_mode)
     assert not packed and not sparse_grad
     N = means.shape[0]
     viewmat, K = viewmats[0], Ks[0]
@@ -381,6 +385,33 @@ def rasterization(
                                        near_plane, far_plane, radius_clip, tile_size),
     }
     return render[None], alphas[None, ..., None], meta
+
+
+def _rasterization_batch(means, quats, scales, opacities, colors, viewmats, Ks, width, height, **kw):
+    """C > 1 cameras (gsplat batches them in one call; SURVEY.md A.3: keys camera << (32 + tb) | tile << 32 | depth bits,
+    values camera * N + g): the cameras are independent, so the oracle renders them one after the other and stacks."""
+    C, N = viewmats.shape[0], means.shape[0]
+    tile_size = kw.get("tile_size", 16)
+    tw, th = math.ceil(width / tile_size), math.ceil(height / tile_size)
+    tb = int(math.floor(math.log2(tw * th))) + 1
+    bgs = kw.pop("backgrounds", None)
+    outs = [rasterization(means, quats, scales, opacities, colors, viewmats[c:c + 1], Ks[c:c + 1], width, height,
+                          backgrounds=None if bgs is None else bgs[c:c + 1], **kw) for c in range(C)]
+    infos = [o[2] for o in outs]
+    base, flat, ids, offs = 0, [], [], []
+    for c, i in enumerate(infos):
+        flat.append(i["flatten_ids"] + c * N)
+        ids.append(i["isect_ids"] | (c << (32 + tb)))
+        offs.append(i["isect_offsets"] + base)
+        base += i["flatten_ids"].shape[0]
+    meta = dict(infos[0])
+    for k in ("radii", "means2d", "depths", "conics", "opacities", "tiles_per_gauss"):      # each [1, N, ...]
+        meta[k] = torch.cat([i[k] for i in infos], 0)
+    for k in ("borderline", "edge_gaussians"):                                              # [H, W] / [N]
+        meta[k] = torch.stack([i[k] for i in infos])
+    meta["per_camera_means2d"] = [i["means2d"] for i in infos]     # the leaves that receive .grad / .absgrad
+    meta.update(flatten_ids=torch.cat(flat), isect_ids=torch.cat(ids), isect_offsets=torch.cat(offs, 0), n_cameras=C)
+    return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0), meta
 
 
 def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height,

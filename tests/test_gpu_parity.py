@@ -461,6 +461,71 @@ def test_densify_stats_match_nerfstudio_after_train(dns):
     assert float(stats.vis_counts.max()) == 3.0 and float(stats.max_2Dsize.max()) > 0
 
 
+@pytest.mark.parametrize("step,kw", [(3500, {}), (2500, {}), (16000, {}), (3500, dict(cull_alpha_thresh=0.005))])
+def test_device_refinement_matches_the_reference_sequence(dns, step, kw):
+    """N3: dnsplat_densify_classify / dnsplat_densify_split and the whole device-side refinement step fed by the renderer's
+    own statistics (two cameras' backward passes through dnsplat_densify_stats), against the reference sequence
+    (oracle/densify_ref.py) on the same noise: same decisions, same new Gaussian set, same Adam moments."""
+    from dn_splatter_amd import densify, synthetic
+    from oracle import densify_ref as ref
+
+    N, W, H = 20_000, 320, 240
+    gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=3, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(4)
+    with torch.no_grad():
+        gp["scales"] += torch.randn(N, 3, device=DEV, generator=g) * 1.2 - 1.5
+        gp["opacities"] += torch.randn(N, 1, device=DEV, generator=g) * 2.5
+    m = dns.DNSplatterRenderer(gp, fused=True)
+    stats = dns.DensifyStats(N, DEV)
+    for view in (0, 3):
+        cam = synthetic.orbit_camera(view, width=W, height=H, focal=200.0).to(DEV)
+        out = m.get_outputs(cam)
+        for k in GRAD_NAMES:
+            gp[k].grad = None
+        (out["rgb"].sum() * 40 + out["depth"].sum()).backward()
+        stats.after_train(m, W, H)
+    params = {k: v.detach() for k, v in gp.items()}
+    adam = {k: {"exp_avg": torch.randn(v.shape, device=DEV, generator=g), "exp_avg_sq": torch.rand(v.shape, device=DEV, generator=g)}
+            for k, v in params.items() if k != "normals"}
+    cfg = densify.RefineConfig(**kw)
+    do_densify = step < cfg.stop_split_at
+    # the two kernels against their torch restatements
+    flags = densify.classify(params, stats, cfg, step, (H, W), do_densify)
+    flags_t = ref.classify_torch(params, stats, cfg, step, (H, W), do_densify)
+    assert int((flags != flags_t).sum()) <= 2, int((flags != flags_t).sum())      # a threshold met within an ulp of exp()
+    parents = torch.nonzero((flags & 1) != 0).reshape(-1)
+    if parents.numel():
+        noise = torch.randn(2 * parents.numel(), 3, device=DEV, generator=g)
+        cm, cs = densify.split_children(params, parents, noise)
+        cm_t, cs_t = ref.split_children_torch(params, parents, noise)
+        assert_close(cm, cm_t, "split children means", 1e-6)
+        assert_close(cs, cs_t, "split children log-scales", 1e-6)
+    # the whole step on device vs the reference-structured sequence (run in torch on the same device, same noise)
+    seen = {}
+
+    def split_spy(p, par, noise):
+        seen["noise"] = noise
+        return densify.split_children(p, par, noise)
+
+    new, new_adam, report = densify.refinement_after(params, stats, cfg, step, 100, (H, W), adam_state=adam, seed=5, split_fn=split_spy)
+    model = ref.Model(params, cfg, step, 100, (H, W), stats.xys_grad_norm.clone(), stats.vis_counts.clone(), stats.max_2Dsize.clone(), adam)
+    model.refinement_after(lambda n: seen["noise"] if n else torch.zeros(0, 3, device=DEV))
+    if int((flags != flags_t).sum()) == 0:
+        for k in params:
+            assert new[k].shape == model.gauss_params[k].shape, (k, new[k].shape, model.gauss_params[k].shape)
+            assert_close(new[k], model.gauss_params[k], "refined " + k, 1e-6)
+        for k in adam:
+            assert torch.equal(new_adam[k]["exp_avg"], model.adam[k]["exp_avg"]), k
+    assert report["n_after"] == new["means"].shape[0]
+    if do_densify:
+        assert report["n_split"] > 50 and report["n_dup"] > 50 and report["n_culled"] > 50, report
+        # the refined set renders: shapes stay consistent through the renderer
+        out = dns.DNSplatterRenderer({k: v for k, v in new.items()}, fused=True).get_outputs(synthetic.orbit_camera(1, width=W, height=H, focal=200.0).to(DEV))
+        assert bool(torch.isfinite(out["rgb"]).all())
+    else:
+        assert report["n_split"] == 0 and report["n_culled"] > 50, report
+
+
 @pytest.mark.parametrize("W,H", [(64, 48), (75, 53), (256, 200), (11, 11)])
 def test_fused_loss_matches_the_torch_loss_stack(dns, W, H):
     """N2: dnsplat_dn_loss (value + cotangents) == autograd over the PyTorch restatement of get_loss_dict."""
@@ -497,8 +562,9 @@ def test_fused_loss_matches_the_torch_loss_stack(dns, W, H):
     assert float(g_f["depth"].abs().max()) == 0.0 and float(g_f["normal"].abs().max()) == 0.0
 
 
-def test_batched_multi_stream_rendering_equals_sequential(dns):
-    """N4: get_outputs_batch (frames issued on two HIP streams) returns exactly what get_outputs returns per camera."""
+def test_batched_render_loop_equals_sequential(dns):
+    """N4: get_outputs_batch — all cameras projected, binned (camera, tile, depth) and composited in ONE launch sequence —
+    returns exactly what get_outputs returns per camera."""
     from dn_splatter_amd import synthetic
 
     N, W, H = 30_000, 320, 240
@@ -510,15 +576,65 @@ def test_batched_multi_stream_rendering_equals_sequential(dns):
     for policy in ("sync", "capacity"):
         dns.set_bin_policy(policy)
         try:
-            for n_streams in (1, 2, 3):
-                got = m.get_outputs_batch(cams, n_streams=n_streams)
+            for max_batch in (6, 4, 2):
+                got = m.get_outputs_batch(cams, max_batch=max_batch)
                 torch.cuda.synchronize()
                 assert len(got) == len(cams)
                 for a, b in zip(got, ref):
                     for k in ("rgb", "depth", "normal", "surface_normal", "accumulation"):
-                        assert torch.equal(a[k], b[k]), (policy, n_streams, k)
+                        assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), (policy, max_batch, k)
+                assert m.last_info["n_cameras"] == (max_batch if len(cams) % max_batch == 0 else len(cams) % max_batch)
         finally:
             dns.set_bin_policy("sync")
+
+
+@pytest.mark.parametrize("W,H", [(160, 128), (200, 120)])
+def test_multi_camera_rasterization_equals_sequential_calls_and_oracle(dns, orc, W, H):
+    """gsplat.rasterization with viewmats [C,4,4] (N4): the C = 4 result equals 4 single-camera calls bit for bit (images,
+    projections, per-camera tile lists), its integer outputs — flatten_ids = camera * N + g, isect_offsets [C,th,tw],
+    isect_ids with the camera bits of SURVEY.md A.3 — equal the oracle's, and the gradient of a loss over all cameras is the
+    sum of the per-camera gradients.  (200 x 120: a frame whose height is not a multiple of the tile size, so the cameras'
+    tile grids do not tile a stacked image.)"""
+    from dn_splatter_amd import synthetic
+
+    N, C = 4000, 4
+    inp, _vm, K, _ = gsplat_inputs(N, W, H, focal=0.7 * W, seed=21, anisotropic=True)
+    vms = torch.cat([dns.get_viewmat(synthetic.orbit_camera(v, width=W, height=H, focal=0.7 * W).camera_to_worlds) for v in (0, 2, 3, 5)])
+    Ks = K.expand(C, 3, 3).contiguous()
+    kw = dict(width=W, height=H, packed=False, sh_degree=3, render_mode="RGB+ED", absgrad=True)
+    gi = to_leaf(inp, DEV)
+    r_b, a_b, info_b = dns.rasterization(**gi, viewmats=vms.to(DEV), Ks=Ks.to(DEV), **kw)
+    assert r_b.shape == (C, H, W, 4) and a_b.shape == (C, H, W, 1) and info_b["n_cameras"] == C
+    assert info_b["radii"].shape == (C, N) and info_b["means2d"].shape == (C, N, 2)
+    v_r, v_a = cotangents([r_b.shape, a_b.shape], 5)
+    info_b["means2d"].retain_grad()
+    ((r_b * v_r.to(DEV)).sum() + (a_b * v_a.to(DEV)).sum()).backward()
+    # sequential single-camera calls
+    gs = to_leaf(inp, DEV)
+    base = 0
+    th, tw = info_b["tile_height"], info_b["tile_width"]
+    for c in range(C):
+        r, a, info = dns.rasterization(**gs, viewmats=vms[c:c + 1].to(DEV), Ks=Ks[c:c + 1].to(DEV), **kw)
+        assert torch.equal(r[0], r_b[c]) and torch.equal(a[0], a_b[c]), f"camera {c}: batched image differs"
+        for k in ("radii", "means2d", "depths", "conics", "tiles_per_gauss"):
+            assert torch.equal(info[k][0], info_b[k][c]), (c, k)
+        n = info["n_isects"]
+        assert torch.equal(info["flatten_ids"] + c * N, info_b["flatten_ids"][base:base + n]), f"camera {c}: tile lists"
+        assert torch.equal(info["isect_offsets"][0] + base, info_b["isect_offsets"][c])
+        base += n
+        info["means2d"].retain_grad()
+        ((r * v_r[c:c + 1].to(DEV)).sum() + (a * v_a[c:c + 1].to(DEV)).sum()).backward()     # accumulates over the cameras
+        assert_close(info_b["means2d"].grad[c], info["means2d"].grad[0], f"camera {c} means2d.grad", 1e-5)
+        assert_close(info_b["means2d"].absgrad[c], info["means2d"].absgrad[0], f"camera {c} means2d.absgrad", 1e-5)
+    assert base == info_b["n_isects"]
+    for k in gi:
+        assert_close(gi[k].grad, gs[k].grad, "batched grad " + k, 1e-5)              # atomics order only
+    # the oracle's batch (gsplat key layout)
+    with torch.no_grad():
+        _r, _a, info_o = orc.rasterization(**inp, viewmats=vms, Ks=Ks, **kw)
+    for k in INT_KEYS:
+        assert_equal_int(info_b[k], info_o[k], "batch " + k)
+    assert_equal_int(info_b["isect_ids"].get(), info_o["isect_ids"], "batch isect_ids (camera bits)")
 
 
 @pytest.mark.parametrize("layout", ["split", "cat"])

@@ -145,3 +145,50 @@ def test_torch_loss_stack_restatement():
     # scale term: mean over Gaussians of the smallest exp(scale)  (regularization_strategy.py:195-199)
     only_scale = tl.dn_loss({k: v.detach() for k, v in out.items()}, {"image": out["rgb"].detach()}, scales)
     assert abs(float(only_scale) - float(torch.exp(scales).min(dim=1)[0].mean())) < 1e-6
+
+
+@pytest.mark.parametrize("step,kw", [(3500, {}), (2500, {}), (3100, {}), (16000, {}), (3500, dict(cull_alpha_thresh=0.005)),
+                                     (16000, dict(continue_cull_post_densification=False)), (400, {})])
+def test_refinement_step_equals_the_reference_sequence(step, kw):
+    """N3: densify.refinement_after (flag byte -> index gathers) against the statement-by-statement restatement of
+    DNSplatterModel.refinement_after + the nerfstudio helpers (oracle/densify_ref.py: boolean masks, cat, cull over the
+    concatenation) on identical split noise — every branch: densify with and without the screen-size / too-big rules,
+    opacity reset, cull-only after stop_split_at, dn-splatter-big's thresholds, warm-up.  Includes the reference's quirk
+    that a split parent whose shrunk scale falls under densify_size_thresh is duplicated as well."""
+    from dn_splatter_amd import densify, synthetic
+    from oracle import densify_ref as ref
+
+    N = 4000
+    gp = {k: v.detach() for k, v in synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=1).items()}
+    g = torch.Generator().manual_seed(2)
+    gp["scales"] = gp["scales"] + torch.randn(N, 3, generator=g) * 1.5 - 3.5
+    gp["opacities"] = gp["opacities"] + torch.randn(N, 1, generator=g) * 2
+    gp["normals"] = torch.randn(N, 3, generator=g)
+    stats = densify.DensifyStats(N, "cpu")
+    stats.xys_grad_norm = torch.rand(N, generator=g) * 0.01
+    stats.vis_counts = torch.randint(1, 5, (N,), generator=g).float()
+    stats.max_2Dsize = torch.rand(N, generator=g) * 0.1
+    adam = {k: {"exp_avg": torch.randn(v.shape, generator=g), "exp_avg_sq": torch.rand(v.shape, generator=g), "step": torch.tensor(7.0)}
+            for k, v in gp.items() if k != "normals"}
+    cfg = densify.RefineConfig(**kw)
+    seen = {}
+
+    def split_fn(params, parents, noise):
+        seen["noise"] = noise
+        return ref.split_children_torch(params, parents, noise)
+
+    new, new_adam, report = densify.refinement_after(gp, stats, cfg, step, 100, (480, 640), adam_state=adam, seed=3,
+                                                     classify_fn=ref.classify_torch, split_fn=split_fn)
+    m = ref.Model(gp, cfg, step, 100, (480, 640), stats.xys_grad_norm.clone(), stats.vis_counts.clone(), stats.max_2Dsize.clone(), adam)
+    m.refinement_after(lambda n: seen["noise"] if n else torch.zeros(0, 3))
+    for k in gp:
+        assert new[k].shape == m.gauss_params[k].shape, (k, new[k].shape, m.gauss_params[k].shape)
+        assert torch.allclose(new[k], m.gauss_params[k], atol=1e-6), k
+    for k in adam:
+        assert torch.equal(new_adam[k]["exp_avg"], m.adam[k]["exp_avg"]) and torch.equal(new_adam[k]["exp_avg_sq"], m.adam[k]["exp_avg_sq"]), k
+    assert report["n_after"] == new["means"].shape[0]
+    if step in (3500, 2500):
+        assert report["n_split"] > 1000 and report["n_dup"] > 100 and report["n_culled"] > 1000
+    if step == 3100:
+        assert report["opacity_reset"] and float(new["opacities"].max()) <= float(torch.logit(torch.tensor(0.2))) + 1e-6
+        assert float(new_adam["opacities"]["exp_avg"].abs().max()) == 0.0

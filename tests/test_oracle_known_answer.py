@@ -195,3 +195,33 @@ def test_legacy_rasterize_gaussians_defaults(orc):
     none = orc.rasterize_gaussians(info["means2d"][0], info["depths"][0], torch.zeros(500, dtype=torch.int32), info["conics"][0],
                                    torch.zeros(500, dtype=torch.int32), cols, inp["opacities"][:, None], 48, 64, 16)
     assert torch.equal(none, torch.ones(48, 64, 3))
+
+
+def test_projection_edge_flags_cover_last_place_jitter(orc):
+    """orc_project_edge marks the Gaussians whose integer outputs may change when the activated inputs differ in the last
+    place (torch's exp / normalisation on the CPU vs the fused kernel's): perturbing scales and quaternions by up to
+    +-2 ulp must never change a radius or a tile count of an unmarked Gaussian — and the marked set stays small."""
+    import numpy as np
+    import torch
+
+    from _scenes import gsplat_inputs
+
+    W, H = 640, 480
+    inp, viewmat, K, _ = gsplat_inputs(200_000, W, H, focal=400.0, seed=3, anisotropic=False)
+    g = torch.Generator().manual_seed(0)
+
+    def jitter(t):
+        a = t.numpy().copy().view(np.int32)
+        a += torch.randint(-2, 3, t.shape, generator=g).numpy().astype(np.int32)
+        return torch.from_numpy(a.view(np.float32))
+
+    with torch.no_grad():
+        edge = orc.project_edge(inp["means"], inp["quats"], inp["scales"], viewmat[0], K[0], W, H)
+        ref = orc.project_fwd(inp["means"], inp["quats"], inp["scales"], viewmat[0], K[0], W, H)
+        changed = torch.zeros_like(edge)
+        for _ in range(3):
+            got = orc.project_fwd(inp["means"], jitter(inp["quats"]), jitter(inp["scales"]), viewmat[0], K[0], W, H)
+            changed |= (got[0] != ref[0]) | (got[5] != ref[5])
+    assert int(changed.sum()) > 0, "the jitter moved no integer at all: the test scene is too easy"
+    assert int((changed & ~edge).sum()) == 0
+    assert int(edge.sum()) < 0.02 * edge.numel()
