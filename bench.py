@@ -18,8 +18,12 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                   bracketed with events inside the timed region (an event pair costs a ~6 us bubble on the stream);
                   the other entries of `stages` come from PROBE_STEPS fully instrumented steps run between the
                   warm-up and the timed region;
+  roofline_valu — the roofline that actually binds the two compositing kernels: (pixel, splat) pairs counted by the
+                  measurement instantiation of the kernels in ONE extra step outside the timed region, x flops per pair
+                  (counted from the kernel source, DESIGN.md §4), / the stage times, against 157.3 TFLOP/s fp32 vector;
   cpu_baseline  — the CPU oracle (a port: the reference has no CPU rasterizer and gsplat's needs CUDA) timed on
-                  the host cores on a bounded crop of the same workload.
+                  the host cores on one full frame of the same workload (a centre crop with --cpu-crop).
+For N > 1 also `multi_gpu`: exchange time exposed / hidden, bytes per GPU and per xGMI link, max / mean intersections per rank.
 """
 from __future__ import annotations
 
@@ -36,6 +40,12 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, guides/MI355X_MICROARCH.md "Chip-level parameters"
+VALU_PEAK_TFLOPS = 157.3  # fp32 vector peak (256 CUs x 4 SIMD32 x 2 flops x 2.4 GHz x packed 2), cdna_hip_programming.md
+# flops per (pixel, splat) pair, counted from the kernel sources for the fused 7-channel pass (FMA = 2):
+#   forward  dx, dy (2) + exponent (u, w: 2 FMA; dy*w; FMA = 7) + exp2, x opacity, min (3) + T(1-alpha) (2) + alpha T (1) + 7 channel FMAs (14)
+#   backward exponent (9) + exp2, x opacity (2) + 1-alpha, rcp, T chain (3) + alpha T (1) + 14 channel FMAs (28) + v_alpha of the two
+#            groups (10) + v_sigma (2) + conic sums (2 mul + 3 FMA = 8) + mean sums (2 mul + 2 add + 2 |.| add = 6) + opacity sum (2) + S chains (4)
+FLOPS_PER_PAIR = {"dnsplat_raster_fwd": 29, "dnsplat_raster_bwd": 75}
 
 WORKLOADS = {
     # name: (N Gaussians, width, height, focal)  — BASELINE.json configs[0..2]; focal is builder-chosen
@@ -52,6 +62,20 @@ SH_K = 16
 D_CH = 7
 
 
+def kernel_source_sha16():
+    """Hash of everything that determines the device code (csrc/*.hip, *.h, include/*.h, the build script)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "dn-splatter_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".sh")))
+    files += sorted(os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def stage_bytes(N, Nv, I, P, T):
     """Algorithmic HBM bytes per launch of each stage (SURVEY.md §8(d) terms re-grouped by our five stages;
     they sum to B = 84 N + 796 Nv + 216 I + 76 P + 12 T).  DESIGN.md "Roofline accounting" derives each."""
@@ -64,10 +88,11 @@ def stage_bytes(N, Nv, I, P, T):
     }
 
 
-def cpu_baseline(workload, crop=896):
+def cpu_baseline(workload, crop=None):
     """Times the CPU oracle — the reference's own two-call sequence (rasterization + legacy
-    rasterize_gaussians, dn_model.py:495-575) through the same host mirror — on a centre crop of the same
-    scene and scales by the pixel ratio.  Test infrastructure used as the checker/baseline only."""
+    rasterize_gaussians, dn_model.py:495-575) through the same host mirror — on ONE FULL FRAME of the same scene
+    (~20 s on 32 threads at C2); with ``crop`` on a centre crop scaled by the pixel ratio (hosts with few cores).
+    Test infrastructure used as the checker/baseline only."""
     import dn_splatter_amd as dns
     from dn_splatter_amd import synthetic
     from dn_splatter_amd.model import Camera
@@ -80,7 +105,9 @@ def cpu_baseline(workload, crop=896):
     torch.set_num_threads(cores)     # torch and the oracle share the process' OpenMP runtime (libgomp)
     gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=0)
     cam = synthetic.orbit_camera(0, width=W, height=H, focal=focal)
-    cw, ch = min(crop, W), min(crop, H)
+    if crop is None and (os.cpu_count() or 1) < 16:
+        crop = 512                                     # a full 1080p frame would take minutes on a small host
+    cw, ch = (W, H) if crop is None else (min(crop, W), min(crop, H))
     x0, y0 = (W - cw) // 2, (H - ch) // 2
     ccam = Camera(cam.camera_to_worlds, cam.fx, cam.fy, cam.cx - x0, cam.cy - y0, cw, ch)
     params = {k: v.detach().requires_grad_(k != "normals") for k, v in gp.items()}
@@ -97,10 +124,13 @@ def cpu_baseline(workload, crop=896):
         "value": 1.0 / (dt * scale),
         "unit": "frames/s",
         "cores": cores,
+        "host_cpu_count": os.cpu_count(),
         "kind": "port",
-        "sample": (f"oracle fwd+bwd of a {cw}x{ch} centre crop of the {workload} scene (all {N} Gaussians projected, "
-                   f"{int(m.last_info['flatten_ids'].shape[0])} intersections) took {dt:.2f} s on {cores} threads; "
-                   f"value = 1/(t x {scale:.1f} pixel ratio)"),
+        "sample": (f"oracle fwd+bwd of {'one full ' + str(cw) + 'x' + str(ch) + ' frame' if scale == 1.0 else 'a ' + str(cw) + 'x' + str(ch) + ' centre crop'} "
+                   f"of the {workload} scene (all {N} Gaussians projected, "
+                   f"{int(m.last_info['flatten_ids'].shape[0])} intersections) took {dt:.2f} s on {cores} of the host's "
+                   f"{os.cpu_count()} hardware threads (the oracle's gradient scatter uses omp atomics and gets slower beyond ~32)"
+                   + ("" if scale == 1.0 else f"; value = 1/(t x {scale:.1f} pixel ratio)")),
     }
 
 
@@ -111,6 +141,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-crop", type=int, default=None, help="time the CPU baseline on a centre crop of this size instead of a full frame")
     ap.add_argument("--bin-policy", default="capacity", choices=["sync", "capacity"])
     ap.add_argument("--dense-allreduce", action="store_true",
                     help="all-reduce the full 236 B/Gaussian bucket instead of exchanging the SH gradients as factors")
@@ -188,6 +219,15 @@ def main():
         return st[name][1] if name in st else None
 
     probe_ms = {name: stage_ms(pstats, name, PROBE_STEPS) for name in STAGE_NAMES}
+    # one step through the COUNTING instantiation of the compositing kernels (outside the timed region)
+    counts = None
+    if not args.two_call and not args.torch_postops:
+        from dn_splatter_amd import _ops
+        _ops.PAIR_COUNTERS = torch.zeros(8, dtype=torch.int64, device=dev)
+        step()
+        torch.cuda.synchronize()
+        counts = _ops.PAIR_COUNTERS.tolist()
+        _ops.PAIR_COUNTERS = None
     dominant = max((n for n in probe_ms if probe_ms[n] is not None), key=lambda n: probe_ms[n])
     live = ("dnsplat_bin_prepare", "dnsplat_bin_emit_sort") if dominant == "binning" else (dominant,)
     dp.barrier()
@@ -222,26 +262,95 @@ def main():
             continue
         stages[name] = {"ms": round(ms, 4), "alg_bytes": b, "GBps": round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
                         "measured": "timed region" if name == dominant else f"{PROBE_STEPS} instrumented steps before it"}
-    pmc_traffic = None
+    # HBM bytes per launch from the PMC passes (tools/pmc_traffic.sh -> profiles/pmc_traffic.json: separate FETCH_SIZE and
+    # WRITE_SIZE runs of this very command, as MI355X_MICROARCH.md prescribes).  The file records the hash of the kernel
+    # sources it was measured on: a figure taken on other kernels is not reported.
+    pmc_traffic, traffic_note, stage_traffic = None, None, {}
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
-            pmc = json.load(open(pmc_path))
-            ent = pmc.get(args.workload, {}).get(dominant)
-            if ent:
-                pmc_traffic = ent["hbm_bytes_per_launch"]
-        except Exception:
-            pmc_traffic = None
+            ent_w = json.load(open(pmc_path)).get(args.workload, {})
+            if ent_w.get("source_sha16") == kernel_source_sha16():
+                stage_traffic = {k: v["hbm_bytes_per_launch"] for k, v in ent_w.items() if isinstance(v, dict)}
+                pmc_traffic = stage_traffic.get(dominant)
+            else:
+                traffic_note = (f"profiles/pmc_traffic.json[{args.workload}] was measured on kernel sources "
+                                f"{ent_w.get('source_sha16')}, this build is {kernel_source_sha16()}: re-run tools/pmc_traffic.sh")
+        except Exception as e:
+            traffic_note = f"profiles/pmc_traffic.json unreadable: {e!r}"
+    for name, t in stage_traffic.items():
+        if name in stages:
+            stages[name]["hbm_traffic"] = t
     ach = stages[dominant]["GBps"]
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic,
                 "alg_bytes_per_launch": sb[dominant], "ms_per_launch": stages[dominant]["ms"]}
+    if traffic_note:
+        roofline["traffic_note"] = traffic_note
+    # VALU roofline of the two compositing kernels (what binds them: DESIGN.md §4)
+    roofline_valu = None
+    if counts is not None:
+        c = [int(x) for x in counts]
+        roofline_valu = {"bound": "valu", "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "pairs": {"list_entries_examined": c[0], "splats_walked": c[1], "fwd_pairs_evaluated": c[2],
+                                   "pairs_blended": c[3], "bwd_slots_issued": c[4], "bwd_pairs_replayed": c[5]},
+                         "flops_per_pair": FLOPS_PER_PAIR}
+        for name, issued, useful in (("dnsplat_raster_fwd", c[2], c[3]), ("dnsplat_raster_bwd", c[4], c[5])):
+            if name in stages and stages[name]["ms"] > 0:
+                t = stages[name]["ms"] * 1e-3
+                f = FLOPS_PER_PAIR[name]
+                roofline_valu[name] = {"achieved": round(issued * f / t / 1e12, 2), "frac": round(issued * f / t / 1e12 / VALU_PEAK_TFLOPS, 4),
+                                       "useful_achieved": round(useful * f / t / 1e12, 2),
+                                       "useful_frac": round(useful * f / t / 1e12 / VALU_PEAK_TFLOPS, 4),
+                                       "useful_pair_fraction": round(useful / max(issued, 1), 4)}
     B = sum(sb.values())
     fps_total = world * args.steps / elapsed
     frame_roofline = {"alg_bytes_per_frame": B, "achieved_GBps": round(B * (args.steps / elapsed) / 1e9, 1),
                       "frac": round(B * (args.steps / elapsed) / 1e9 / HBM_PEAK_GBS, 4)}
     gpu_stage_ms = sum(v["ms"] for v in stages.values())
     i_all = dp.sum_over_ranks([float(I)], dev)[0]
+
+    # ---- multi-GPU accounting, all outside the timed region ----------------------------------------
+    multi = None
+    if world > 1 or os.environ.get("DNSPLAT_FORCE_DIST", "0") == "1":
+        K2 = max(3, min(10, args.steps))
+
+        def timed(fn, n):
+            dp.barrier(); torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize(); dp.barrier()
+            return dp.max_over_ranks((time.perf_counter() - t) / n, dev) * 1e3
+
+        def compute_only():
+            for k in dp.GRAD_KEYS:
+                gp[k].grad = None
+            out = renderer.get_outputs(cam)
+            torch.autograd.backward([out[k] for k in OUT_KEYS], [cot[k] for k in OUT_KEYS])
+
+        def exchange_only():
+            # the same collectives on the same buffers, nothing to hide behind
+            if exchange is not None:
+                exchange.begin(N, dev, 3, 16)
+                exchange.launch()
+            dp.allreduce_gradients(gp, arena, exchange=exchange)
+
+        dns.set_sh_exchange(None)                # kernels write the SH rows themselves, no collective is started
+        t_compute = timed(compute_only, K2)
+        dns.set_sh_exchange(exchange)
+        step(); step()
+        t_step = timed(step, K2)
+        t_comm = timed(exchange_only, K2)
+        exposed = max(0.0, t_step - t_compute)
+        per_rank_I = dp.gather_over_ranks(float(I), dev)
+        multi = {"step_ms": round(t_step, 4), "compute_only_ms": round(t_compute, 4), "exchange_alone_ms": round(t_comm, 4),
+                 "exchange_exposed_ms": round(exposed, 4), "exchange_hidden_ms": round(max(0.0, t_comm - exposed), 4),
+                 "bytes_exchanged_per_gpu_per_step": int(wire),
+                 "bytes_per_xgmi_link_per_step": int(wire / max(world - 1, 1)),
+                 "link_note": "per-GPU bytes spread evenly over the W-1 direct xGMI links of the fully connected node",
+                 "isects_per_rank": [int(x) for x in per_rank_I],
+                 "isects_max_over_mean": round(max(per_rank_I) / (sum(per_rank_I) / len(per_rank_I)), 4)}
 
     if rank == 0:
         res = {
@@ -262,7 +371,9 @@ def main():
                                        + ("geometry grads all-reduced, SH grads all-gathered as factors)" if exchange is not None
                                           else "one all-reduce of the flat gradient bucket)")) if world > 1 else "single GPU"},
             "roofline": roofline,
+            "roofline_valu": roofline_valu,
             "frame_roofline": frame_roofline,
+            "multi_gpu": multi,
             "stages": stages,
             "other_ms_torch_postops_autograd_host": round(1e3 * elapsed / args.steps - gpu_stage_ms, 4),
         }
@@ -270,7 +381,7 @@ def main():
             dns.set_grad_arena(None)
             dns.set_sh_exchange(None)
             try:
-                res["cpu_baseline"] = cpu_baseline(args.workload)
+                res["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_crop)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}

@@ -108,7 +108,7 @@ class RasterArgs(ctypes.Structure):
         ("xy_split", c_int32),
         ("v_splats", c_void_p),
         ("dn", ctypes.POINTER(DnPost)),
-        ("n_cameras", c_int32), ("pair_counters", c_void_p),
+        ("n_cameras", c_int32), ("keep_masks", c_void_p), ("keep_mask_stride", c_int64), ("pair_counters", c_void_p),
     ]
 
 

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -522,6 +523,14 @@ def rasterize(means2d, splats, depths, radii, tiles, *, background=None, width, 
     return render, alphas
 
 
+# The fused pass hands the forward's per-half-tile rectangle-test results to the backward (dnsplat_raster_args.keep_masks);
+# DNSPLAT_KEEP_MASKS=0 makes the backward re-derive them (kernel A/B runs).
+KEEP_MASKS = os.environ.get("DNSPLAT_KEEP_MASKS", "1") != "0"
+
+# Measurement hook (bench.py's VALU roofline): a uint64 [8] device tensor makes the fused pass run the COUNTING instantiation of
+# both compositing kernels, which tally list entries / splats walked / pairs evaluated / pairs blended / slots issued.
+PAIR_COUNTERS: Optional[Tensor] = None
+
 _BG7: Dict[torch.device, Tensor] = {}
 
 
@@ -551,7 +560,7 @@ class _RasterDnFn(torch.autograd.Function):
         rgb = torch.empty(C, height, width, 3, **f32)
         depth_raw = torch.empty(C, height, width, **f32)
         normal = torch.empty(C, height, width, 3, **f32)
-        depth_max = torch.zeros(C, **f32)
+        depth_max = torch.empty(C, **f32)               # zeroed in composite() (again if the capacity guess forces a re-run)
         depth_out = torch.empty(C, height, width, 1, **f32)
         surface_normal = torch.empty(C, height, width, 3, **f32)
         bg_rgb = _f32c(bg_rgb, "background")
@@ -560,11 +569,20 @@ class _RasterDnFn(torch.autograd.Function):
         dn.background_rgb, dn.rgb, dn.depth, dn.normal = _ptr(bg_rgb), _ptr(rgb), _ptr(depth_raw), _ptr(normal)
         dn.depth_max = _ptr(depth_max)
         counters = holder.get("pair_counters") if holder is not None else None
+        if counters is None:
+            counters = PAIR_COUNTERS
+        keep = {}
 
         def composite(b: Binning):
             depth_max.zero_()
             a = RasterArgs()
             a.n_cameras = C
+            if KEEP_MASKS:
+                # the forward's rectangle-test ballots, one 64-bit word per (half tile, 64 list entries): the backward takes
+                # them instead of re-testing (and re-gathering) every list entry
+                stride = (b.flatten_ids.numel() >> 6) + C * b.tile_width * b.tile_height + 1
+                keep["masks"], keep["stride"] = torch.empty(2 * stride, dtype=torch.int64, device=dev), stride
+                a.keep_masks, a.keep_mask_stride = _ptr(keep["masks"]), stride
             a.width, a.height, a.tile_size, a.D = width, height, 16, 7
             a.splats, a.flatten_ids, a.tile_offsets = _ptr(splats), _ptr(b.flatten_ids), _ptr(b.tile_offsets)
             a.background = _ptr(bg7)
@@ -583,6 +601,7 @@ class _RasterDnFn(torch.autograd.Function):
         if holder is not None:
             holder["binning"] = b
         ctx.save_for_backward(means2d, splats, b.flatten_ids, b.tile_offsets, render, alphas, last_ids, bg_rgb)
+        ctx.keep = keep
         ctx.cfg = (width, height, absgrad, C, counters)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(surface_normal)
@@ -615,6 +634,8 @@ class _RasterDnFn(torch.autograd.Function):
         a.v_splats = _ptr(v_splats)
         a.dn = ctypes.pointer(dn)
         a.pair_counters = _ptr(counters)
+        if ctx.keep:
+            a.keep_masks, a.keep_mask_stride = _ptr(ctx.keep["masks"]), ctx.keep["stride"]
         _lib.run("dnsplat_raster_bwd", _lib.lib().dnsplat_raster_bwd, ctypes.byref(a), _stream())
         if absgrad:
             means2d.absgrad = v_splats[:, 14:16].reshape(means2d.shape)

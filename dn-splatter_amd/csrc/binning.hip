@@ -71,34 +71,33 @@ __device__ __forceinline__ uint32_t block_incl_scan_256(uint32_t v, uint32_t *ld
     return inc + base;
 }
 
-__global__ void set_u32_kernel(uint32_t *p, uint32_t v) { *p = v; }
-
-// ------------------------------------------------------------------------------------------------
-// 1. depth keys
-__global__ __launch_bounds__(256) void depth_keys_kernel(int N, const int32_t *__restrict__ radii,
-                                                         const float *__restrict__ depths,
-                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
-{
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= N) return;
-    // visible Gaussians have depth >= near_plane > 0, so the raw bits order like the floats; culled
-    // ones sort to the very end and emit nothing.
-    keys[g] = radii[g] > 0 ? __float_as_uint(depths[g]) : 0xFFFFFFFFu;
-    vals[g] = (uint32_t)g;
-}
-
 // ------------------------------------------------------------------------------------------------
 // 2. one LSD radix pass = histogram, per-digit scan, stable scatter
 // K = key type: uint32_t for the depth keys, uint16_t for tile ids (any image up to 65536 tiles), which halves the
 // key traffic of the two I-sized passes.
-template <typename K, int ITEMS>
+// Depth key of entry g: visible Gaussians have depth >= near_plane > 0, so the raw bits order like the floats; culled ones
+// sort to the very end and emit nothing.  The first depth pass reads (radii, depths) directly — key = depth_key(g), value = g —
+// instead of a key / value pair a separate kernel would have to write first.
+__device__ __forceinline__ uint32_t depth_key(const int32_t *__restrict__ radii, const float *__restrict__ depths, uint32_t g)
+{
+    return radii[g] > 0 ? __float_as_uint(depths[g]) : 0xFFFFFFFFu;
+}
+
+// FIRST = first pass of the depth sort (keys synthesised from radii / depths, n given by value: n_ptr may be NULL)
+template <typename K, int ITEMS, bool FIRST = false>
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const K *__restrict__ keys,
                                                                 const uint32_t *__restrict__ n_ptr, uint32_t n_cap,
                                                                 int shift, uint32_t mask, uint32_t *__restrict__ table,
-                                                                int nb)
+                                                                int nb, const int32_t *__restrict__ radii = nullptr,
+                                                                const float *__restrict__ depths = nullptr,
+                                                                int32_t *__restrict__ tile_first = nullptr, int n_tiles = 0)
 {
     __shared__ uint32_t hist[RS_DIGITS];
-    const uint32_t n = min(*n_ptr, n_cap);
+    const uint32_t n = n_ptr ? min(*n_ptr, n_cap) : n_cap;
+    // first pass of the tile sort: also presets the tile offsets to n (the last scatter pass lowers the non-empty tiles'
+    // entries with atomicMin, tile_offsets_fill gives the empty ones the offset of the next non-empty tile)
+    if (tile_first)
+        for (int i = blockIdx.x * RS_THREADS + threadIdx.x; i <= n_tiles; i += gridDim.x * RS_THREADS) tile_first[i] = (int32_t)n;
     hist[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * (RS_THREADS * ITEMS);
@@ -106,7 +105,10 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const K *__restr
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             uint32_t idx = base + i * RS_THREADS + threadIdx.x;
-            if (idx < n) atomicAdd(&hist[((uint32_t)keys[idx] >> shift) & mask], 1u);
+            if (idx < n) {
+                const uint32_t k = FIRST ? depth_key(radii, depths, idx) : (uint32_t)keys[idx];
+                atomicAdd(&hist[(k >> shift) & mask], 1u);
+            }
         }
     }
     __syncthreads();
@@ -150,11 +152,12 @@ __global__ __launch_bounds__(SC_THREADS) void radix_scan_kernel(uint32_t *__rest
 // a tile's entries start is.  Inside one digit's run of the LDS-sorted chunk the keys are non-decreasing (the stream
 // was already sorted on the lower bits and the pass is stable), so "key differs from its left neighbour" marks the
 // chunk-local first entry of a tile; the minimum of those positions over the chunks is the tile's offset.
-template <typename K, bool LAST, int DBITS, int ITEMS>
+template <typename K, bool LAST, int DBITS, int ITEMS, bool FIRST = false>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ n_ptr, uint32_t n_cap, int shift,
-    const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nb, int32_t *__restrict__ tile_first)
+    const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nb, int32_t *__restrict__ tile_first,
+    const int32_t *__restrict__ radii = nullptr, const float *__restrict__ depths = nullptr)
 {
     // The chunk is first sorted by digit INSIDE LDS (stable), then written out run by run: consecutive lanes
     // store to consecutive addresses of one digit's run, so the stores coalesce.  A direct scatter from the
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     __shared__ uint32_t vals_s[CHUNK];
     __shared__ uint32_t lds_wave[4];
     constexpr uint32_t DMASK = (1u << DBITS) - 1u;
-    const uint32_t n = min(*n_ptr, n_cap);
+    const uint32_t n = n_ptr ? min(*n_ptr, n_cap) : n_cap;
     const uint32_t base = blockIdx.x * CHUNK;
     if (base >= n) return;
     const uint32_t n_valid = min((uint32_t)CHUNK, n - base);
@@ -187,8 +190,13 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     for (int r = 0; r < ITEMS; ++r) {
         const uint32_t idx = wave_start + r * DNS_WAVE + lane;
         const bool valid = idx < n;
-        key[r] = valid ? (uint32_t)keys_in[idx] : 0u;
-        val[r] = valid ? vals_in[idx] : 0u;
+        if (FIRST) {
+            key[r] = valid ? depth_key(radii, depths, idx) : 0u;
+            val[r] = idx;
+        } else {
+            key[r] = valid ? (uint32_t)keys_in[idx] : 0u;
+            val[r] = valid ? vals_in[idx] : 0u;
+        }
         const uint32_t d = (key[r] >> shift) & DMASK;
         // match-any by digit: DBITS ballots partition the wave into equal-digit lane sets
         uint64_t m = dns_ballot(valid);
@@ -268,20 +276,6 @@ __global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(int N, const uint
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(SC_THREADS) void scan_sums_excl_kernel(uint32_t *__restrict__ sums, int nb)
-{
-    __shared__ uint32_t lds_wave[4];
-    uint32_t carry = 0;
-    for (int start = 0; start < nb; start += SC_THREADS) {
-        int i = start + threadIdx.x;
-        uint32_t v = (i < nb) ? sums[i] : 0u;
-        uint32_t tot;
-        uint32_t inc = block_incl_scan_256(v, lds_wave, tot);
-        if (i < nb) sums[i] = carry + inc - v;
-        carry += tot;
-    }
-}
-
 __global__ __launch_bounds__(SC_THREADS) void scan_final_kernel(int N, const uint32_t *__restrict__ order,
                                                                 const int32_t *__restrict__ tiles,
                                                                 const uint32_t *__restrict__ sums,
@@ -298,9 +292,15 @@ __global__ __launch_bounds__(SC_THREADS) void scan_final_kernel(int N, const uin
         v[i] = (j < N) ? (uint32_t)tiles[order[j]] : 0u;
         s += v[i];
     }
+    // exclusive prefix of the chunk sums: every workgroup adds up the (few hundred) sums of the chunks before it itself,
+    // which is cheaper than a separate single-workgroup scan launch between the two passes
+    uint32_t before = 0;
+    for (int c = threadIdx.x; c < (int)blockIdx.x; c += SC_THREADS) before += sums[c];
+    uint32_t tot_before;
+    block_incl_scan_256(before, lds_wave, tot_before);
     uint32_t tot;
     uint32_t inc = block_incl_scan_256(s, lds_wave, tot);
-    uint32_t run = sums[blockIdx.x] + inc - s;
+    uint32_t run = tot_before + inc - s;
 #pragma unroll
     for (int i = 0; i < SC_ITEMS; ++i) {
         int j = base + i;
@@ -376,16 +376,9 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int n_per_cam, const u
 
 // ------------------------------------------------------------------------------------------------
 // 5. tile offsets (gsplat isect_offset_encode), T+1 entries: offsets[t] = number of entries with tile id < t.
-// tile_first_init fills the array with n; the last scatter pass lowers the entries of the non-empty tiles to the
+// The first histogram pass of the tile sort fills the array with n; the last scatter pass lowers the entries of the non-empty tiles to the
 // position of their first entry (atomicMin); tile_offsets_fill gives every empty tile the offset of the next
 // non-empty one (a suffix minimum), which is the same number.
-__global__ __launch_bounds__(256) void tile_first_init_kernel(const uint32_t *__restrict__ n_ptr, uint32_t n_cap, int n_tiles,
-                                                              int32_t *__restrict__ offsets)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= n_tiles) offsets[i] = (int32_t)min(*n_ptr, n_cap);
-}
-
 constexpr int TO_THREADS = 1024;
 __global__ __launch_bounds__(TO_THREADS) void tile_offsets_fill_kernel(int n_tiles, int32_t *__restrict__ offsets)
 {
@@ -479,10 +472,19 @@ int tile_bits(int n_tiles);
 // one LSD pass over `dbits` bits at `shift`; tile_first != nullptr marks the last pass of the tile sort
 template <typename K, int ITEMS>
 void radix_pass(hipStream_t stream, const K *ka, const uint32_t *va, K *kb, uint32_t *vb, const uint32_t *n_ptr,
-                uint32_t n_cap, int shift, int dbits, uint32_t *table, uint32_t *totals, int nb, int32_t *tile_first = nullptr)
+                uint32_t n_cap, int shift, int dbits, uint32_t *table, uint32_t *totals, int nb, int32_t *tile_first = nullptr,
+                const int32_t *radii = nullptr, const float *depths = nullptr, int32_t *init_offsets = nullptr, int n_tiles = 0)
 {
     const uint32_t mask = (1u << dbits) - 1u;
-    hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb);
+    if (radii) {   // first pass of the depth sort: 8-bit digit, keys synthesised from (radii, depths)
+        hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS, true>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb, radii, depths);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3(1 << dbits), dim3(SC_THREADS), 0, stream, table, nb, totals);
+        hipLaunchKernelGGL((radix_scatter_kernel<K, false, 8, ITEMS, true>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb,
+                           n_ptr, n_cap, shift, table, totals, nb, tile_first, radii, depths);
+        return;
+    }
+    hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb,
+                       (const int32_t *)nullptr, (const float *)nullptr, init_offsets, n_tiles);
     hipLaunchKernelGGL(radix_scan_kernel, dim3(1 << dbits), dim3(SC_THREADS), 0, stream, table, nb, totals);
 #define DNS_SCATTER(B)                                                                                                      \
     do {                                                                                                                    \
@@ -518,15 +520,13 @@ void emit_and_sort(hipStream_t stream, const dnsplat_bin_args *a, const BinWs &w
                        a->means2d, a->radii, a->tile_size, tw, th, cap, ka, va);
     const int bits = tile_bits(n_tiles);
     const int passes = (bits + 7) / 8;
-    hipLaunchKernelGGL(tile_first_init_kernel, dim3((n_tiles + 1 + 255) / 256), dim3(256), 0, stream, w.total, cap, n_tiles,
-                       a->tile_offsets);
     int shift = 0;
     for (int pass = 0; pass < passes; ++pass) {
         const int dbits = (bits - shift + (passes - pass) - 1) / (passes - pass);   // 13 bits -> 7 + 6
         const bool last = pass == passes - 1;
         uint32_t *vout = last ? (uint32_t *)a->flatten_ids : vb;
         radix_pass<K, RS_ITEMS_I>(stream, ka, va, kb, vout, w.total, cap, shift, dbits, w.tab_i, w.totals, w.nb_i,
-                      last ? a->tile_offsets : nullptr);
+                      last ? a->tile_offsets : nullptr, nullptr, nullptr, pass == 0 ? a->tile_offsets : nullptr, n_tiles);
         shift += dbits;
         K *t = ka; ka = kb; kb = t;
         uint32_t *u = va; va = vb; vb = u;
@@ -574,20 +574,18 @@ extern "C" int dnsplat_bin_prepare(const dnsplat_bin_args *a, dnsplat_stream_t s
         if (hipMemsetAsync(w.total, 0, sizeof(uint32_t), stream) != hipSuccess) return DNSPLAT_ERR_LAUNCH;
     } else {
         const uint32_t n_u32 = (uint32_t)N;
-        hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, stream, w.n_gauss, n_u32);
-        hipLaunchKernelGGL(depth_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, a->radii, a->depths,
-                           w.key_a, w.val_a);
         uint32_t *ka = w.key_a, *kb = w.key_b, *va = w.val_a, *vb = w.val_b;
         for (int pass = 0; pass < 4; ++pass) {
             const int shift = 8 * pass;
-            radix_pass<uint32_t, RS_ITEMS_N>(stream, ka, va, kb, vb, w.n_gauss, n_u32, shift, 8, w.tab_n, w.totals, w.nb_n);
+            // the element count is known on the host here (n_ptr = NULL); pass 0 reads (radii, depths) instead of a key / value pair
+            radix_pass<uint32_t, RS_ITEMS_N>(stream, ka, va, kb, vb, nullptr, n_u32, shift, 8, w.tab_n, w.totals, w.nb_n, nullptr,
+                                             pass == 0 ? a->radii : nullptr, pass == 0 ? a->depths : nullptr);
             uint32_t *t = ka; ka = kb; kb = t;
             t = va; va = vb; vb = t;
         }
         // after 4 passes the sorted order is back in val_a
         hipLaunchKernelGGL(scan_sums_kernel, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.val_a, a->tiles_per_gauss,
                            w.sums);
-        hipLaunchKernelGGL(scan_sums_excl_kernel, dim3(1), dim3(SC_THREADS), 0, stream, w.sums, w.nb_scan);
         hipLaunchKernelGGL(scan_final_kernel, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.val_a,
                            a->tiles_per_gauss, w.sums, w.cum, w.total, a->n_isects);
         DNS_CHECK_LAUNCH();

@@ -82,6 +82,12 @@ constexpr int TILE = 16;
 #endif
 // wave-uniform loop bounds moved to scalar registers explicitly (readfirstlane): left alone, hipcc keeps the step counter in a
 // VGPR with a per-lane exit mask (v_add, v_cmp, s_or, s_andn2 exec per step)
+// 0: two instantiations of the step loop, the clamp-free one for groups that hold no splat with opacity > 0.999 (one compare,
+//    one select and the min per splat less); 1: only the clamping loop.  With both loops in the kernel hipcc needs ~34 more
+//    VGPRs (154 vs 120 with the forward's keep masks): mode 1 is what lets a fourth wave per SIMD in.
+#ifndef DNS_BWD_CLAMP_MODE
+#define DNS_BWD_CLAMP_MODE 1
+#endif
 #ifndef DNS_BWD_SCALAR_LOOP
 #define DNS_BWD_SCALAR_LOOP 1
 #endif
@@ -111,6 +117,8 @@ struct BwdArgs {
     int width, height, tw, n_tiles;            // n_tiles: per camera; the launch covers n_tiles x cameras stacked tile grids
     unsigned long long *counters;              // measurement instantiation only (dnsplat_raster_args.pair_counters)
     int n_cameras;
+    const unsigned long long *__restrict__ keep_masks;   // MASKS instantiations: the forward's rectangle-test ballots (dnsplat.h)
+    long long keep_mask_stride;
     const float4 *__restrict__ splats;
     const int32_t *__restrict__ flatten_ids;
     const int32_t *__restrict__ tile_offsets;
@@ -188,7 +196,10 @@ __device__ __forceinline__ float dpp_wave_shr1(float from_prev, float lane0_valu
 // SPLIT >= 0: compile-time split; SPLIT < 0: run-time a.xy_split
 // COUNT: measurement build of the fused pass (bench.py's VALU roofline): tallies the (pixel, splat) slots the stream issues and
 // the pairs it replays into a.counters[4..5]; never the instantiation that is timed.
-template <int D, int SPLIT, bool DN, bool COUNT = false>
+// MASKS: which list entries can contribute to this half tile comes from the forward (a.keep_masks) instead of being re-derived
+// with dns_cull_rect: same decisions (the forward ran the same test on the same records), no record gathers for rejected
+// entries, and the test's registers (the kernel's VGPR peak) are gone.
+template <int D, int SPLIT, bool DN, bool COUNT = false, bool MASKS = false>
 __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(BwdArgs a)
 {
     __shared__ float4 pix[NPIX][3];            // [p][0..1] = v_k, [p][2] = (T, S_a, S_b, bin_final)
@@ -322,6 +333,11 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     int cursor = hi;  // next (highest) list index not yet examined
+    // MASKS: entries are taken in the forward's batches of 64 (aligned to the start of the list), highest batch first
+    [[maybe_unused]] int batch = (hi - range_start) >> 6;
+    [[maybe_unused]] const unsigned long long *masks =
+        MASKS ? a.keep_masks + (size_t)part * a.keep_mask_stride + (range_start >> 6) + cam * a.n_tiles + tile : nullptr;
+    [[maybe_unused]] const uint64_t gt_mask = (lane == 63) ? 0ull : (~0ull << (lane + 1));
     int qn = 0;       // entries waiting in the queue beyond the current bucket (wave-uniform)
     const uint32_t pix_base = (uint32_t)(uintptr_t)&pix[0][0];   // LDS byte address of the table
 #if DNS_BWD_COORD_TABLE
@@ -358,7 +374,20 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
             __builtin_amdgcn_wave_barrier();
             if (lane < qn) queue[lane] = moved;
         }
-        while (qn < BUCKET && cursor >= range_start) {
+        if (MASKS) {
+            while (qn < BUCKET && batch >= 0) {
+                uint64_t m = masks[batch];                                    // wave-uniform
+                const int bstart = range_start + (batch << 6);
+                const int top = hi - bstart;                                  // entries above `hi` were never blended by any pixel here
+                if (top < 63) m &= (2ull << top) - 1ull;
+                // lane l looks at entry bstart + l; the queue is filled in descending list order
+                if ((m >> lane) & 1ull) queue[qn + __popcll(m & gt_mask)] = bstart + lane;
+                qn += __popcll(m);
+                --batch;
+            }
+            cursor = batch >= 0 ? range_start : range_start - 1;             // "list exhausted" test below
+        }
+        while (!MASKS && qn < BUCKET && cursor >= range_start) {
             const int idx = cursor - lane;
             bool keep = false;
             if (idx >= range_start) {
@@ -594,8 +623,12 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
             }
             };
             if (COUNT) n_slots += (unsigned long long)nsteps * BUCKET;
+#if DNS_BWD_CLAMP_MODE == 1
+            step_loop(std::true_type{});
+#else
             if (dns_ballot(opac.x > (float)DNS_ALPHA_MAX || opac.y > (float)DNS_ALPHA_MAX) != 0ull) step_loop(std::true_type{});
             else step_loop(std::false_type{});
+#endif
         }
         if (last) break;
         prev_take = take;
@@ -610,10 +643,10 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
 #endif
 }
 
-template <int D, int SPLIT, bool DN = false, bool COUNT = false>
+template <int D, int SPLIT, bool DN = false, bool COUNT = false, bool MASKS = false>
 int launch_bwd(const BwdArgs &ba, hipStream_t stream)
 {
-    hipLaunchKernelGGL((raster_bwd_kernel<D, SPLIT, DN, COUNT>), dim3(ba.n_tiles * ba.n_cameras * PARTS), dim3(DNS_WAVE), 0, stream, ba);
+    hipLaunchKernelGGL((raster_bwd_kernel<D, SPLIT, DN, COUNT, MASKS>), dim3(ba.n_tiles * ba.n_cameras * PARTS), dim3(DNS_WAVE), 0, stream, ba);
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;
 }
@@ -655,6 +688,9 @@ extern "C" int dnsplat_raster_bwd(const dnsplat_raster_args *a, dnsplat_stream_t
     if (a->n_cameras < 0) return DNSPLAT_ERR_INVALID_ARG;
     ba.n_cameras = a->n_cameras > 1 ? a->n_cameras : 1;
     ba.counters = reinterpret_cast<unsigned long long *>(a->pair_counters);
+    ba.keep_masks = reinterpret_cast<const unsigned long long *>(a->keep_masks);
+    ba.keep_mask_stride = a->keep_mask_stride;
+    if (ba.keep_masks && a->keep_mask_stride <= 0) return DNSPLAT_ERR_INVALID_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     if (a->dn) {
         const dnsplat_dn_post *dn = a->dn;
@@ -663,6 +699,7 @@ extern "C" int dnsplat_raster_bwd(const dnsplat_raster_args *a, dnsplat_stream_t
         ba.bg_rgb = dn->background_rgb; ba.dn_v_rgb = dn->v_rgb; ba.dn_v_depth = dn->v_depth;
         ba.dn_v_normal = dn->v_normal; ba.dn_v_acc = dn->v_accumulation;
         if (ba.counters) return launch_bwd<7, 4, true, true>(ba, stream);
+        if (ba.keep_masks) return launch_bwd<7, 4, true, false, true>(ba, stream);
         return launch_bwd<7, 4, true>(ba, stream);
     }
     switch (a->D) {

@@ -31,6 +31,8 @@ constexpr int FWD_THREADS = FWD_WAVES * DNS_WAVE;
 struct FwdArgs {
     int width, height, tw, n_tiles;            // n_tiles: per camera; the launch covers n_tiles x cameras stacked tile grids
     unsigned long long *counters;              // measurement instantiation only (dnsplat_raster_args.pair_counters)
+    unsigned long long *keep_masks;            // or NULL: per (half tile, 64-entry batch) ballot of the rectangle test, for the backward
+    long long keep_mask_stride;
     const float4 *__restrict__ splats;
     const int32_t *__restrict__ flatten_ids;
     const int32_t *__restrict__ tile_offsets;
@@ -150,6 +152,8 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
         const bool keep = (batch_start + lane < range_end) &&
                           !dns_cull_rect(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rxl, rxh, ryl, ryh);
         uint64_t todo = dns_ballot(keep);
+        if (a.keep_masks && lane == 0)
+            a.keep_masks[(size_t)wave * a.keep_mask_stride + (range_start >> 6) + list + ((batch_start - range_start) >> 6)] = todo;
         if (COUNT) n_entries += min(DNS_WAVE, range_end - batch_start);
         // stage the prefetched records (waits for the gather here) with the conic pre-scaled for exp2,
         // then start the next gather
@@ -306,6 +310,8 @@ extern "C" int dnsplat_raster_fwd(const dnsplat_raster_args *a, dnsplat_stream_t
     fa.render = a->render; fa.alphas = a->alphas; fa.last_ids = a->last_ids;
     fa.bg_rgb = nullptr; fa.dn_rgb = fa.dn_depth = fa.dn_normal = fa.dn_depth_max = nullptr;
     fa.counters = reinterpret_cast<unsigned long long *>(a->pair_counters);
+    fa.keep_masks = reinterpret_cast<unsigned long long *>(a->keep_masks);
+    fa.keep_mask_stride = a->keep_mask_stride;
     if (a->n_cameras < 0) return DNSPLAT_ERR_INVALID_ARG;
     const int C = a->n_cameras > 1 ? a->n_cameras : 1;
     hipStream_t stream = (hipStream_t)stream_;

@@ -270,3 +270,14 @@ def sum_over_ranks(values: Iterable[float], device, group=None):
     if _collectives_on(group):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t.tolist()
+
+
+def gather_over_ranks(value: float, device, group=None):
+    """[value of rank 0, value of rank 1, ...] on every rank."""
+    if not _collectives_on(group):
+        return [value]
+    w = world_size(group)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = torch.empty(w, dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out.tolist()

@@ -87,7 +87,7 @@ def rasterize_gaussians(
     render, alphas = _ops.rasterize(xys.detach(), splats, depths, radii.to(torch.int32).contiguous(),
                                     num_tiles_hit.to(torch.int32).contiguous(), background=background,
                                     width=img_width, height=img_height, tile_size=block_width, D=C)
-    render, alphas = render[0], alphas[0]
+    render, alphas = render.squeeze(0), alphas.squeeze(0)
     if return_alpha:
         return render, alphas
     return render

@@ -199,6 +199,12 @@ typedef struct dnsplat_raster_args {
     const dnsplat_dn_post *dn;          /* NULL, or the fused dn-splatter epilogue (then v_render / v_alphas are unused) */
     int32_t n_cameras;                  /* 0 or 1: one image.  C > 1: images [C,H,W,.] stacked, tile_offsets [C*n_tiles+1], splat /
                                            gradient records [C*N,16] (record cam*N + g), as produced by a dnsplat_bin_args batch */
+    uint64_t *keep_masks;               /* NULL, or device [2 * keep_mask_stride] 64-bit words handed from the forward to the backward:
+                                           for every 16x8 half tile and every batch of 64 consecutive list entries, which entries
+                                           passed the forward's rectangle test (can reach alpha >= 1/255 somewhere in the half tile).
+                                           Word of (list l = camera*n_tiles + tile, half h, batch b): [h * stride + (tile_offsets[l] >> 6) + l + b].
+                                           The backward then skips its own test and never gathers the records of rejected entries. */
+    int64_t keep_mask_stride;           /* >= (isect capacity >> 6) + n_cameras * n_tiles + 1 */
     uint64_t *pair_counters;            /* NULL, or device [8] (measurement builds of the fused pass, bench.py's VALU roofline), added to:
                                            forward  [0] list entries examined  [1] splats walked (kept by the rectangle test)
                                                     [2] live (pixel, splat) pairs evaluated  [3] pairs blended

@@ -201,9 +201,9 @@ def test_hip_gaussian_normals_equal_the_reference():
                   with_depth=True, with_normals=True, want_normals_world=True)
     pr = _ops.project(p["means"], p["quats"], p["scales"], p["opacities"].reshape(N), sh0=p["features_dc"], shN=p["features_rest"],
                       viewmat=viewmat, K=K, normal_frame=nf, cfg=cfg)
-    vis = (pr["radii"] > 0).cpu()
+    vis = (pr["radii"][0] > 0).cpu()
     assert 40 <= int(vis.sum()) < N
-    assert float((pr["normals_world"].cpu() - torch.from_numpy(g["normals_world"])).abs().max()) < 2e-6
+    assert float((pr["normals_world"][0].cpu() - torch.from_numpy(g["normals_world"])).abs().max()) < 2e-6
     rec = pr["splats"].detach().cpu()
     assert float((rec[vis][:, 10:13] - torch.from_numpy(g["normals_cam"])[vis]).abs().max()) < 2e-6
     # A0 inside the kernel: opacity column = sigmoid(logit) as the reference hands it to gsplat
