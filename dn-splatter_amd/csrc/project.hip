@@ -249,7 +249,16 @@ __device__ __forceinline__ void gaussian_normal(const float *Rq, const float *sc
     float m = scale_raw[0];
     if (scale_raw[1] < m) { m = scale_raw[1]; k = 1; }
     if (scale_raw[2] < m) { m = scale_raw[2]; k = 2; }
-    float c0 = Rq[0 + k], c1 = Rq[3 + k], c2 = Rq[6 + k];
+    // Column k of R(q) by selection among REGISTER values, not by a run-time index: an indexed read — or a select between
+    // loads, which LLVM folds back into a load through a selected pointer — keeps the whole projection state (the struct Rq
+    // lives in) in scratch memory: 248 bytes per lane written and re-read per launch.  The empty asm pins each candidate in a
+    // VGPR before the select.
+    float r[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { r[i] = Rq[i]; asm volatile("" : "+v"(r[i])); }
+    const float c0 = k == 0 ? r[0] : (k == 1 ? r[1] : r[2]);
+    const float c1 = k == 0 ? r[3] : (k == 1 ? r[4] : r[5]);
+    const float c2 = k == 0 ? r[6] : (k == 1 ? r[7] : r[8]);
     nrm = fmaxf(sqrtf(c0 * c0 + c1 * c1 + c2 * c2), 1e-12f);
     n[0] = c0 / nrm; n[1] = c1 / nrm; n[2] = c2 / nrm;
     float vx = campos[0] - mean[0], vy = campos[1] - mean[1], vz = campos[2] - mean[2];
@@ -300,6 +309,25 @@ __device__ __forceinline__ void sh_stage_out(float *__restrict__ gbase, int nflo
         g4[i] = make_float4(lds[o], lds[o + 1], lds[o + 2], lds[o + 3]);
     }
     for (int e = (n4 << 2) + threadIdx.x; e < nfloats; e += SH_STAGE_THREADS) gbase[e] = lds[sh_lds_index<L>(e)];
+}
+
+// Feature channel `ch` (run-time: 3 colours or n_colors direct ones, then depth, then the normal) of a record held in
+// registers.  A plain r[REC_CH0 + ch] with a run-time index sends the whole array — and every other privately indexed array
+// of the kernel — to scratch memory: 248 bytes per lane written out and read back per launch, which showed up as ~250 B per
+// Gaussian of extra WRITE_SIZE in project_bwd (2.0x its algorithmic bytes) and ~55 B in project_fwd.  A select chain over
+// the 8 possible positions keeps everything in VGPRs.
+__device__ __forceinline__ void rec_set_ch(float *r, int ch, float v)
+{
+#pragma unroll
+    for (int k = 0; k < DNS_MAX_CH; ++k) r[REC_CH0 + k] = (k == ch) ? v : r[REC_CH0 + k];   // value selects (a conditional store
+                                                                                          // becomes a store through a selected pointer)
+}
+__device__ __forceinline__ float rec_get_ch(const float *r, int ch)
+{
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < DNS_MAX_CH; ++k) v = (k == ch) ? r[REC_CH0 + k] : v;
+    return v;
 }
 
 struct FwdParams {
@@ -395,11 +423,13 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(FwdParams p)
             const float *c0 = p.s.sh0 + (size_t)g * p.s.sh0_stride;
             const float *cN = p.s.shN + (size_t)g * p.s.shN_stride;
             col[0] = bas[0] * c0[0]; col[1] = bas[0] * c0[1]; col[2] = bas[0] * c0[2];
-            for (int k = 1; k < nb; ++k) {
-                col[0] += bas[k] * cN[3 * (k - 1) + 0];
-                col[1] += bas[k] * cN[3 * (k - 1) + 1];
-                col[2] += bas[k] * cN[3 * (k - 1) + 2];
-            }
+#pragma unroll
+            for (int k = 1; k < 16; ++k)      // static indices (bas[] stays in registers), run-time band count
+                if (k < nb) {
+                    col[0] += bas[k] * cN[3 * (k - 1) + 0];
+                    col[1] += bas[k] * cN[3 * (k - 1) + 1];
+                    col[2] += bas[k] * cN[3 * (k - 1) + 2];
+                }
         } else {
             const float *row = sh_lds + threadIdx.x * ShRowTraits<L>::LDS_ROW;   // this lane's LDS row
             const float *cN = L == SH_CAT ? row + 3 : row;
@@ -409,21 +439,25 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(FwdParams p)
                 const float *c0 = p.s.sh0 + (size_t)g * p.s.sh0_stride;
                 col[0] = bas[0] * c0[0]; col[1] = bas[0] * c0[1]; col[2] = bas[0] * c0[2];
             }
-            for (int k = 1; k < nb; ++k) {
-                col[0] += bas[k] * cN[3 * (k - 1) + 0];
-                col[1] += bas[k] * cN[3 * (k - 1) + 1];
-                col[2] += bas[k] * cN[3 * (k - 1) + 2];
-            }
+#pragma unroll
+            for (int k = 1; k < 16; ++k)      // static indices (bas[] stays in registers), run-time band count
+                if (k < nb) {
+                    col[0] += bas[k] * cN[3 * (k - 1) + 0];
+                    col[1] += bas[k] * cN[3 * (k - 1) + 1];
+                    col[2] += bas[k] * cN[3 * (k - 1) + 2];
+                }
         }
         r[REC_CH0 + 0] = fmaxf(col[0] + 0.5f, 0.f);
         r[REC_CH0 + 1] = fmaxf(col[1] + 0.5f, 0.f);
         r[REC_CH0 + 2] = fmaxf(col[2] + 0.5f, 0.f);
         ch = 3;
     } else {
-        for (int k = 0; k < p.s.n_colors; ++k) r[REC_CH0 + k] = p.s.colors[(size_t)g * p.s.n_colors + k];
+#pragma unroll
+        for (int k = 0; k < DNS_MAX_CH; ++k)
+            if (k < p.s.n_colors) r[REC_CH0 + k] = p.s.colors[(size_t)g * p.s.n_colors + k];
         ch = p.s.n_colors;
     }
-    if (p.o.with_depth_channel) { r[REC_CH0 + ch] = st.mean_c[2]; ch += 1; }
+    if (p.o.with_depth_channel) { rec_set_ch(r, ch, st.mean_c[2]); ch += 1; }
     if (p.o.with_normal_channels || p.o.normals_world) {
         const float *np = p.c.normal_frame ? p.c.normal_frame + 9 : cam.pos;
         float campos[3] = {np[0], np[1], np[2]};
@@ -436,7 +470,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(FwdParams p)
             const float *Mn = p.c.normal_frame;
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                r[REC_CH0 + ch + i] = Mn[3 * i + 0] * n[0] + Mn[3 * i + 1] * n[1] + Mn[3 * i + 2] * n[2];
+                rec_set_ch(r, ch + i, Mn[3 * i + 0] * n[0] + Mn[3 * i + 1] * n[1] + Mn[3 * i + 2] * n[2]);
         }
     }
     rec4[0] = make_float4(r[0], r[1], r[2], r[3]);
@@ -556,11 +590,13 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(BwdParams p)
                 const float *c0 = p.s.sh0 + (size_t)g * p.s.sh0_stride;
                 const float *cN = p.s.shN + (size_t)g * p.s.shN_stride;
                 float col[3] = {bas[0] * c0[0], bas[0] * c0[1], bas[0] * c0[2]};
-                for (int k = 1; k < nbK; ++k) {
-                    col[0] += bas[k] * cN[3 * (k - 1) + 0];
-                    col[1] += bas[k] * cN[3 * (k - 1) + 1];
-                    col[2] += bas[k] * cN[3 * (k - 1) + 2];
-                }
+#pragma unroll
+                for (int k = 1; k < 16; ++k)          // static indices keep bas[] / bx[] / by[] / bz[] in registers
+                    if (k < nbK) {
+                        col[0] += bas[k] * cN[3 * (k - 1) + 0];
+                        col[1] += bas[k] * cN[3 * (k - 1) + 1];
+                        col[2] += bas[k] * cN[3 * (k - 1) + 2];
+                    }
                 // clamp_min(c + 0.5, 0): gradient passes where c + 0.5 >= 0
                 float vcol[3];
 #pragma unroll
@@ -568,41 +604,49 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(BwdParams p)
                 fcol[0] = vcol[0]; fcol[1] = vcol[1]; fcol[2] = vcol[2];
                 if (vsh0 && !sh_elsewhere) { vsh0[0] = bas[0] * vcol[0]; vsh0[1] = bas[0] * vcol[1]; vsh0[2] = bas[0] * vcol[2]; }
                 if (vshN && !sh_elsewhere) {
-                    for (int k = 1; k < nbK; ++k) {
-                        vshN[3 * (k - 1) + 0] = bas[k] * vcol[0];
-                        vshN[3 * (k - 1) + 1] = bas[k] * vcol[1];
-                        vshN[3 * (k - 1) + 2] = bas[k] * vcol[2];
-                    }
+#pragma unroll
+                    for (int k = 1; k < 16; ++k)
+                        if (k < nbK) {
+                            vshN[3 * (k - 1) + 0] = bas[k] * vcol[0];
+                            vshN[3 * (k - 1) + 1] = bas[k] * vcol[1];
+                            vshN[3 * (k - 1) + 2] = bas[k] * vcol[2];
+                        }
                     for (int k = 3 * (nbK - 1); k < 3 * restK; ++k) vshN[k] = 0.f;
                 }
-                for (int k = 1; k < nbK; ++k) {
-                    float s = cN[3 * (k - 1)] * vcol[0] + cN[3 * (k - 1) + 1] * vcol[1] + cN[3 * (k - 1) + 2] * vcol[2];
-                    vdn[0] += bx[k] * s; vdn[1] += by[k] * s; vdn[2] += bz[k] * s;
-                }
+#pragma unroll
+                for (int k = 1; k < 16; ++k)
+                    if (k < nbK) {
+                        float s = cN[3 * (k - 1)] * vcol[0] + cN[3 * (k - 1) + 1] * vcol[1] + cN[3 * (k - 1) + 2] * vcol[2];
+                        vdn[0] += bx[k] * s; vdn[1] += by[k] * s; vdn[2] += bz[k] * s;
+                    }
             } else {
                 float c00, c01, c02;
                 if (L == SH_CAT) { c00 = lrow[0]; c01 = lrow[1]; c02 = lrow[2]; }
                 else { const float *c0 = p.s.sh0 + (size_t)g * p.s.sh0_stride; c00 = c0[0]; c01 = c0[1]; c02 = c0[2]; }
                 float col[3] = {bas[0] * c00, bas[0] * c01, bas[0] * c02};
-                for (int k = 1; k < nbK; ++k) {
-                    col[0] += bas[k] * lN[3 * (k - 1) + 0];
-                    col[1] += bas[k] * lN[3 * (k - 1) + 1];
-                    col[2] += bas[k] * lN[3 * (k - 1) + 2];
-                }
+#pragma unroll
+                for (int k = 1; k < 16; ++k)
+                    if (k < nbK) {
+                        col[0] += bas[k] * lN[3 * (k - 1) + 0];
+                        col[1] += bas[k] * lN[3 * (k - 1) + 1];
+                        col[2] += bas[k] * lN[3 * (k - 1) + 2];
+                    }
                 float vcol[3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) vcol[i] = (col[i] + 0.5f >= 0.f) ? vr[REC_CH0 + i] : 0.f;
                 fcol[0] = vcol[0]; fcol[1] = vcol[1]; fcol[2] = vcol[2];
                 if (L == SH_CAT) { lrow[0] = bas[0] * vcol[0]; lrow[1] = bas[0] * vcol[1]; lrow[2] = bas[0] * vcol[2]; }
                 else if (vsh0 && !sh_elsewhere) { vsh0[0] = bas[0] * vcol[0]; vsh0[1] = bas[0] * vcol[1]; vsh0[2] = bas[0] * vcol[2]; }
-                for (int k = 1; k < nbK; ++k) {   // read the coefficient, then overwrite it with its gradient
-                    const float a0 = lN[3 * (k - 1)], a1 = lN[3 * (k - 1) + 1], a2 = lN[3 * (k - 1) + 2];
-                    const float s = a0 * vcol[0] + a1 * vcol[1] + a2 * vcol[2];
-                    vdn[0] += bx[k] * s; vdn[1] += by[k] * s; vdn[2] += bz[k] * s;
-                    lN[3 * (k - 1) + 0] = bas[k] * vcol[0];
-                    lN[3 * (k - 1) + 1] = bas[k] * vcol[1];
-                    lN[3 * (k - 1) + 2] = bas[k] * vcol[2];
-                }
+#pragma unroll
+                for (int k = 1; k < 16; ++k)     // read the coefficient, then overwrite it with its gradient
+                    if (k < nbK) {
+                        const float a0 = lN[3 * (k - 1)], a1 = lN[3 * (k - 1) + 1], a2 = lN[3 * (k - 1) + 2];
+                        const float s = a0 * vcol[0] + a1 * vcol[1] + a2 * vcol[2];
+                        vdn[0] += bx[k] * s; vdn[1] += by[k] * s; vdn[2] += bz[k] * s;
+                        lN[3 * (k - 1) + 0] = bas[k] * vcol[0];
+                        lN[3 * (k - 1) + 1] = bas[k] * vcol[1];
+                        lN[3 * (k - 1) + 2] = bas[k] * vcol[2];
+                    }
                 for (int k = 3 * (nbK - 1); k < 45; ++k) lN[k] = 0.f;
             }
             if (fact) { fact[0] = dx; fact[1] = dy; fact[2] = dz; fact[3] = fcol[0]; fact[4] = fcol[1]; fact[5] = fcol[2]; }
@@ -615,10 +659,12 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(BwdParams p)
             ch = 3;
         } else {
             if (p.g.v_colors)
-                for (int k = 0; k < p.s.n_colors; ++k) p.g.v_colors[(size_t)g * p.s.n_colors + k] = vr[REC_CH0 + k];
+#pragma unroll
+                for (int k = 0; k < DNS_MAX_CH; ++k)
+                    if (k < p.s.n_colors) p.g.v_colors[(size_t)g * p.s.n_colors + k] = vr[REC_CH0 + k];
             ch = p.s.n_colors;
         }
-        if (p.o.with_depth_channel) { v_depth += vr[REC_CH0 + ch]; ch += 1; }
+        if (p.o.with_depth_channel) { v_depth += rec_get_ch(vr, ch); ch += 1; }
         if (p.o.with_normal_channels) {
             // n_cam = Mn * (sgn * col/|col|), col = Rq[:,k]  ->  only the quaternion receives gradient
             const float *Mn = p.c.normal_frame;
@@ -628,11 +674,15 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(BwdParams p)
             float vn[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                vn[i] = sgn * (Mn[0 + i] * vr[REC_CH0 + ch] + Mn[3 + i] * vr[REC_CH0 + ch + 1] + Mn[6 + i] * vr[REC_CH0 + ch + 2]);
+                vn[i] = sgn * (Mn[0 + i] * rec_get_ch(vr, ch) + Mn[3 + i] * rec_get_ch(vr, ch + 1) + Mn[6 + i] * rec_get_ch(vr, ch + 2));
             float u[3] = {n[0] * sgn, n[1] * sgn, n[2] * sgn};
             float d = u[0] * vn[0] + u[1] * vn[1] + u[2] * vn[2];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) v_R[3 * i + k] += (vn[i] - u[i] * d) / nrm;
+            for (int i = 0; i < 3; ++i) {
+                const float add = (vn[i] - u[i] * d) / nrm;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) v_R[3 * i + j] += (j == k) ? add : 0.f;      // static indices: v_R stays in registers
+            }
         }
 
         // ---- conic -> cov2d (A.8)

@@ -33,6 +33,12 @@ class GradArena:
 
     ``_ops._ProjectFn.backward`` asks ``take(name, like)`` for its output tensors, so the kernels write
     directly into the bucket and autograd installs those views as ``param.grad``.
+
+    Contract: ``param.grad`` should be ``None`` when a backward starts (``zero_grad(set_to_none=True)``).  If a ``.grad`` that
+    already lives in the bucket is still set — gradient accumulation over several cameras, ``zero_grad(set_to_none=False)`` —
+    the kernels write into a fresh tensor instead (``_ops._grad_like``) and autograd's in-place ``+=`` lands in the bucket:
+    still correct, one extra pass over the gradients.  (Writing into the bucket in that case would alias old and new
+    gradient and the sum would come out as 2 x new.)
     """
 
     def __init__(self, params: Dict[str, Tensor]):

@@ -724,6 +724,33 @@ def test_sh_factor_exchange_rebuilds_the_multi_camera_gradient(dns, layout):
         assert_close(sh_1.grad, dense[0][1].grad, "single-rank exchange", 1e-6)
 
 
+@pytest.mark.parametrize("n_views,sh_degree", [(8, 3), (4, 2), (2, 1)])
+def test_sh_rebuild_kernel_equals_torch_rebuild_at_node_scale(dns, n_views, sh_degree):
+    """dnsplat_sh_grads_from_factors (what dp.ShFactorExchange._rebuild runs on every rank after the all-gather) against the
+    torch rebuild the gloo tests substitute for it — autograd through a dense SH evaluation, summed over the views — for the
+    8 views of a full node (BASELINE C4 / C5), random factors, odd N."""
+    from dn_splatter_amd import dp
+    from oracle import dense_ref
+
+    N = 10_007
+    g = torch.Generator().manual_seed(40 + n_views)
+    dirs = torch.nn.functional.normalize(torch.randn(n_views, N, 3, generator=g), dim=-1)      # unit view directions, as dnsplat_sh_factors writes them
+    cols = torch.randn(n_views, N, 3, generator=g)
+    fac = torch.cat([dirs, cols], -1).contiguous()
+    tot = torch.zeros(N, 16, 3)
+    for v in range(n_views):
+        co = torch.zeros(N, 16, 3, requires_grad=True)
+        (dense_ref.sh_colors(sh_degree, dirs[v], co) * cols[v]).sum().backward()
+        tot += co.grad
+    tot /= n_views
+    v0 = torch.full((N, 3), float("nan"), device=DEV)
+    vN = torch.full((N, 15, 3), float("nan"), device=DEV)
+    dp._rebuild_hip(fac.to(DEV), N, n_views, sh_degree, 16, None, v0, vN)
+    torch.cuda.synchronize()
+    assert_close(v0, tot[:, 0], "rebuilt band 0", 1e-5)
+    assert_close(vN, tot[:, 1:], "rebuilt bands 1..3 (inactive bands must be zero, not untouched)", 1e-5)
+
+
 def test_small_frame_stays_in_the_millisecond_range(dns):
     """Regression guard.  A wave shuffle placed under a lane-dependent branch once made the emit kernel read a neighbour's
     count as 0 and spin through 2^32 / 32 guarded iterations: every result stayed bit-exact, but a 320 x 240 frame (300

@@ -5,7 +5,7 @@ out = {}
 for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); ids = collections.defaultdict(set)
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0][:90]
+        k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:90]
         acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); ids[k].add(row["Dispatch_Id"])
     for k in acc:
         n = len(ids[k])
