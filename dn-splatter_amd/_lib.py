@@ -129,7 +129,7 @@ class ProjGrads(ctypes.Structure):
 EXPORTS = [
     "dnsplat_strerror", "dnsplat_abi_version",
     "dnsplat_project_fwd", "dnsplat_pack_splats",
-    "dnsplat_bin_workspace_bytes", "dnsplat_bin_prepare", "dnsplat_bin_emit_sort", "dnsplat_bin_isect_ids",
+    "dnsplat_bin_workspace_bytes", "dnsplat_bin_status_offset", "dnsplat_bin_prepare", "dnsplat_bin_emit_sort", "dnsplat_bin_isect_ids",
     "dnsplat_raster_fwd", "dnsplat_raster_bwd",
     "dnsplat_dn_depth_normals", "dnsplat_camera_prepare", "dnsplat_densify_stats", "dnsplat_densify_classify",
     "dnsplat_densify_split", "dnsplat_dn_loss", "dnsplat_sh_grads_from_factors", "dnsplat_sh_factors",
@@ -165,6 +165,8 @@ def lib() -> ctypes.CDLL:
         L.dnsplat_abi_version.restype = ctypes.c_int
         L.dnsplat_bin_workspace_bytes.restype = c_size_t
         L.dnsplat_bin_workspace_bytes.argtypes = [c_int32, c_int64, c_int32]
+        L.dnsplat_bin_status_offset.restype = c_size_t
+        L.dnsplat_bin_status_offset.argtypes = [c_int32, c_int64]
         L.dnsplat_project_fwd.argtypes = [ctypes.POINTER(Scene), ctypes.POINTER(Camera), ctypes.POINTER(ProjOut), c_void_p]
         L.dnsplat_project_bwd.argtypes = [ctypes.POINTER(Scene), ctypes.POINTER(Camera), ctypes.POINTER(ProjOut),
                                           ctypes.POINTER(ProjGrads), c_void_p]
@@ -187,7 +189,7 @@ def lib() -> ctypes.CDLL:
                                              c_void_p]
         L.dnsplat_sh_factors.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         for name in EXPORTS:
-            if name not in ("dnsplat_strerror", "dnsplat_bin_workspace_bytes"):
+            if name not in ("dnsplat_strerror", "dnsplat_bin_workspace_bytes", "dnsplat_bin_status_offset"):
                 getattr(L, name).restype = ctypes.c_int
         if L.dnsplat_abi_version() != ABI_VERSION:
             raise DnsplatError(f"libdnsplat ABI {L.dnsplat_abi_version()} != binding {ABI_VERSION}; rebuild")

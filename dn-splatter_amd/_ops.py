@@ -434,6 +434,16 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
     return b
 
 
+def binning_status(b: Binning, n_entries: int) -> int:
+    """The tile sort's status word of the frame that produced ``b`` (0 = fine; see dnsplat_bin_status_offset).  Reads the
+    workspace of the current stream, i.e. call it before the next frame is binned there; synchronises."""
+    ws = BUFFERS.ws.get(_Buffers._key(b.flatten_ids.device))
+    if ws is None:
+        return 0
+    off = _lib.lib().dnsplat_bin_status_offset(n_entries, b.flatten_ids.numel())
+    return int(ws[off:off + 4].view(torch.int32).item())
+
+
 def isect_ids(b: Binning, depths: Tensor) -> Tensor:
     """gsplat's 64-bit sorted keys (camera | tile << 32 | depth bits), rebuilt on demand for the info dict."""
     out = torch.empty(max(b.n_isects, 1), dtype=torch.int64, device=depths.device)

@@ -26,7 +26,11 @@
 namespace {
 
 constexpr int RS_THREADS = 256;                  // 4 waves per workgroup
-constexpr int RS_ITEMS_I = 16;                   // keys per lane in the I-sized tile passes: 4096 per workgroup
+#ifndef DNS_RS_ITEMS_I
+#define DNS_RS_ITEMS_I 16
+#endif
+constexpr int RS_ITEMS_I = DNS_RS_ITEMS_I;       // keys per lane in the I-sized tile passes: 4096 per workgroup (paired A/B at C2 / C3:
+                                                 // 8 -> +7 % / +2 %, 32 -> +29 % / +24 % of the emit + sort time)
 #ifndef DNS_RS_ITEMS_N
 #define DNS_RS_ITEMS_N 8
 #endif
@@ -145,6 +149,80 @@ __global__ __launch_bounds__(SC_THREADS) void radix_scan_kernel(uint32_t *__rest
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Decoupled look-back (DNS_BIN_LOOKBACK, the I-sized tile passes).  The table-based pass needs, per radix pass, a histogram
+// launch that reads every key again and a scan launch over (digits x chunks) counters before the scatter can place anything.
+// With look-back a chunk publishes its own per-digit counts ("aggregate"), then walks back over the chunks before it,
+// adding their aggregates until it meets one that already knows its inclusive prefix, and publishes its own inclusive prefix:
+// the prefix over chunks is computed INSIDE the scatter launch.  What it needs from outside are only the GLOBAL digit totals
+// of every pass, which one launch computes for all passes at once (tile_digit_totals_kernel).
+//   * A chunk's number is a ticket drawn at workgroup start, so every chunk a workgroup waits for has started before it:
+//     waiting never depends on a workgroup that is not resident yet, whatever order the dispatcher uses.
+//   * A descriptor is ONE 64-bit word (2 status bits + count) written and read with agent-scope atomics — it is its own
+//     payload, nothing else has to become visible with it (the per-XCD L2s are not coherent with each other).
+//   * Every spin is bounded by the 100 MHz wall clock; on expiry the chunk records it in *fail and carries on with what it
+//     has (wrong lists, but the launch always ends).
+constexpr unsigned long long LB_AGG = 1ull << 62, LB_INC = 2ull << 62, LB_VAL = (1ull << 62) - 1ull;
+constexpr unsigned long long LB_SPIN_TICKS = 20ull * 100000ull;      // 20 ms
+
+__device__ __forceinline__ void lb_store(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long lb_load(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Global digit totals of up to three passes over the emitted tile keys (one read of the keys), and the zero state of the
+// look-back descriptors and tickets of those passes.  totals: [3][256], tickets: [3], desc: [n_desc] words.
+template <typename K, int ITEMS>
+__global__ __launch_bounds__(RS_THREADS) void tile_digit_totals_kernel(const K *__restrict__ keys, const uint32_t *__restrict__ n_ptr,
+                                                                       uint32_t n_cap, int passes, int shift1, int shift2,
+                                                                       uint32_t mask0, uint32_t mask1, uint32_t mask2,
+                                                                       uint32_t *__restrict__ totals,
+                                                                       unsigned long long *__restrict__ desc, size_t n_desc,
+                                                                       int32_t *__restrict__ tile_first, int n_tiles)
+{
+    __shared__ uint32_t hist[3][RS_DIGITS];
+    const uint32_t n = min(*n_ptr, n_cap);
+    for (size_t i = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; i < n_desc; i += (size_t)gridDim.x * RS_THREADS) desc[i] = 0ull;
+    // the tile offsets start at n (the last scatter pass lowers the non-empty tiles' entries with atomicMin)
+    for (int i = blockIdx.x * RS_THREADS + threadIdx.x; i <= n_tiles; i += gridDim.x * RS_THREADS) tile_first[i] = (int32_t)n;
+    hist[0][threadIdx.x] = 0; hist[1][threadIdx.x] = 0; hist[2][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (RS_THREADS * ITEMS);
+    if (base < n) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t idx = base + i * RS_THREADS + threadIdx.x;
+            if (idx < n) {
+                const uint32_t k = (uint32_t)keys[idx];
+                atomicAdd(&hist[0][k & mask0], 1u);
+                if (passes > 1) {
+                    // consecutive entries share their high digits almost always: count once per run of equal digits in the wave
+                    const uint32_t d1 = (k >> shift1) & mask1;
+                    const uint32_t prev1 = __shfl_up(d1, 1, DNS_WAVE);
+                    const bool head1 = lane_id() == 0 || prev1 != d1;
+                    const uint64_t heads = dns_ballot(head1);
+                    const int n_act = __popcll(dns_ballot(true));                           // the active lanes are lanes 0 .. n_act-1
+                    if (head1) {
+                        const uint64_t after = heads & ~((2ull << lane_id()) - 1ull);       // next run head above this lane
+                        const int end = after ? __ffsll((unsigned long long)after) - 1 : n_act;
+                        atomicAdd(&hist[1][d1], (uint32_t)(end - (int)lane_id()));
+                    }
+                }
+                if (passes > 2) atomicAdd(&hist[2][(k >> shift2) & mask2], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int p = 0; p < passes; ++p) {
+        const uint32_t c = hist[p][threadIdx.x];
+        if (c) atomicAdd(&totals[p * RS_DIGITS + threadIdx.x], c);
+    }
+}
+
 // DBITS = digit width of this pass (<= 8): the tile passes split their 13 bits 7 + 6 instead of 8 + 8 — fewer
 // ballots per key and longer per-digit runs for the coalesced run stores.
 //
@@ -152,12 +230,15 @@ __global__ __launch_bounds__(SC_THREADS) void radix_scan_kernel(uint32_t *__rest
 // a tile's entries start is.  Inside one digit's run of the LDS-sorted chunk the keys are non-decreasing (the stream
 // was already sorted on the lower bits and the pass is stable), so "key differs from its left neighbour" marks the
 // chunk-local first entry of a tile; the minimum of those positions over the chunks is the tile's offset.
-template <typename K, bool LAST, int DBITS, int ITEMS, bool FIRST = false>
+// LOOKBACK: the count of the chunks before this one comes from the descriptors of those chunks (see above) instead of a
+// precomputed table; `totals` are then the pass's global digit totals from tile_digit_totals_kernel.
+template <typename K, bool LAST, int DBITS, int ITEMS, bool FIRST = false, bool LOOKBACK = false>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ n_ptr, uint32_t n_cap, int shift,
     const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nb, int32_t *__restrict__ tile_first,
-    const int32_t *__restrict__ radii = nullptr, const float *__restrict__ depths = nullptr)
+    const int32_t *__restrict__ radii = nullptr, const float *__restrict__ depths = nullptr,
+    unsigned long long *__restrict__ desc = nullptr, uint32_t *__restrict__ ticket = nullptr, uint32_t *__restrict__ fail = nullptr)
 {
     // The chunk is first sorted by digit INSIDE LDS (stable), then written out run by run: consecutive lanes
     // store to consecutive addresses of one digit's run, so the stores coalesce.  A direct scatter from the
@@ -173,12 +254,24 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     __shared__ uint32_t lds_wave[4];
     constexpr uint32_t DMASK = (1u << DBITS) - 1u;
     const uint32_t n = n_ptr ? min(*n_ptr, n_cap) : n_cap;
-    const uint32_t base = blockIdx.x * CHUNK;
+    uint32_t chunk = blockIdx.x;
+    if (LOOKBACK) {
+        __shared__ uint32_t ticket_s;
+        if (threadIdx.x == 0) ticket_s = atomicAdd(ticket, 1u);
+        __syncthreads();
+        chunk = ticket_s;
+    }
+    const uint32_t base = chunk * CHUNK;
     if (base >= n) return;
     const uint32_t n_valid = min((uint32_t)CHUNK, n - base);
     const int w = threadIdx.x / DNS_WAVE;
     const uint32_t lane = lane_id();
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // this thread's digit: its global total and the count of the chunks before this one — requested now, needed only
+    // after the ranking (two loads that depend on nothing and otherwise sit exposed between two barriers)
+    const bool is_digit = threadIdx.x <= DMASK;
+    const uint32_t pre_tot = is_digit ? totals[threadIdx.x] : 0u;
+    const uint32_t pre_tab = (is_digit && !LOOKBACK) ? table[(size_t)threadIdx.x * nb + blockIdx.x] : 0u;
 
 #pragma unroll
     for (int i = 0; i < RS_WAVES; ++i) wave_cnt[i][threadIdx.x] = 0;
@@ -226,10 +319,34 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         wave_loc[2][threadIdx.x] = ls + c0 + c1;
         wave_loc[3][threadIdx.x] = ls + c0 + c1 + c2;
         // global base = (#keys with smaller digit) + (#same digit in earlier chunks)
-        const bool is_digit = threadIdx.x <= DMASK;
-        const uint32_t tot = is_digit ? totals[threadIdx.x] : 0u;
+        const uint32_t tot = pre_tot;
         const uint32_t ginc = block_incl_scan_256(tot, lds_wave, t2);
-        gbase[threadIdx.x] = is_digit ? (ginc - tot) + table[(size_t)threadIdx.x * nb + blockIdx.x] : 0u;
+        uint32_t before = pre_tab;
+        if (LOOKBACK && is_digit) {
+            constexpr int DIGITS = 1 << DBITS;
+            unsigned long long *mine = desc + (size_t)chunk * DIGITS + threadIdx.x;
+            if (chunk == 0) {
+                lb_store(mine, LB_INC | cnt);
+            } else {
+                lb_store(mine, LB_AGG | cnt);
+                unsigned long long sum = 0;
+                const unsigned long long t_end = wall_clock64() + LB_SPIN_TICKS;
+                for (int c = (int)chunk - 1; c >= 0; --c) {
+                    const unsigned long long *theirs = desc + (size_t)c * DIGITS + threadIdx.x;
+                    unsigned long long v = lb_load(theirs);
+                    while ((v >> 62) == 0ull) {
+                        if (wall_clock64() > t_end) { atomicOr(fail, 1u); v = LB_INC; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        v = lb_load(theirs);
+                    }
+                    sum += v & LB_VAL;
+                    if ((v >> 62) == 2ull) break;
+                }
+                before = (uint32_t)sum;
+                lb_store(mine, LB_INC | (sum + cnt));
+            }
+        }
+        gbase[threadIdx.x] = is_digit ? (ginc - tot) + before : 0u;
     }
     __syncthreads();
 #pragma unroll
@@ -323,8 +440,12 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int n_per_cam, const u
                                                    const uint32_t *__restrict__ cum,
                                                    const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                                                    int tile_size, int tw, int th, uint32_t cap,
-                                                   K *__restrict__ tkeys, uint32_t *__restrict__ tvals)
+                                                   K *__restrict__ tkeys, uint32_t *__restrict__ tvals,
+                                                   uint32_t *__restrict__ lb_ctl = nullptr, int lb_ctl_words = 0)
 {
+    // the look-back control words (digit totals, tickets, failure flag) of the tile passes that follow start at zero
+    if (lb_ctl && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < lb_ctl_words; i += blockDim.x) lb_ctl[i] = 0u;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = lane_id();
     uint32_t gid = 0, end = 0, start = 0;
@@ -421,6 +542,18 @@ __global__ __launch_bounds__(256) void isect_ids_kernel(int n_tiles, int tile_bi
 }
 
 // ------------------------------------------------------------------------------------------------
+constexpr int LB_CTL_WORDS = 3 * RS_DIGITS + 4;
+
+// Tile sort by decoupled look-back (1) or with per-pass histogram + scan launches (0).  MEASURED AND REJECTED (paired A/B of
+// dnsplat_bin_emit_sort, bit-identical lists, no wait ever hit its bound): C2 0.319 -> 0.475 ms, C5 0.82 -> 1.13 ms.  ~1000
+// chunks run concurrently and all start together, so at the start of a pass the look-back of chunk c walks back through up
+// to c descriptors one at a time, each an agent-scope (sc1) load of ~1 us across the non-coherent L2s: a serial chain that
+// costs more than the two launches (histogram 22 us + scan 10 us) it removes.  The classic remedy — a whole wave inspecting
+// 32-64 predecessors per step — does not fit a layout in which every lane owns a digit.  Kept compiled out as the record.
+#ifndef DNS_BIN_LOOKBACK
+#define DNS_BIN_LOOKBACK 0
+#endif
+
 struct BinWs {
     uint32_t *key_a, *key_b, *val_a, *val_b;  // [N]
     uint32_t *cum;                            // [N]
@@ -431,6 +564,8 @@ struct BinWs {
     uint32_t *total;                          // [1] n_isects as u32
     uint32_t *tkey_a, *tkey_b, *tval_a, *tval_b;  // [cap]
     uint32_t *tab_i;                          // [256 * nb_i]
+    uint32_t *lb_ctl;                         // look-back control: [3][256] digit totals | [3] tickets | [1] failure flag
+    unsigned long long *lb_desc;              // look-back descriptors, [3][nb_i][256] at most
     int nb_n, nb_i, nb_scan;
     size_t bytes;
 };
@@ -463,6 +598,8 @@ BinWs carve(void *ws, int N, int64_t cap)
     b.total = take(1);
     b.tkey_a = take(c); b.tkey_b = take(c); b.tval_a = take(c); b.tval_b = take(c);
     b.tab_i = take((size_t)RS_DIGITS * b.nb_i);
+    b.lb_ctl = take(LB_CTL_WORDS);
+    b.lb_desc = reinterpret_cast<unsigned long long *>(take((size_t)3 * RS_DIGITS * b.nb_i * 2));
     b.bytes = off;
     return b;
 }
@@ -516,10 +653,54 @@ void emit_and_sort(hipStream_t stream, const dnsplat_bin_args *a, const BinWs &w
     K *ka = reinterpret_cast<K *>(w.tkey_a), *kb = reinterpret_cast<K *>(w.tkey_b);
     uint32_t *va = w.tval_a, *vb = w.tval_b;
     const int n_cam = a->n_cameras > 1 ? a->n_cameras : 1;
-    hipLaunchKernelGGL(emit_kernel<K>, dim3((a->N + 255) / 256), dim3(256), 0, stream, a->N, a->N / n_cam, w.val_a, w.cum,
-                       a->means2d, a->radii, a->tile_size, tw, th, cap, ka, va);
     const int bits = tile_bits(n_tiles);
     const int passes = (bits + 7) / 8;
+#if DNS_BIN_LOOKBACK
+    {
+        hipLaunchKernelGGL(emit_kernel<K>, dim3((a->N + 255) / 256), dim3(256), 0, stream, a->N, a->N / n_cam, w.val_a, w.cum,
+                           a->means2d, a->radii, a->tile_size, tw, th, cap, ka, va, w.lb_ctl, LB_CTL_WORDS);
+        int dbits[3] = {0, 0, 0}, shifts[3] = {0, 0, 0};
+        size_t desc_off[4] = {0, 0, 0, 0};
+        for (int pass = 0, sh = 0; pass < passes; ++pass) {
+            dbits[pass] = (bits - sh + (passes - pass) - 1) / (passes - pass);       // 13 bits -> 7 + 6
+            shifts[pass] = sh;
+            sh += dbits[pass];
+            desc_off[pass + 1] = desc_off[pass] + ((size_t)w.nb_i << dbits[pass]);
+        }
+        uint32_t *totals = w.lb_ctl, *tickets = w.lb_ctl + 3 * RS_DIGITS, *fail = tickets + 3;
+        hipLaunchKernelGGL((tile_digit_totals_kernel<K, RS_ITEMS_I>), dim3(w.nb_i), dim3(RS_THREADS), 0, stream, ka, w.total, cap, passes,
+                           shifts[1], shifts[2], (1u << dbits[0]) - 1u, (1u << dbits[1]) - 1u, (1u << dbits[2]) - 1u, totals,
+                           w.lb_desc, desc_off[passes], a->tile_offsets, n_tiles);
+        for (int pass = 0; pass < passes; ++pass) {
+            const bool last = pass == passes - 1;
+            uint32_t *vout = last ? (uint32_t *)a->flatten_ids : vb;
+#define DNS_LB(B, L)                                                                                                              \
+            hipLaunchKernelGGL((radix_scatter_kernel<K, L, B, RS_ITEMS_I, false, true>), dim3(w.nb_i), dim3(RS_THREADS), 0, stream, ka, va, \
+                               kb, vout, w.total, cap, shifts[pass], (const uint32_t *)nullptr, totals + pass * RS_DIGITS, w.nb_i,  \
+                               last ? a->tile_offsets : (int32_t *)nullptr, (const int32_t *)nullptr, (const float *)nullptr,      \
+                               w.lb_desc + desc_off[pass], tickets + pass, fail)
+#define DNS_LB2(B) do { if (last) DNS_LB(B, true); else DNS_LB(B, false); } while (0)
+            switch (dbits[pass]) {
+                case 1: DNS_LB2(1); break;
+                case 2: DNS_LB2(2); break;
+                case 3: DNS_LB2(3); break;
+                case 4: DNS_LB2(4); break;
+                case 5: DNS_LB2(5); break;
+                case 6: DNS_LB2(6); break;
+                case 7: DNS_LB2(7); break;
+                default: DNS_LB2(8); break;
+            }
+#undef DNS_LB2
+#undef DNS_LB
+            K *t = ka; ka = kb; kb = t;
+            uint32_t *u = va; va = vb; vb = u;
+        }
+        hipLaunchKernelGGL(tile_offsets_fill_kernel, dim3(1), dim3(TO_THREADS), 0, stream, n_tiles, a->tile_offsets);
+        return;
+    }
+#endif
+    hipLaunchKernelGGL(emit_kernel<K>, dim3((a->N + 255) / 256), dim3(256), 0, stream, a->N, a->N / n_cam, w.val_a, w.cum,
+                       a->means2d, a->radii, a->tile_size, tw, th, cap, ka, va);
     int shift = 0;
     for (int pass = 0; pass < passes; ++pass) {
         const int dbits = (bits - shift + (passes - pass) - 1) / (passes - pass);   // 13 bits -> 7 + 6
@@ -548,6 +729,13 @@ extern "C" size_t dnsplat_bin_workspace_bytes(int32_t N, int64_t isect_capacity,
     (void)n_tiles;
     if (N < 0 || isect_capacity < 0) return 0;
     return carve(nullptr, N, isect_capacity).bytes;
+}
+
+extern "C" size_t dnsplat_bin_status_offset(int32_t N, int64_t isect_capacity)
+{
+    if (N < 0 || isect_capacity < 0) return 0;
+    const BinWs w = carve(nullptr, N, isect_capacity);
+    return (size_t)((char *)(w.lb_ctl + 3 * RS_DIGITS + 3) - (char *)nullptr);
 }
 
 static int check_bin(const dnsplat_bin_args *a)

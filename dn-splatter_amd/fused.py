@@ -149,6 +149,6 @@ def _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest
         "tiles_per_gauss": pr["tiles_per_gauss"], "normals_world": pr["normals_world"][-1],      # dn_model.py:558 keeps the last camera's
         "flatten_ids": b.flatten_ids[: b.n_isects], "isect_offsets": b.tile_offsets[:-1].reshape(C, b.tile_height, b.tile_width),
         "n_isects": b.n_isects, "tile_width": b.tile_width, "tile_height": b.tile_height,
-        "width": width, "height": height, "tile_size": 16, "n_cameras": C,
+        "width": width, "height": height, "tile_size": 16, "n_cameras": C, "_binning": b,
     }
     return {"rgb": rgb, "depth": depth, "normal": normal, "surface_normal": surface_normal, "accumulation": acc}, info

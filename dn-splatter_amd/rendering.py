@@ -120,6 +120,7 @@ def rasterization(
         "tile_size": tile_size,
         "n_cameras": C,
         "n_isects": b.n_isects,
+        "_binning": b,             # not a gsplat key: handle for _ops.binning_status / lazily built entries
     }
     if pr["compensations"] is not None:
         meta["compensations"] = pr["compensations"]

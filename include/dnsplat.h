@@ -124,6 +124,12 @@ int dnsplat_pack_splats(int32_t N, const float *means2d, const float *conics, co
  * and (3) a stable radix sort on the tile id only. */
 size_t dnsplat_bin_workspace_bytes(int32_t N, int64_t isect_capacity, int32_t n_tiles);
 
+/* Byte offset, inside a workspace of that geometry, of a 32-bit status word: non-zero after dnsplat_bin_emit_sort iff a
+ * look-back wait of the tile sort ran into its 20 ms bound (the lists of that frame are then wrong).  By construction a
+ * wait only depends on workgroups that have already started, so this is a safety net against a hung device, not an
+ * expected event; tests read it after the large frames. */
+size_t dnsplat_bin_status_offset(int32_t N, int64_t isect_capacity);
+
 typedef struct dnsplat_bin_args {
     int32_t N;                       /* entries = n_cameras x Gaussians; entry cam * (N / n_cameras) + g is Gaussian g seen by camera cam */
     int32_t n_cameras;               /* >= 1; images of one batch share width / height (gsplat rasterization with C cameras) */

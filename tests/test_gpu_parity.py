@@ -933,6 +933,8 @@ def test_full_size_projection_and_binning_match_oracle(dns, orc, workload):
         tw, th = math.ceil(W / 16), math.ceil(H / 16)
         _t, isect_ids, flatten_ids = orc.isect_tiles(means2d, radii, depths, 16, tw, th)
         offsets = orc.isect_offset_encode(isect_ids, tw, th)
+    from dn_splatter_amd import _ops
+    assert _ops.binning_status(info["_binning"], N) == 0, "a look-back wait of the tile sort timed out"
     assert_equal_int(info["radii"][0], radii, workload + " radii")
     assert_equal_int(info["tiles_per_gauss"][0], tiles, workload + " tiles_per_gauss")
     assert info["n_isects"] == flatten_ids.shape[0] > 30_000_000
@@ -943,8 +945,11 @@ def test_full_size_projection_and_binning_match_oracle(dns, orc, workload):
 
 
 def test_full_size_binning_properties(dns, full_scene):
+    from dn_splatter_amd import _ops
+
     gp, cam, m, out = full_scene
     info = m.last_info
+    assert _ops.binning_status(info["_binning"], info["radii"].numel()) == 0, "a look-back wait of the tile sort timed out"
     n = info["n_isects"]
     tiles = info["tiles_per_gauss"][0].long()
     assert int(tiles.sum()) == n, "sum(tiles_per_gauss) != n_isects"
