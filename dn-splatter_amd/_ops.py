@@ -131,7 +131,7 @@ def _grad_like(param: Tensor) -> Tensor:
     run ``param.grad += new``: had the kernel written into the bucket, old and new gradient would be the same memory and
     the sum would come out as 2 x new.  A fresh tensor keeps accumulation correct (the sum still lands in the bucket)."""
     a = GRAD_ARENA
-    if a is not None and not a.holds(param.grad):
+    if a is not None and not a.in_use(param):
         t = a.take(param)
         if t is not None:
             return t.view(param.shape)
@@ -438,7 +438,7 @@ def binning_status(b: Binning, n_entries: int) -> int:
     """The tile sort's status word of the frame that produced ``b`` (0 = fine; see dnsplat_bin_status_offset).  Reads the
     workspace of the current stream, i.e. call it before the next frame is binned there; synchronises."""
     ws = BUFFERS.ws.get(_Buffers._key(b.flatten_ids.device))
-    if ws is None:
+    if ws is None or b.n_isects <= 0:
         return 0
     off = _lib.lib().dnsplat_bin_status_offset(n_entries, b.flatten_ids.numel())
     return int(ws[off:off + 4].view(torch.int32).item())

@@ -700,7 +700,7 @@ void emit_and_sort(hipStream_t stream, const dnsplat_bin_args *a, const BinWs &w
     }
 #endif
     hipLaunchKernelGGL(emit_kernel<K>, dim3((a->N + 255) / 256), dim3(256), 0, stream, a->N, a->N / n_cam, w.val_a, w.cum,
-                       a->means2d, a->radii, a->tile_size, tw, th, cap, ka, va);
+                       a->means2d, a->radii, a->tile_size, tw, th, cap, ka, va, w.lb_ctl, LB_CTL_WORDS);   // status word := 0
     int shift = 0;
     for (int pass = 0; pass < passes; ++pass) {
         const int dbits = (bits - shift + (passes - pass) - 1) / (passes - pass);   // 13 bits -> 7 + 6

@@ -53,6 +53,7 @@ class GradArena:
             dev = p.device
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self._by_ptr = {params[k].data_ptr(): k for k in GRAD_KEYS}
+        self._leaf = {k: params[k] for k in GRAD_KEYS}      # the leaves whose .grad the slices become
 
     def view(self, name: str) -> Tensor:
         off, n, shape = self.slices[name]
@@ -64,6 +65,15 @@ class GradArena:
         if name is None or self.slices[name][1] != like.numel():
             return None
         return self.view(name)
+
+    def in_use(self, like: Tensor) -> bool:
+        """True when the bucket slice of parameter ``like`` (a leaf, or a view of one such as opacities.reshape(N)) is
+        currently installed as that leaf's ``.grad`` — the backward must then not write into it (see the class docstring)."""
+        name = self._by_ptr.get(like.data_ptr())
+        if name is None:
+            return False
+        g = self._leaf[name].grad
+        return g is not None and self.holds(g)
 
     def holds(self, t: Optional[Tensor]) -> bool:
         if t is None:

@@ -751,6 +751,59 @@ def test_sh_rebuild_kernel_equals_torch_rebuild_at_node_scale(dns, n_views, sh_d
     assert_close(vN, tot[:, 1:], "rebuilt bands 1..3 (inactive bands must be zero, not untouched)", 1e-5)
 
 
+def test_gradient_accumulation_into_the_flat_bucket(dns):
+    """with a GradArena installed, a second backward while param.grad still lives in the bucket must give
+    g1 + g2 (autograd's in-place +=), not 2 x g2 (which is what writing the new gradient into the aliased bucket gave)."""
+    from dn_splatter_amd import dp, synthetic
+
+    N, W, H = 20_000, 320, 240
+    gp = synthetic.make_gauss_params(N, sh_rest_std=0.2, seed=6, device=DEV)
+    cams = [synthetic.orbit_camera(v, width=W, height=H, focal=200.0).to(DEV) for v in (0, 3)]
+    m = dns.DNSplatterRenderer(gp, fused=True)
+
+    def grads(cam):
+        for k in GRAD_NAMES:
+            gp[k].grad = None
+        out = m.get_outputs(cam)
+        (out["rgb"].sum() + out["depth"].sum() + out["normal"].sum()).backward()
+        return {k: gp[k].grad.clone() for k in GRAD_NAMES}
+
+    g1, g2 = grads(cams[0]), grads(cams[1])
+    arena = dp.GradArena(gp)
+    dns.set_grad_arena(arena)
+    try:
+        for k in GRAD_NAMES:
+            gp[k].grad = None
+        for cam in cams:                                   # no zero_grad in between: accumulate
+            out = m.get_outputs(cam)
+            (out["rgb"].sum() + out["depth"].sum() + out["normal"].sum()).backward()
+        torch.cuda.synchronize()
+        for k in GRAD_NAMES:
+            assert arena.holds(gp[k].grad), k              # the sum still lives in the bucket
+            assert_close(gp[k].grad, g1[k] + g2[k], "accumulated grad " + k, 1e-5)
+    finally:
+        dns.set_grad_arena(None)
+
+
+def test_background_width_follows_gsplat(dns, orc):
+    """gsplat takes backgrounds [C, colour channels] and gives the depth channel of RGB+ED a zero background
+    itself; a row of any other width must raise instead of making the kernel read past it."""
+    inp, viewmat, K, _ = gsplat_inputs(2000, 96, 80, focal=70.0, seed=7, anisotropic=True)
+    bg3 = torch.tensor([[0.2, 0.4, 0.6]])
+    gi = {k: v.to(DEV) for k, v in inp.items()}
+    kw = dict(width=96, height=80, packed=False, sh_degree=3, render_mode="RGB+ED")
+    with torch.no_grad():
+        r_o, a_o, info_o = orc.rasterization(**inp, viewmats=viewmat, Ks=K, backgrounds=bg3, **kw)
+        r_g, a_g, _ = dns.rasterization(**gi, viewmats=viewmat.to(DEV), Ks=K.to(DEV), backgrounds=bg3.to(DEV), **kw)
+        r_4, _a, _ = dns.rasterization(**gi, viewmats=viewmat.to(DEV), Ks=K.to(DEV),
+                                       backgrounds=torch.tensor([[0.2, 0.4, 0.6, 0.0]], device=DEV), **kw)
+    keep = keep_mask(info_o["borderline"], "background width")
+    assert_close(r_g, r_o, "render with a 3-wide background in RGB+ED", keep=keep)
+    assert torch.equal(r_g, r_4)
+    with pytest.raises(ValueError):
+        dns.rasterization(**gi, viewmats=viewmat.to(DEV), Ks=K.to(DEV), backgrounds=torch.zeros(1, 2, device=DEV), **kw)
+
+
 def test_small_frame_stays_in_the_millisecond_range(dns):
     """Regression guard.  A wave shuffle placed under a lane-dependent branch once made the emit kernel read a neighbour's
     count as 0 and spin through 2^32 / 32 guarded iterations: every result stayed bit-exact, but a 320 x 240 frame (300

@@ -1,4 +1,4 @@
-"""Forward-only frames/s of the offline render loop (N4): sequential get_outputs vs get_outputs_batch on HIP streams."""
+"""Forward-only frames/s of the offline render loop (N4): sequential get_outputs vs get_outputs_batch (C cameras per launch sequence)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,6 +16,6 @@ def timed(fn, reps=3):
     torch.cuda.synchronize()
     return len(cams) * reps / (time.perf_counter() - t)
 with torch.no_grad():
-    print("sequential get_outputs      : %.1f frames/s" % timed(lambda: [m.get_outputs(c) for c in cams]))
-for ns in (1, 2, 3, 4):
-    print("get_outputs_batch streams=%d : %.1f frames/s" % (ns, timed(lambda: m.get_outputs_batch(cams, n_streams=ns))))
+    print("sequential get_outputs        : %.1f frames/s" % timed(lambda: [m.get_outputs(c) for c in cams]))
+for mb in (1, 2, 4, 8):
+    print("get_outputs_batch max_batch=%d : %.1f frames/s" % (mb, timed(lambda: m.get_outputs_batch(cams, max_batch=mb))))
