@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # profiles refresh: full GPU suite, bench line, rocprofv3 kernel stats, PMC traffic (bench) and the per-kernel replay traffic
-cd "${GRAFT_REPO_ROOT:-.}"; R=$(pwd); O=gpurun_out/r02g; mkdir -p $O; export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-.}"; R=$(pwd); O=gpurun_out/profiles_refresh; mkdir -p $O; export TMPDIR=/tmp
 echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
 echo "== bench"; python bench.py --steps 30 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.json | cut -c1-400
 echo "== kernel stats"
@@ -24,7 +24,7 @@ echo "== VALU busy counters"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d "$R/$O/pmc_grbm" -o p -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1); echo "grbm rc=$?"
 python tools/pmc_summary.py $O > $O/pmc_sq_summary.json 2>/dev/null; python - <<'PY'
 import json
-d=json.load(open("gpurun_out/r02g/pmc_sq_summary.json"))
+d=json.load(open("gpurun_out/profiles_refresh/pmc_sq_summary.json"))
 for k in ("raster_bwd_kernel","raster_fwd_kernel"):
     if k in d: print(k, {c:v for c,v in d[k].items() if c.startswith(("SQ_","GRBM"))})
 PY
