@@ -76,7 +76,7 @@ GRAD_NAMES = ("means", "scales", "quats", "features_dc", "features_rest", "opaci
 OUT_KEYS = ("rgb", "depth", "normal", "accumulation")
 
 
-def _mirror_pair(dns, orc, gp, cam, hip_kw, cot_seed=2, what="mirror"):
+def _mirror_pair(dns, orc, gp, cam, hip_kw, cot_seed=2, what="mirror", config=None, step=None):
     """DNSplatterModel.get_outputs (dn_model.py:404-612) twice: the reference's own op sequence with the oracle plugged in
     for the two gsplat calls (CPU), and the product (GPU, ``hip_kw`` picks fused / two-call).  The oracle runs first: its
     borderline mask (plus the pixels whose pre-clamp rgb sits within rounding of the clamp(0, 1) corners, where the
@@ -93,8 +93,11 @@ def _mirror_pair(dns, orc, gp, cam, hip_kw, cot_seed=2, what="mirror"):
         return {k: v.detach().to(device).clone().requires_grad_(k != "normals") for k, v in gp.items()}
 
     p_o = leaves("cpu")
-    m_o = dns.DNSplatterRenderer(p_o, fused=False, rasterization_fn=rasterization_spy,
+    m_o = dns.DNSplatterRenderer(p_o, config=config, fused=False, rasterization_fn=rasterization_spy,
                                  rasterize_gaussians_fn=orc.rasterize_gaussians)
+    if step is not None:
+        m_o.step = step
+    orc.last_borderline = None
     out_o = m_o.get_outputs(cam)
     border = captured["info"]["borderline"].clone()
     if orc.last_borderline is not None and orc.last_borderline.shape == border.shape:
@@ -104,12 +107,16 @@ def _mirror_pair(dns, orc, gp, cam, hip_kw, cot_seed=2, what="mirror"):
     keep = keep_mask(border, what)
     gen = torch.Generator().manual_seed(cot_seed)
     cot = {k: zero_borderline(torch.rand(out_o[k].shape, generator=gen) * 2 - 1, keep) for k in OUT_KEYS}
-    torch.autograd.backward([out_o[k] for k in OUT_KEYS], [cot[k] for k in OUT_KEYS])
+    live = [k for k in OUT_KEYS if out_o[k].requires_grad]          # predict_normals=False hands out a constant normal image
+    torch.autograd.backward([out_o[k] for k in live], [cot[k] for k in live])
 
     p_g = leaves(DEV)
-    m_g = dns.DNSplatterRenderer(p_g, **hip_kw)
+    m_g = dns.DNSplatterRenderer(p_g, config=config, **hip_kw)
+    if step is not None:
+        m_g.step = step
     out_g = m_g.get_outputs(cam.to(DEV))
-    torch.autograd.backward([out_g[k] for k in OUT_KEYS], [cot[k].to(DEV) for k in OUT_KEYS])
+    assert [k for k in OUT_KEYS if out_g[k].requires_grad] == live
+    torch.autograd.backward([out_g[k] for k in live], [cot[k].to(DEV) for k in live])
     torch.cuda.synchronize()
     return (out_g, p_g, m_g), (out_o, p_o, m_o), keep
 
@@ -144,6 +151,9 @@ def _check_mirror(hip, ora, keep, what="mirror", quat_atol=0.0, ints=True):
         assert out_g[k].shape == out_o[k].shape
         assert_close(out_g[k], out_o[k], what + " " + k, keep=keep)
     for k in GRAD_NAMES:
+        if p_o[k].grad is None:           # e.g. the inactive SH bands' tensor when sh_degree == 0 feeds sigmoid(colours)
+            assert p_g[k].grad is None or float(p_g[k].grad.abs().max()) == 0.0, k
+            continue
         assert_close(p_g[k].grad, p_o[k].grad, what + " grad " + k, atol=quat_atol if k == "quats" else 0.0)
     assert_close(m_g.xys.grad, m_o.xys.grad, what + " xys.grad (dn_model.py:517-519)")
     assert_close(m_g.xys.absgrad, m_o.xys.absgrad, what + " xys.absgrad")
@@ -433,6 +443,33 @@ def test_get_outputs_mirror_matches_reference_sequence(dns, orc, mode):
     sn = out_g["surface_normal"].detach().cpu()
     assert torch.equal(sn[0], torch.full_like(sn[0], 0.5)) and torch.equal(sn[:, -1], torch.full_like(sn[:, -1], 0.5))
     assert_close(p_g["normals"], p_o["normals"], "gauss_params['normals'] (dn_model.py:558)", 1e-5)
+
+
+@pytest.mark.parametrize("name,cfg_kw,step,hip_kw", [
+    ("sh_degree_0", dict(sh_degree=0), None, dict(fused=True)),                         # dn_model.py:491-493: sigmoid(colours), sh_degree=None
+    ("no_normals", dict(predict_normals=False), None, dict(fused=True)),                # dn_model.py:542: zeros for the normal image
+    ("sh_schedule", dict(), 1500, dict(fused=True)),                                    # dn_model.py:487-490: min(step // 1000, 3) = 1 active band set
+    ("antialiased", dict(rasterize_mode="antialiased"), None, dict(fused=True)),        # compensated opacities in pass 1 only (dn_model.py:571)
+])
+def test_get_outputs_mirror_config_variants(dns, orc, name, cfg_kw, step, hip_kw):
+    """The branches of get_outputs the default configuration does not take, product (it picks the fused or the two-call
+    route itself) against the reference sequence on the oracle."""
+    from dn_splatter_amd import RendererConfig, synthetic
+
+    N, W, H = 6000, 192, 144
+    gp = synthetic.make_gauss_params(N, sh_rest_std=0.2, seed=8)
+    g_ = torch.Generator().manual_seed(22)
+    gp["scales"] = (gp["scales"].detach() + torch.randn(N, 3, generator=g_) * 0.5).requires_grad_(True)
+    if name == "sh_degree_0":
+        gp["features_rest"] = torch.zeros(N, 0, 3, requires_grad=True)      # num_sh_bases(0) = 1: no higher bands (dn_model.py:139-154)
+    cam = synthetic.orbit_camera(5, width=W, height=H, focal=130.0)
+    hip, ora, keep = _mirror_pair(dns, orc, gp, cam, hip_kw, what="mirror " + name, config=RendererConfig(**cfg_kw), step=step)
+    _check_mirror(hip, ora, keep, "mirror " + name, ints=False)
+    assert_equal_int(hip[2].radii, ora[2].radii, "radii")
+    if name == "no_normals":
+        assert float(hip[0]["normal"].abs().max()) == 0.0
+    if name == "sh_schedule":
+        assert float(hip[1]["features_rest"].grad[:, 3:].abs().max()) == 0.0      # bands 2 and 3 are inactive at step 1500
 
 
 def test_densify_stats_match_nerfstudio_after_train(dns):
