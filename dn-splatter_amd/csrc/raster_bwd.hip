@@ -56,17 +56,17 @@ constexpr int TILE = 16;
 #ifndef DNS_BWD_ROWS
 #define DNS_BWD_ROWS 8
 #endif
-// Register budget.  Left alone hipcc uses ~164 VGPRs (3 waves per SIMD), which already keep the SIMDs 95 % busy (PMC).  Forcing a
-// fourth wave per SIMD (amdgpu_waves_per_eu(4,4): 128 VGPRs) puts nine loop-invariant splat parameters into scratch that are
-// re-read every step: measured 1.68 -> 2.74 ms.
+// Register budget.  The benchmark instantiation (fused pass, forward's keep masks) sits right at the 128-VGPR line that
+// separates 4 from 3 waves per SIMD, and hipcc's allocation lands on 120 ... 130 depending on details of the control flow
+// around the step loop.  That instantiation is therefore PINNED to 4 waves (amdgpu_waves_per_eu): what does not fit (two
+// values at the time of writing) is spilled to scratch outside the step loop — stored once per work unit, reloaded once
+// per bucket (tools/check_asm_hazards.py checks that the step loop itself stays scratch-free).  The other instantiations
+// are left alone: forcing the same budget on the instantiation that re-derives the masks (164 VGPRs) put nine
+// loop-invariant splat parameters into scratch that were re-read every step: measured 1.68 -> 2.74 ms.
 #ifndef DNS_BWD_WAVES_PER_EU
-#define DNS_BWD_WAVES_PER_EU 0
+#define DNS_BWD_WAVES_PER_EU 4
 #endif
-#if DNS_BWD_WAVES_PER_EU > 0
-#define DNS_BWD_OCCUPANCY __attribute__((amdgpu_waves_per_eu(DNS_BWD_WAVES_PER_EU, DNS_BWD_WAVES_PER_EU)))
-#else
-#define DNS_BWD_OCCUPANCY
-#endif
+#define DNS_BWD_OCCUPANCY(pinned) __attribute__((amdgpu_waves_per_eu((pinned) ? DNS_BWD_WAVES_PER_EU : 1, (pinned) ? DNS_BWD_WAVES_PER_EU : 8)))
 // pixel coordinates from an LDS table read one step ahead (1) or recomputed from the pixel counter every step (0).
 // Measured (paired A/B, tools/ab_kernels.py): the table is not faster — the six integer / convert instructions it removes were
 // not on the kernel's critical resource.
@@ -91,6 +91,17 @@ constexpr int TILE = 16;
 #ifndef DNS_BWD_SCALAR_LOOP
 #define DNS_BWD_SCALAR_LOOP 1
 #endif
+// Folding of the last, partly filled bucket of a work unit (1) or the plain array (0).
+// The 64 lanes are four ROWS OF 16 linked through LDS instead of one 64-lane shift register: the pixel state moves by
+// row_shr:1 inside a row, the last lane of a row parks it in the pixel's LDS row and the first lane of the next row picks it
+// up from there one step later — for free, every lane reads its pixel's row (for bin_final) anyway, and the park is the
+// store lane 63 already did.  A bucket costs ~143 steps however few splats it holds, and the last bucket of a unit holds
+// 64 on average: with <= 64 (<= 32) splats the four rows are re-cut into two (four) independent arrays that each hold
+// ALL of the bucket's splats and stream a share of the pixels — 80 + 48 (56 + 40 + 24 + 8) of the 128, unequal because a
+// later row is still busy with the previous bucket for 16 more steps per row — and the bucket ends after 111 (71) steps.
+#ifndef DNS_BWD_FOLD
+#define DNS_BWD_FOLD 1
+#endif
 constexpr int ROWS = DNS_BWD_ROWS;
 constexpr int PARTS = TILE / ROWS;              // waves (workgroups) per tile
 constexpr int NPIX = TILE * ROWS;
@@ -100,6 +111,7 @@ constexpr int BUCKET = 2 * DNS_WAVE;   // splats in the array at a time: two per
 #endif
 constexpr int GROUP = DNS_BWD_GROUP;            // lanes that change splats at the same step
 constexpr int NGROUP = DNS_WAVE / GROUP;
+static_assert(!DNS_BWD_FOLD || GROUP == 16, "the folded arrays start at the DPP rows' (16 lanes) switch steps");
 #ifndef DNS_BWD_FLUSH_REC
 #define DNS_BWD_FLUSH_REC 16
 #endif
@@ -188,9 +200,15 @@ __device__ __forceinline__ void pk_fma_bcast(f2 &acc, f2 a, f2 b, int hi)
 
 __device__ __forceinline__ float dpp_wave_shr1(float from_prev, float lane0_value)
 {
+#if DNS_BWD_FOLD
+    // lane l receives `from_prev` of lane l-1 of its row of 16; the first lane of a row (no source) keeps `lane0_value`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0_value), __float_as_int(from_prev),
+                                                      0x111 /* row_shr:1 */, 0xf, 0xf, false));
+#else
     // lane l receives `from_prev` of lane l-1; lane 0 (no source) keeps `lane0_value`
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0_value), __float_as_int(from_prev),
                                                       0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+#endif
 }
 
 // SPLIT >= 0: compile-time split; SPLIT < 0: run-time a.xy_split
@@ -200,7 +218,7 @@ __device__ __forceinline__ float dpp_wave_shr1(float from_prev, float lane0_valu
 // with dns_cull_rect: same decisions (the forward ran the same test on the same records), no record gathers for rejected
 // entries, and the test's registers (the kernel's VGPR peak) are gone.
 template <int D, int SPLIT, bool DN, bool COUNT = false, bool MASKS = false>
-__global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(BwdArgs a)
+__global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) void raster_bwd_kernel(BwdArgs a)
 {
     __shared__ float4 pix[NPIX][3];            // [p][0..1] = v_k, [p][2] = (T, S_a, S_b, bin_final)
     // compacted list indices waiting for a bucket (never more than 127 + 64) + the 1 KiB staging area of the transposed flush, which
@@ -359,6 +377,9 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
     for (int k = 0; k < 8; ++k) { ch[k] = zero2; g_ch[k] = zero2; }
     [[maybe_unused]] bool touched_a = false, touched_b = false;
     int p = -(1 << 20);                           // negative = not started; a group's switch sets it to -(lane % GROUP)
+    // DNS_BWD_FOLD: the lane's array streams pixels [p_first, p_first + p_count) of the half tile (all of them unless folded)
+    [[maybe_unused]] int p_first = 0, p_count = NPIX;
+    [[maybe_unused]] bool folded = false;          // the bucket in the lanes is a folded (hence the last) one (wave-uniform)
     float T_out = 0.f, SA_out = 0.f, SB_out = 0.f;
 
     const int col = lane & 15;
@@ -404,6 +425,17 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
         const int take = min(qn, BUCKET);     // entries [0, take) are this bucket; lane l owns 2l (A) and 2l+1 (B)
         qn -= take;                           // what is left sits at [BUCKET, BUCKET + qn) until the next boundary
         const bool last = take == 0;          // nothing new: only drain what is still in the lanes
+#if DNS_BWD_FOLD
+        // take < BUCKET only when the list is exhausted: this is the unit's last bucket.  fold = number of independent arrays
+        const int fold = (take > 0 && take <= BUCKET / 4) ? 4 : (take > 0 && take <= BUCKET / 2) ? 2 : 1;
+        const int fold_lanes = DNS_WAVE / fold;                 // lanes per array
+        // after a folded bucket every lane is finished when its steps end: the closing pass only flushes (all four groups)
+        const bool flush_only = last && folded;
+        if (flush_only) prev_take = BUCKET;
+#else
+        constexpr int fold = 1;
+        constexpr bool flush_only = false;
+#endif
 
 #pragma nounroll
         for (int grp = 0; grp < NGROUP; ++grp) {
@@ -459,8 +491,13 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
             }
             // -- the group's new splats, as packed pairs
             if (mine) {
-                const int idx_a = 2 * lane < take ? queue[2 * lane] : -1;
-                const int idx_b = 2 * lane + 1 < take ? queue[2 * lane + 1] : -1;
+#if DNS_BWD_FOLD
+                const int ll = lane & (fold_lanes - 1);          // position in the lane's array
+#else
+                const int ll = lane;
+#endif
+                const int idx_a = 2 * ll < take ? queue[2 * ll] : -1;
+                const int idx_b = 2 * ll + 1 < take ? queue[2 * ll + 1] : -1;
                 float4 ra0 = make_float4(0.f, 0.f, 0.f, 0.f), ra1 = ra0, ra2 = ra0, ra3 = ra0;
                 float4 rb0 = ra0, rb1 = ra0, rb2 = ra0, rb3 = ra0;
                 gid_a = 0; gid_b = 0;
@@ -490,12 +527,28 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
 #pragma unroll
                 for (int k = 0; k < 8; ++k) g_ch[k] = zero2;
                 touched_a = false; touched_b = false;
+#if DNS_BWD_FOLD
+                // pixel shares: array j starts 16 j (fold 4) / 32 j (fold 2) steps after array 0 and all end together
+                const int arr = lane / fold_lanes;
+                p_first = fold == 4 ? (arr == 0 ? 0 : arr == 1 ? 56 : arr == 2 ? 96 : 120) * NPIX / 128
+                        : fold == 2 ? (arr == 0 ? 0 : 80) * NPIX / 128 : 0;
+                p_count = fold == 4 ? (arr == 0 ? 56 : arr == 1 ? 40 : arr == 2 ? 24 : 8) * NPIX / 128
+                        : fold == 2 ? (arr == 0 ? 80 : 48) * NPIX / 128 : NPIX;
+                p = p_first - (lane % GROUP);
+#else
                 p = -(lane % GROUP);
+#endif
 #if DNS_BWD_COORD_TABLE
                 { const float2 c = coord[p & (NPIX - 1)]; pxy = f2{c.x, c.y}; }
 #endif
             }
             int nsteps = grp < NGROUP - 1 ? GROUP : PERIOD - GROUP * (NGROUP - 1);
+#if DNS_BWD_FOLD
+            // a folded bucket: every array ends (its start) + (its lanes - 1) + (its pixels) steps after the bucket's start
+            if (grp == NGROUP - 1 && fold > 1) nsteps = (fold == 4 ? 15 + 56 * NPIX / 128 : 31 + 80 * NPIX / 128) - GROUP * (NGROUP - 1);
+            if (grp == NGROUP - 1) folded = fold > 1;
+            if (flush_only) continue;                                     // nothing left to stream
+#endif
             if (last) {
                 if (2 * GROUP * (grp + 1) >= prev_take) break;           // that was the last group with anything to flush
                 nsteps = GROUP;
@@ -518,7 +571,11 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
             auto step_loop = [&](auto clamp_tag) {
             constexpr bool CLAMP = decltype(clamp_tag)::value;
             for (int s = 0; s < nsteps; ++s) {
+#if DNS_BWD_FOLD
+                const bool active = (unsigned)(p - p_first) < (unsigned)p_count;
+#else
                 const bool active = (unsigned)p < (unsigned)NPIX;
+#endif
                 int pcur = p & (NPIX - 1);
                 v4f c0, c1, cst;
                 row_issue(pix_base + pcur * 48, c0, c1, cst, pcur);
@@ -618,7 +675,11 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY void raster_bwd_kernel(
                 }
                 T_out = T; SA_out = SA; SB_out = SB;
                 // park the state of the pixel leaving the array for the next (nearer) bucket
+#if DNS_BWD_FOLD
+                if ((lane & 15) == 15 && active) pix[pcur][2] = make_float4(T, SA, SB, cst.w);   // to the next row / bucket
+#else
                 if (lane == DNS_WAVE - 1 && active) pix[pcur][2] = make_float4(T, SA, SB, cst.w);
+#endif
                 ++p;
             }
             };

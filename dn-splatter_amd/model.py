@@ -259,7 +259,7 @@ class DNSplatterRenderer:
         if cfg.predict_normals and normals_im is None:
             # the reference's second pass, verbatim (dn_model.py:543-575)
             quats_n = quats / quats.norm(dim=-1, keepdim=True)
-            normals = F.one_hot(torch.argmin(scales, dim=-1), num_classes=3).float()
+            normals = F.one_hot(torch.argmin(scales, dim=-1), num_classes=3).to(scales.dtype)   # .float() in the reference
             rots = quat_to_rotmat(quats_n)
             normals = torch.bmm(rots, normals[:, :, None]).squeeze(-1)
             normals = F.normalize(normals, dim=1)

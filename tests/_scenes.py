@@ -70,10 +70,20 @@ def zero_borderline(v, keep):
     return v * k[..., None]
 
 
-def assert_close(a, b, what, tol=REL_TOL, atol=0.0, keep=None):
-    """max|a-b| <= tol * max|b| + atol over all entries (over the pixels selected by ``keep`` for images).
+def assert_close(a, b, what, tol=REL_TOL, atol=0.0, keep=None, envelope=None):
+    """|a-b| <= tol * max|b| + atol (+ envelope) at every entry (over the pixels selected by ``keep`` for images).
     ``atol`` is only for tensors that are mathematically zero (e.g. the quaternion gradient of isotropic
-    Gaussians), where both sides hold nothing but fp32 rounding noise."""
+    Gaussians), where both sides hold nothing but fp32 rounding noise.
+    ``envelope``: per-entry rounding envelope of the REFERENCE algorithm itself, FP32_ENVELOPE x |oracle in fp32 - the same
+    oracle in fp64| (fp64_envelope below): on anisotropic scenes the fp32 evaluation of a few gradient entries (sums with
+    heavy cancellation through an ill-conditioned 2x2 inverse) is itself 1-2.4 tolerances away from exact arithmetic
+    (tools/parity_seed_sweep.py), so no fp32 implementation with a different summation order can be expected closer than that
+    THERE.  Example (seed 103 of the sweep): d/d(scale_0) of a disc with scales (0.021, 0.30, 0.40) covering 140 tiles is
+    -1.65686 in fp64, -1.65977 in the fp32 oracle, -1.66212 / -1.66300 in two HIP runs (the atomics' order differs): a
+    relative error of 2e-3 in EVERY fp32 evaluation.  Everywhere else the envelope is ~1e-7 of the value and the comparison
+    stays at the plain tolerance; with the envelope the suite's worst comparison sits at 0.52 of its allowance and 60 unseen
+    seeds of the C1 scene pass (without it: 0.77, and 3 of 60 fail).
+    DNSPLAT_MARGIN_LOG=<file>: append "what, worst error / allowance" for every comparison (how close the suite runs to its limits)."""
     a_ = a.detach().cpu()
     b_ = b.detach().cpu()
     assert a_.shape == b_.shape, f"{what}: shape {tuple(a_.shape)} vs {tuple(b_.shape)}"
@@ -84,11 +94,31 @@ def assert_close(a, b, what, tol=REL_TOL, atol=0.0, keep=None):
     if keep is not None:
         a_, b_ = image_pixels(a_, keep), image_pixels(b_, keep)
     d = (a_.double() - b_.double()).abs().reshape(-1)
-    err = d.max().item() if d.numel() else 0.0
-    if err > tol * scale + atol:
-        n_bad = int((d > tol * scale + atol).sum())
-        raise AssertionError(f"{what}: max abs error {err:.3e} > {tol:.1e} * scale {scale:.3e} + {atol:.1e} "
+    allow = torch.full_like(d, tol * scale + atol)
+    if envelope is not None:
+        assert keep is None and envelope.shape == b.shape
+        allow = allow + envelope.detach().cpu().double().reshape(-1)
+    ratio = (d / allow.clamp_min(1e-300)) if d.numel() else d
+    worst = ratio.max().item() if d.numel() else 0.0
+    log = os.environ.get("DNSPLAT_MARGIN_LOG")
+    if log:
+        strict = (d.max().item() / (tol * scale + atol)) if d.numel() and tol * scale + atol > 0 else 0.0
+        with open(log, "a") as f:
+            f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]}\t{what}\t{worst:.3f}\t{strict:.3f}\n")
+    if worst > 1.0:
+        n_bad = int((ratio > 1.0).sum())
+        raise AssertionError(f"{what}: max abs error {d.max().item():.3e} vs {tol:.1e} * scale {scale:.3e} + {atol:.1e}"
+                             f"{' + fp64 envelope' if envelope is not None else ''}: worst error / allowance = {worst:.2f} "
                              f"({n_bad} of {d.numel()} entries beyond it)")
+
+
+FP32_ENVELOPE = 4.0
+
+
+def fp64_envelope(g32, g64):
+    """FP32_ENVELOPE x |fp32 oracle - fp64 oracle| per entry: how far the reference algorithm's own fp32 evaluation is from
+    exact arithmetic at that entry (assert_close)."""
+    return FP32_ENVELOPE * (g32.detach().double() - g64.detach().double()).abs()
 
 
 def assert_equal_int(a, b, what):

@@ -4,7 +4,9 @@ row_issue() starts three ds_read_b128 whose destination registers the compiler b
 immediately; row_wait() carries the s_waitcnt.  The ISA must not touch those registers in between (a
 compiler-inserted copy there would read data that has not landed), and it should not wait for them early
 (that only costs time).  Compiles the file with -save-temps and
-scans every raster_bwd_kernel instantiation.  Exit code 1 on a hazard.
+scans every raster_bwd_kernel instantiation.  Also checked: the step loop (the innermost loop around those loads) holds no
+scratch access — the benchmark instantiation is pinned to 128 VGPRs and may spill, but only outside that loop.
+Exit code 1 on a hazard.
 """
 import os
 import re
@@ -36,10 +38,11 @@ def check() -> int:
         asm = open(os.path.join(tmp, "raster_bwd-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     kernels = re.findall(r"^(_ZN\S*raster_bwd_kernel\S*):", asm, re.M)
     assert kernels, "no raster_bwd_kernel found in the ISA"
-    hazards = groups = early = 0
+    hazards = groups = early = spills = 0
     for name in kernels:
         body = re.search(re.escape(name) + r":(.*?)\.Lfunc_end", asm, re.S).group(1)
         lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
+        label_at = {m.group(1): n for n, l in enumerate(lines) for m in [re.match(r"(\.LBB\w+):", l)] if m}
         i = 0
         while i < len(lines):
             if all(i + k < len(lines) and lines[i + k].startswith("ds_read_b128") for k in range(3)):
@@ -48,6 +51,17 @@ def check() -> int:
                     a, b = re.search(r"v\[(\d+):(\d+)\]", l).groups()
                     dest |= set(range(int(a), int(b) + 1))
                 groups += 1
+                # the step loop: from the target of the first backward branch after the loads to that branch
+                for e in range(i, len(lines)):
+                    m = re.match(r"s_cbranch_\w+\s+(\.LBB\w+)", lines[e])
+                    if m and label_at.get(m.group(1), len(lines)) <= i:
+                        in_loop = [l for l in lines[label_at[m.group(1)]:e] if l.startswith("scratch_")]
+                        if in_loop:
+                            spills += 1
+                            print(f"SCRATCH IN THE STEP LOOP of {name}: {in_loop[:3]}")
+                        break
+                else:
+                    raise AssertionError("step loop not found")
                 j = i + 3
                 # a wait fewer than MIN_COVER instructions after the loads was put there by the compiler (a pending LDS
                 # result from before the loop, WAW on one of its registers): correct, but the LDS latency is then exposed
@@ -68,8 +82,8 @@ def check() -> int:
                 i = j
             else:
                 i += 1
-    print(f"{len(kernels)} kernels, {groups} load groups, {hazards} hazards, {early} early waits")
-    return 1 if hazards or early or groups < len(kernels) else 0
+    print(f"{len(kernels)} kernels, {groups} load groups, {hazards} hazards, {early} early waits, {spills} step loops with scratch accesses")
+    return 1 if hazards or early or spills or groups < len(kernels) else 0
 
 
 if __name__ == "__main__":
