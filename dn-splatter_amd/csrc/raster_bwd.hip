@@ -53,6 +53,13 @@ constexpr int TILE = 16;
 // drain at 39 % occupancy (tools/bwd_timeline.sh): the end of the kernel lasts about one unit.  Half tiles make the units half as
 // long (and the rectangle cull and the per-pixel list bound tighter), at the price of 15 idle slots per 128 instead of per 256
 // stream steps and two atomic rows per (tile, splat).
+// What is left of that drain (tools/bwd_timeline.sh, C2: 16200 units of 501 +- 6 % steps, ~4 per resident wave; the chip is full
+// for 1.34 ms and empties over the last 0.38 ms) is NOT idle capacity: a unit that runs with one or two waves on its SIMD takes
+// ~200 us instead of ~380 us, i.e. two waves already keep a SIMD's vector unit about as busy as four.  Two attempts to "repair"
+// the tail confirmed it and were removed again: (a) as many persistent waves as the chip holds, each walking the units with a
+// fixed stride: +10 % (the waves of a SIMD are not served evenly — some finish four units while others finish two — so a fixed
+// assignment only moves the imbalance); (b) cutting the last 10-27 % of the units into 2-3 pieces over pixel windows so that the
+// drain lasts one piece: -0.5 % ... +5 % (a piece costs max(64, pixels + 15) steps per bucket).
 #ifndef DNS_BWD_ROWS
 #define DNS_BWD_ROWS 8
 #endif
@@ -242,10 +249,11 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
     if (range_end <= range_start) return;
     [[maybe_unused]] unsigned long long n_slots = 0, n_pairs = 0;
 #ifdef DNS_BWD_TIMELINE
-    // instrumented build (tools/bwd_timeline.sh): per work unit (start, end) of the 100 MHz wall clock and the list depth, written
+    // instrumented build (tools/bwd_timeline.sh): per work unit (start, end) of the 100 MHz wall clock, its work and where it ran, written
     // through the v_alphas pointer, which the fused (DN) pass does not use
     unsigned long long *dbg_tl = DN ? (unsigned long long *)a.v_alphas : nullptr;
     const unsigned long long tl_t0 = wall_clock64();
+    unsigned long long tl_steps = 0, tl_splats = 0;
 #endif
     const int tile_x0 = (tile % a.tw) * TILE, tile_y0 = (tile / a.tw) * TILE + part * ROWS;
     const int split = SPLIT >= 0 ? SPLIT : a.xy_split;
@@ -684,6 +692,9 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
             }
             };
             if (COUNT) n_slots += (unsigned long long)nsteps * BUCKET;
+#ifdef DNS_BWD_TIMELINE
+            tl_steps += nsteps; if (grp == 0) tl_splats += take;
+#endif
 #if DNS_BWD_CLAMP_MODE == 1
             step_loop(std::true_type{});
 #else
@@ -697,9 +708,12 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
     if (COUNT && lane == 0 && a.counters) { atomicAdd(a.counters + 4, n_slots); atomicAdd(a.counters + 5, n_pairs); }
 #ifdef DNS_BWD_TIMELINE
     if (dbg_tl && lane == 0) {
-        dbg_tl[3 * blockIdx.x] = tl_t0;
-        dbg_tl[3 * blockIdx.x + 1] = wall_clock64();
-        dbg_tl[3 * blockIdx.x + 2] = (unsigned long long)(hi - range_start + 1);
+        dbg_tl[4 * blockIdx.x] = tl_t0;
+        dbg_tl[4 * blockIdx.x + 1] = wall_clock64();
+        // list depth (20 bits) | steps streamed (20 bits) | splats in the buckets (20 bits)
+        dbg_tl[4 * blockIdx.x + 2] = (unsigned long long)(hi - range_start + 1) | (tl_steps << 20) | (tl_splats << 40);
+        // where it ran: HW_ID (wave, simd, pipe, cu, sh, se) and the XCC
+        dbg_tl[4 * blockIdx.x + 3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
     }
 #endif
 }
