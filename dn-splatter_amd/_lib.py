@@ -18,7 +18,7 @@ _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["DNSPLAT_LIB"]).resolve() if os.environ.get("DNSPLAT_LIB") else _PKG_DIR / "libdnsplat.so"
 CSRC_DIR = _PKG_DIR / "csrc"
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 RECORD_FLOATS = 16
 MAX_CHANNELS = 8
 
@@ -44,7 +44,7 @@ class Camera(ctypes.Structure):
         ("viewmat", c_void_p), ("K", c_void_p), ("normal_frame", c_void_p),
         ("width", c_int32), ("height", c_int32), ("tile_size", c_int32),
         ("eps2d", c_float), ("near_plane", c_float), ("far_plane", c_float), ("radius_clip", c_float),
-        ("antialiased", c_int32),
+        ("antialiased", c_int32), ("tight_tiles", c_int32),
     ]
 
 
@@ -65,6 +65,7 @@ class BinArgs(ctypes.Structure):
         ("flatten_ids", c_void_p), ("tile_offsets", c_void_p),
         ("n_isects", c_void_p), ("n_isects_host", c_void_p),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("splats", c_void_p), ("tight_tiles", c_int32),
     ]
 
 

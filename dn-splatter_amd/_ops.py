@@ -65,6 +65,7 @@ class ProjCfg:
     with_depth: bool = False
     with_normals: bool = False
     want_normals_world: bool = False
+    tight_tiles: bool = False    # dnsplat_camera.tight_tiles: tile counts over the alpha >= 1/255 box instead of gsplat's 3-sigma box
 
     @property
     def tiles(self):
@@ -175,6 +176,7 @@ def _camera_struct(viewmat, K, normal_frame, cfg: ProjCfg):
     c.width, c.height, c.tile_size = cfg.width, cfg.height, cfg.tile_size
     c.eps2d, c.near_plane, c.far_plane, c.radius_clip = cfg.eps2d, cfg.near_plane, cfg.far_plane, cfg.radius_clip
     c.antialiased = int(cfg.antialiased)
+    c.tight_tiles = int(cfg.tight_tiles)
     return c
 
 
@@ -368,7 +370,7 @@ class Binning:
 
 
 def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, width: int, height: int,
-              tile_size: int, after_emit=None, n_cameras: int = 1) -> Binning:
+              tile_size: int, after_emit=None, n_cameras: int = 1, tight_splats: Optional[Tensor] = None) -> Binning:
     """Stage 2 over ``n_cameras`` stacked projections (inputs flattened to [C*N, ...]).  ``after_emit(binning)`` (optional)
     is called right after the emit/sort kernels are enqueued and BEFORE any host wait, so the caller can queue the
     compositing kernel behind them; in "capacity" mode it is called again if the capacity guess turned out too small."""
@@ -391,6 +393,8 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
         a.flatten_ids, a.tile_offsets = _ptr(flatten_ids), _ptr(tile_offsets)
         a.n_isects, a.n_isects_host = _ptr(n_dev), ctypes.c_void_p(n_host.data_ptr())
         a.workspace, a.workspace_bytes = _ptr(ws), ws.numel()
+        # ``tiles`` were counted over the tight boxes (ProjCfg.tight_tiles): the emit kernel rebuilds them from the records
+        a.splats, a.tight_tiles = _ptr(tight_splats), int(tight_splats is not None)
         return a, ws
 
     tile_offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
@@ -536,6 +540,10 @@ def rasterize(means2d, splats, depths, radii, tiles, *, background=None, width, 
 # The fused pass hands the forward's per-half-tile rectangle-test results to the backward (dnsplat_raster_args.keep_masks);
 # DNSPLAT_KEEP_MASKS=0 makes the backward re-derive them (kernel A/B runs).
 KEEP_MASKS = os.environ.get("DNSPLAT_KEEP_MASKS", "1") != "0"
+# The fused get_outputs path keeps its tile lists to itself, so it bins over the tight tile boxes (dnsplat_camera.tight_tiles:
+# ~1/3 fewer intersections on the benchmark scenes, same images and gradients).  DNSPLAT_TIGHT_TILES=0 (or setting this to
+# False) makes it use gsplat's boxes, as the drop-in calls always do.
+TIGHT_TILES = os.environ.get("DNSPLAT_TIGHT_TILES", "1") != "0"
 
 # Measurement hook (bench.py's VALU roofline): a uint64 [8] device tensor makes the fused pass run the COUNTING instantiation of
 # both compositing kernels, which tally list entries / splats walked / pairs evaluated / pairs blended / slots issued.
@@ -562,6 +570,7 @@ class _RasterDnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, splats, depths, radii, tiles, bg_rgb, width, height, intr, absgrad, holder):
         dev = splats.device
+        tight = bool(holder is not None and holder.get("tight_tiles"))
         C = means2d.shape[0]                     # cameras of the batch; intr = [(fx, fy, cx, cy)] * C
         f32 = dict(dtype=torch.float32, device=dev)
         render = torch.empty(C, height, width, 7, **f32)
@@ -603,7 +612,7 @@ class _RasterDnFn(torch.autograd.Function):
             _lib.run("dnsplat_raster_fwd", _lib.lib().dnsplat_raster_fwd, ctypes.byref(a), _stream())
 
         b = bin_tiles(means2d.detach().reshape(-1, 2), radii.reshape(-1), depths.detach().reshape(-1), tiles.reshape(-1), width,
-                      height, 16, after_emit=composite, n_cameras=C)
+                      height, 16, after_emit=composite, n_cameras=C, tight_splats=splats.detach() if tight else None)
         for c in range(C):
             fx, fy, cx, cy = intr[c]
             _lib.run("dnsplat_dn_depth_normals", _lib.lib().dnsplat_dn_depth_normals, width, height, fx, fy, cx, cy,

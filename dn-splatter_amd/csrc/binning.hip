@@ -441,7 +441,8 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int n_per_cam, const u
                                                    const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                                                    int tile_size, int tw, int th, uint32_t cap,
                                                    K *__restrict__ tkeys, uint32_t *__restrict__ tvals,
-                                                   uint32_t *__restrict__ lb_ctl = nullptr, int lb_ctl_words = 0)
+                                                   uint32_t *__restrict__ lb_ctl = nullptr, int lb_ctl_words = 0,
+                                                   const float4 *__restrict__ splats = nullptr)
 {
     // the look-back control words (digit totals, tickets, failure flag) of the tile passes that follow start at zero
     if (lb_ctl && blockIdx.x == 0)
@@ -456,7 +457,11 @@ __global__ __launch_bounds__(256) void emit_kernel(int N, int n_per_cam, const u
         start = (j == 0) ? 0u : cum[j - 1];
         if (end > start) {
             int x1, y1;
-            dns_tile_bbox(means2d[2 * gid], means2d[2 * gid + 1], (float)radii[gid], tile_size, tw, th, x0, y0, x1, y1);
+            if (splats) {      // tight tile boxes (dnsplat_bin_args.tight_tiles): the box the projection kernel counted
+                const float4 r0 = splats[(size_t)gid * 4], r1 = splats[(size_t)gid * 4 + 1];
+                dns_snug_tile_bbox(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, (float)radii[gid], tile_size, tw, th, x0, y0, x1, y1);
+            } else
+                dns_tile_bbox(means2d[2 * gid], means2d[2 * gid + 1], (float)radii[gid], tile_size, tw, th, x0, y0, x1, y1);
             bw = x1 - x0;
             // batch of cameras: entry gid belongs to camera gid / n_per_cam, whose tile grid is stacked below the previous
             // cameras' (tile id = camera * tw * th + row * tw + column) — folded into the first tile row of the box
@@ -658,7 +663,8 @@ void emit_and_sort(hipStream_t stream, const dnsplat_bin_args *a, const BinWs &w
 #if DNS_BIN_LOOKBACK
     {
         hipLaunchKernelGGL(emit_kernel<K>, dim3((a->N + 255) / 256), dim3(256), 0, stream, a->N, a->N / n_cam, w.val_a, w.cum,
-                           a->means2d, a->radii, a->tile_size, tw, th, cap, ka, va, w.lb_ctl, LB_CTL_WORDS);
+                           a->means2d, a->radii, a->tile_size, tw, th, cap, ka, va, w.lb_ctl, LB_CTL_WORDS,
+                           a->tight_tiles ? reinterpret_cast<const float4 *>(a->splats) : nullptr);
         int dbits[3] = {0, 0, 0}, shifts[3] = {0, 0, 0};
         size_t desc_off[4] = {0, 0, 0, 0};
         for (int pass = 0, sh = 0; pass < passes; ++pass) {
@@ -700,7 +706,8 @@ void emit_and_sort(hipStream_t stream, const dnsplat_bin_args *a, const BinWs &w
     }
 #endif
     hipLaunchKernelGGL(emit_kernel<K>, dim3((a->N + 255) / 256), dim3(256), 0, stream, a->N, a->N / n_cam, w.val_a, w.cum,
-                       a->means2d, a->radii, a->tile_size, tw, th, cap, ka, va, w.lb_ctl, LB_CTL_WORDS);   // status word := 0
+                       a->means2d, a->radii, a->tile_size, tw, th, cap, ka, va, w.lb_ctl, LB_CTL_WORDS,
+                       a->tight_tiles ? reinterpret_cast<const float4 *>(a->splats) : nullptr);   // status word := 0
     int shift = 0;
     for (int pass = 0; pass < passes; ++pass) {
         const int dbits = (bits - shift + (passes - pass) - 1) / (passes - pass);   // 13 bits -> 7 + 6
@@ -790,6 +797,7 @@ extern "C" int dnsplat_bin_emit_sort(const dnsplat_bin_args *a, dnsplat_stream_t
     int rc = check_bin(a);
     if (rc != DNSPLAT_OK) return rc;
     if (!a->tile_offsets || (a->isect_capacity > 0 && !a->flatten_ids)) return DNSPLAT_ERR_INVALID_ARG;
+    if (a->tight_tiles && !a->splats && a->N > 0) return DNSPLAT_ERR_INVALID_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     BinWs w = carve(a->workspace, a->N, a->isect_capacity);
     const int tw = dns_tiles_w(a->width, a->tile_size), th = dns_tiles_h(a->height, a->tile_size);

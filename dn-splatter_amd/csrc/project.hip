@@ -393,8 +393,13 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(FwdParams p)
 
     const int tw = (p.c.width + p.c.tile_size - 1) / p.c.tile_size;
     const int th = (p.c.height + p.c.tile_size - 1) / p.c.tile_size;
+    if (p.c.antialiased) opac *= st.compensation;
     int x0, y0, x1, y1;
-    dns_tile_bbox(st.mean2d[0], st.mean2d[1], st.radius, p.c.tile_size, tw, th, x0, y0, x1, y1);
+    if (p.c.tight_tiles)
+        dns_snug_tile_bbox(st.mean2d[0], st.mean2d[1], st.conic[0], st.conic[1], st.conic[2], opac, st.radius, p.c.tile_size, tw, th,
+                           x0, y0, x1, y1);
+    else
+        dns_tile_bbox(st.mean2d[0], st.mean2d[1], st.radius, p.c.tile_size, tw, th, x0, y0, x1, y1);
 
     p.o.radii[g] = (int32_t)st.radius;
     p.o.means2d[2 * g] = st.mean2d[0]; p.o.means2d[2 * g + 1] = st.mean2d[1];
@@ -402,7 +407,6 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(FwdParams p)
     p.o.conics[3 * g] = st.conic[0]; p.o.conics[3 * g + 1] = st.conic[1]; p.o.conics[3 * g + 2] = st.conic[2];
     if (p.o.compensations) p.o.compensations[g] = st.compensation;
     p.o.tiles_per_gauss[g] = (y1 - y0) * (x1 - x0);
-    if (p.c.antialiased) opac *= st.compensation;
 
     float r[DNS_REC];
 #pragma unroll

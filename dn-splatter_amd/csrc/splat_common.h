@@ -53,6 +53,36 @@ __device__ __forceinline__ void dns_tile_bbox(float mx, float my, float radius, 
     x0 = (int)fx0; y0 = (int)fy0; x1 = (int)fx1; y1 = (int)fy1;
 }
 
+// Tile box of the part of a splat that can reach alpha >= 1/255 at some pixel centre (the "SnugBox" of Speedy-Splat): the
+// axis-aligned box of the ellipse  sigma(d) = 1/2 d^T conic d <= ln(255 opacity), widened by a rounding margin and clipped to
+// gsplat's 3-sigma box (dns_tile_bbox).  Every (tile, splat) pair it leaves out fails the per-pixel alpha test at all 256 pixel
+// centres of the tile, so the images and gradients composited from the shorter lists are the same numbers; the tile lists
+// themselves are NOT gsplat's any more, which is why only the fused get_outputs path (whose lists are internal) asks for it.
+// Evaluated by the projection kernel (tile counts) and by the emit kernel (tile pairs) from the same record floats: contraction
+// is pinned off so that both translation units round identically.
+__device__ __forceinline__ void dns_snug_tile_bbox(float mx, float my, float ca, float cb, float cc, float opac, float radius,
+                                                   int tile_size, int tw, int th, int &x0, int &y0, int &x1, int &y1)
+{
+#pragma clang fp contract(off)
+    dns_tile_bbox(mx, my, radius, tile_size, tw, th, x0, y0, x1, y1);
+    const float tau = logf(255.f * opac);          // alpha = opacity exp(-sigma) >= 1/255  <=>  sigma <= tau
+    if (!(tau > 0.f)) { x1 = x0; y1 = y0; return; }   // opacity <= 1/255: never composited
+    const float det = ca * cc - cb * cb;
+    if (!(det > 0.f)) return;                       // degenerate conic: keep gsplat's box
+    // half widths sqrt(2 tau Sigma_xx), sqrt(2 tau Sigma_yy) with Sigma = conic^-1; `rel` covers the cancellation in det
+    const float s = 2.f * tau / det;
+    const float rel = 1e-4f + 2.4e-7f * ((ca * cc + cb * cb) / det);
+    const float hx = sqrtf(s * cc) * (1.f + rel) + 0.01f, hy = sqrtf(s * ca) * (1.f + rel) + 0.01f;
+    const float ts = (float)tile_size;
+    // tile column t holds the pixel centres t ts + 0.5 ... t ts + ts - 0.5
+    const float fx0 = fminf(fmaxf(ceilf((mx - hx - (ts - 0.5f)) / ts), 0.f), (float)tw);
+    const float fx1 = fminf(fmaxf(floorf((mx + hx - 0.5f) / ts) + 1.f, 0.f), (float)tw);
+    const float fy0 = fminf(fmaxf(ceilf((my - hy - (ts - 0.5f)) / ts), 0.f), (float)th);
+    const float fy1 = fminf(fmaxf(floorf((my + hy - 0.5f) / ts) + 1.f, 0.f), (float)th);
+    x0 = max(x0, (int)fx0); x1 = max(min(x1, (int)fx1), x0);
+    y0 = max(y0, (int)fy0); y1 = max(min(y1, (int)fy1), y0);
+}
+
 // XCD-aware block remap (guide §5.5 T1): hardware places block b on XCD b % 8.  Give every XCD one
 // contiguous band of work ids so that neighbouring tiles — which share most of their splats —
 // hit the same 4 MiB L2.  Bijective for any grid size.

@@ -134,10 +134,10 @@ def _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest
     C = viewmats.shape[0]
     cfg = ProjCfg(width=width, height=height, tile_size=16, eps2d=eps2d, near_plane=near_plane, far_plane=far_plane,
                   antialiased=False, scales_are_log=True, opacities_are_logit=True, sh_degree=int(sh_degree),
-                  with_depth=True, with_normals=True, want_normals_world=True)
+                  with_depth=True, with_normals=True, want_normals_world=True, tight_tiles=_ops.TIGHT_TILES)
     pr = _ops.project(means, quats, scales, opacities.reshape(N), sh0=features_dc, shN=features_rest, viewmat=viewmats,
                       K=Ks, normal_frame=nfs, cfg=cfg)
-    holder: Dict = {}
+    holder: Dict = {"tight_tiles": cfg.tight_tiles}      # the tile lists of this path are internal: tight tile boxes
     if pair_counters is not None:
         holder["pair_counters"] = pair_counters
     rgb, depth, normal, acc, surface_normal = _ops.rasterize_dn(
@@ -149,6 +149,6 @@ def _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest
         "tiles_per_gauss": pr["tiles_per_gauss"], "normals_world": pr["normals_world"][-1],      # dn_model.py:558 keeps the last camera's
         "flatten_ids": b.flatten_ids[: b.n_isects], "isect_offsets": b.tile_offsets[:-1].reshape(C, b.tile_height, b.tile_width),
         "n_isects": b.n_isects, "tile_width": b.tile_width, "tile_height": b.tile_height,
-        "width": width, "height": height, "tile_size": 16, "n_cameras": C, "_binning": b,
+        "width": width, "height": height, "tile_size": 16, "n_cameras": C, "_binning": b, "tight_tiles": cfg.tight_tiles,
     }
     return {"rgb": rgb, "depth": depth, "normal": normal, "surface_normal": surface_normal, "accumulation": acc}, info

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DNSPLAT_ABI_VERSION 5
+#define DNSPLAT_ABI_VERSION 6
 #define DNSPLAT_RECORD_FLOATS 16
 #define DNSPLAT_MAX_CHANNELS 8
 
@@ -91,6 +91,10 @@ typedef struct dnsplat_camera {
     int32_t width, height, tile_size;
     float eps2d, near_plane, far_plane, radius_clip;
     int32_t antialiased;       /* rasterize_mode == "antialiased": opacity *= compensation */
+    int32_t tight_tiles;       /* 0: tiles_per_gauss counts gsplat's 3-sigma tile box (A.3, what the drop-in calls return).
+                                  1: the box of the part of the splat that can reach alpha >= 1/255 at a pixel centre, clipped
+                                  to gsplat's box — shorter tile lists, same images and gradients; for callers that keep the
+                                  lists to themselves (the fused get_outputs path).  dnsplat_bin_args.tight_tiles must match. */
 } dnsplat_camera;
 
 typedef struct dnsplat_proj_out {
@@ -145,6 +149,8 @@ typedef struct dnsplat_bin_args {
     int64_t *n_isects_host;          /* optional pinned host mirror, written by an async D2H copy; NULL to skip */
     void *workspace;
     size_t workspace_bytes;
+    const float *splats;             /* [N,16] records of stage 1; read only when tight_tiles != 0 */
+    int32_t tight_tiles;             /* as dnsplat_camera.tight_tiles of the projection that produced tiles_per_gauss */
 } dnsplat_bin_args;
 
 /* 2a: depth sort + inclusive offsets + total.  After this (and a stream sync or

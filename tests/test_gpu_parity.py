@@ -179,7 +179,6 @@ def _check_mirror(hip, ora, keep, what="mirror", quat_atol=0.0, ints=True):
         r_g, r_o = m_g.radii.cpu(), m_o.radii
         t_g, t_o = m_g.num_tiles_hit.reshape(-1).cpu(), m_o.num_tiles_hit.reshape(-1)
         assert_equal_int(r_g[solid], r_o[solid], what + " radii")
-        assert_equal_int(t_g[solid], t_o[solid], what + " num_tiles_hit")
         assert int(((r_g[edge] - r_o[edge]).abs() > 1).sum()) == 0 or bool(((r_g[edge] == 0) | (r_o[edge] == 0)).any())
         lists = []
         for m in (m_g, m_o):
@@ -187,9 +186,49 @@ def _check_mirror(hip, ora, keep, what="mirror", quat_atol=0.0, ints=True):
             offs = torch.cat([m.last_info["isect_offsets"].reshape(-1).cpu().long(), torch.tensor([fid.numel()])])
             tile_of = torch.searchsorted(offs, torch.arange(fid.numel()), right=True) - 1
             sel = solid[fid]
-            lists.append((fid[sel], torch.bincount(tile_of[sel], minlength=offs.numel() - 1)))
-        assert_equal_int(lists[0][0], lists[1][0], what + " flatten_ids (rounding-sensitive Gaussians taken out)")
-        assert_equal_int(lists[0][1], lists[1][1], what + " tile list lengths (rounding-sensitive Gaussians taken out)")
+            lists.append((fid[sel], tile_of[sel], offs.numel() - 1))
+        (fid_g, tile_g, n_t), (fid_o, tile_o, _) = lists
+        if m_g.last_info.get("tight_tiles"):
+            # The fused path bins over the tight tile boxes (dnsplat_camera.tight_tiles): its lists are the reference's lists with
+            # the pairs taken out whose splat cannot reach alpha >= 1/255 at any pixel centre of the tile.  Checked here: they are
+            # an order-preserving sub-list of the oracle's, and every pair left out has min sigma over the tile's pixel-centre
+            # rectangle >= ln(255 opacity) (float64, closed form), i.e. the per-pixel test of A.5 rejects it at all 256 pixels.
+            N_ = solid.numel()
+            key_g, key_o = tile_g * N_ + fid_g, tile_o * N_ + fid_o
+            kept = torch.isin(key_o, key_g)
+            assert_equal_int(fid_o[kept], fid_g, what + " tight tile lists are an order-preserving sub-list of the reference's")
+            assert_equal_int(tile_o[kept], tile_g, what + " tight tile lists: tiles")
+            assert (t_g[solid] <= t_o[solid]).all()
+            gone_t, gone_g = tile_o[~kept], fid_o[~kept]
+            info_o = m_o.last_info
+            tw_ = int(info_o["tile_width"]) if "tile_width" in info_o else int(info_o["isect_offsets"].shape[-1])
+            xy = info_o["means2d"].detach().reshape(-1, 2).double()[gone_g]
+            con = info_o["conics"].detach().reshape(-1, 3).double()[gone_g]
+            opa = torch.sigmoid(p_o["opacities"].detach().double()).reshape(-1)[gone_g]
+            tx, ty = (gone_t % tw_).double(), (gone_t // tw_).double()
+            # d = pixel centre - mean, over [lo, hi] per axis; convex quadratic: the minimum over the rectangle is at the clamped
+            # centre if the unconstrained minimum (d = 0) is inside, else on one of the four edges (1-D minima, clamped)
+            lox, hix = tx * 16 + 0.5 - xy[:, 0], tx * 16 + 15.5 - xy[:, 0]
+            loy, hiy = ty * 16 + 0.5 - xy[:, 1], ty * 16 + 15.5 - xy[:, 1]
+            a_, b_, c_ = con[:, 0], con[:, 1], con[:, 2]
+            sig = lambda dx, dy: 0.5 * (a_ * dx * dx + c_ * dy * dy) + b_ * dx * dy
+            cands = [sig(torch.minimum(torch.maximum(torch.zeros_like(lox), lox), hix), torch.minimum(torch.maximum(torch.zeros_like(loy), loy), hiy))]
+            for dx in (lox, hix):
+                cands.append(sig(dx, torch.minimum(torch.maximum(-b_ * dx / c_, loy), hiy)))
+            for dy in (loy, hiy):
+                cands.append(sig(torch.minimum(torch.maximum(-b_ * dy / a_, lox), hix), dy))
+            inside = (lox <= 0) & (hix >= 0) & (loy <= 0) & (hiy >= 0)
+            smin = torch.where(inside, torch.zeros_like(lox), torch.stack(cands[1:]).min(0).values)
+            tau = torch.log(255.0 * opa)
+            bad = smin < tau - 1e-9
+            print(f"[parity] {what}: tight tile boxes keep {int(kept.sum())} of {kept.numel()} list entries ({100.0 * float(kept.sum()) / max(kept.numel(), 1):.1f} %)")
+            assert not bool(bad.any()), f"{what}: {int(bad.sum())} of {bad.numel()} pairs left out of the tight lists could reach alpha >= 1/255"
+            assert float(kept.sum()) < 0.95 * kept.numel() or kept.numel() < 1000, "tight tile boxes removed next to nothing"
+        else:
+            assert_equal_int(t_g[solid], t_o[solid], what + " num_tiles_hit")
+            assert_equal_int(fid_g, fid_o, what + " flatten_ids (rounding-sensitive Gaussians taken out)")
+            assert_equal_int(torch.bincount(tile_g, minlength=n_t), torch.bincount(tile_o, minlength=n_t),
+                             what + " tile list lengths (rounding-sensitive Gaussians taken out)")
     for k in OUT_KEYS:
         assert out_g[k].shape == out_o[k].shape
         assert_close(out_g[k], out_o[k], what + " " + k, keep=keep)
@@ -482,7 +521,10 @@ def test_get_outputs_mirror_matches_reference_sequence(dns, orc, mode):
     assert set(out_g) == {"rgb", "depth", "normal", "surface_normal", "accumulation", "background"}
     _check_mirror(hip, ora, keep, "mirror " + mode, ints=False)
     assert_equal_int(m_g.radii, m_o.radii, "radii")
-    assert_equal_int(m_g.num_tiles_hit.reshape(-1), m_o.num_tiles_hit.reshape(-1), "num_tiles_hit")
+    if m_g.last_info.get("tight_tiles"):      # the fused path counts the tiles of its tight boxes (dnsplat_camera.tight_tiles)
+        assert bool((m_g.num_tiles_hit.reshape(-1).cpu() <= m_o.num_tiles_hit.reshape(-1)).all())
+    else:
+        assert_equal_int(m_g.num_tiles_hit.reshape(-1), m_o.num_tiles_hit.reshape(-1), "num_tiles_hit")
     # surface_normal is a finite-difference stencil of the depth image: depth noise is amplified by ~fx/d, so it
     # is compared on the 99.9 % quantile of the error; the border must be exactly the reference's 0.5
     d_sn = (out_g["surface_normal"].detach().cpu() - out_o["surface_normal"].detach()).abs().reshape(-1)
@@ -1012,7 +1054,7 @@ def test_c2_full_frame_fused_pass_matches_oracle(dns, orc):
     gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=0)
     cam = synthetic.orbit_camera(0, width=W, height=H)
     hip, ora, keep = _mirror_pair(dns, orc, gp, cam, dict(fused=True), cot_seed=1, what="C2 full frame")
-    assert hip[2].last_info["n_isects"] > 20_000_000
+    assert hip[2].last_info["n_isects"] > 12_000_000      # tight tile boxes; 21 M with gsplat's
     assert float(hip[0]["accumulation"].min()) > 0.999                # every pixel saturates, as in the benchmark
     _check_mirror(hip, ora, keep, "C2 full frame", quat_atol=1e-4)    # isotropic init: d/d(quats) is rounding noise
 
@@ -1091,7 +1133,10 @@ def test_full_size_binning_properties(dns, full_scene):
     n = info["n_isects"]
     tiles = info["tiles_per_gauss"][0].long()
     assert int(tiles.sum()) == n, "sum(tiles_per_gauss) != n_isects"
-    assert int(((info["radii"][0] > 0) != (tiles > 0)).sum()) == 0
+    if info.get("tight_tiles"):     # a visible Gaussian may reach alpha >= 1/255 at no pixel centre at all
+        assert int(((tiles > 0) & ~(info["radii"][0] > 0)).sum()) == 0
+    else:
+        assert int(((info["radii"][0] > 0) != (tiles > 0)).sum()) == 0
     offs = info["isect_offsets"].reshape(-1).long()
     assert int(offs[0]) == 0 and bool((offs[1:] >= offs[:-1]).all()) and int(offs[-1]) <= n
     # every tile list is depth-sorted, ties broken by Gaussian index (stable sort, Appendix A.3)
@@ -1147,3 +1192,44 @@ def test_full_size_image_properties_and_linearity(dns, full_scene):
     if bool(hidden.any()):
         for name, c in zip(names, g12):
             assert float(c[hidden].abs().max()) == 0.0, name
+
+
+def test_tight_tile_boxes_change_the_lists_not_the_images(dns):
+    """dnsplat_camera.tight_tiles (the fused path's default): fewer (tile, Gaussian) pairs, the same composited numbers —
+    forward images bit for bit (the pairs left out were skipped at every pixel anyway, the others are blended in the same
+    order), gradients up to the order of the atomic sums."""
+    from dn_splatter_amd import _ops, synthetic
+
+    N, W, H = 20_000, 320, 240
+    gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=5, device=DEV)
+    g_ = torch.Generator().manual_seed(31)
+    gp["scales"] = (gp["scales"].detach() + (torch.randn(N, 3, generator=g_) * 0.6).to(DEV)).requires_grad_(True)
+    gp["opacities"] = (gp["opacities"].detach() + (torch.randn(N, 1, generator=g_) * 2.0).to(DEV)).requires_grad_(True)
+    cam = synthetic.orbit_camera(2, width=W, height=H, focal=200.0).to(DEV)
+    keys = ("rgb", "depth", "normal", "accumulation")
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    cot = None
+    res = {}
+    old = _ops.TIGHT_TILES
+    try:
+        for tight in (False, True):
+            _ops.TIGHT_TILES = tight
+            for v in gp.values():
+                v.grad = None
+            r = dns.DNSplatterRenderer(gp, fused=True)
+            out = r.get_outputs(cam)
+            assert bool(r.last_info.get("tight_tiles")) == tight
+            if cot is None:
+                cot = [torch.rand(out[k].shape, device=DEV, generator=gen) * 2 - 1 for k in keys]
+            torch.autograd.backward([out[k] for k in keys], cot)
+            res[tight] = ({k: out[k].detach().clone() for k in keys}, {k: v.grad.clone() for k, v in gp.items() if v.grad is not None},
+                          int(r.last_info["n_isects"]), r.last_info["tiles_per_gauss"].clone(), r.radii.clone())
+    finally:
+        _ops.TIGHT_TILES = old
+    (o0, g0, n0, t0, r0), (o1, g1, n1, t1, r1) = res[False], res[True]
+    print(f"[parity] tight tile boxes: {n1} of {n0} intersections ({100.0 * n1 / n0:.1f} %)")
+    assert n1 < 0.9 * n0 and bool((t1 <= t0).all()) and torch.equal(r0, r1)
+    for k in keys:
+        assert torch.equal(o0[k], o1[k]), k
+    for k in g0:
+        assert_close(g1[k], g0[k], "tight vs gsplat boxes: grad " + k, tol=2e-6)
