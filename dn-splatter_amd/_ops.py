@@ -485,8 +485,9 @@ class _RasterFn(torch.autograd.Function):
             a.render, a.alphas, a.last_ids = _ptr(render), _ptr(alphas), _ptr(last_ids)
             _lib.run("dnsplat_raster_fwd", _lib.lib().dnsplat_raster_fwd, ctypes.byref(a), _stream())
 
+        tight = bool(holder is not None and holder.get("tight_tiles"))      # ``tiles`` were counted over the tight boxes
         b = bin_tiles(means2d.detach().reshape(-1, 2), radii.reshape(-1), depths.detach().reshape(-1), tiles.reshape(-1), width,
-                      height, tile_size, after_emit=composite, n_cameras=C)
+                      height, tile_size, after_emit=composite, n_cameras=C, tight_splats=splats.detach() if tight else None)
         if holder is not None:
             holder["binning"] = b
         ctx.save_for_backward(means2d, splats, b.flatten_ids, b.tile_offsets, render, alphas, last_ids)

@@ -69,14 +69,14 @@ def render_dn(
     cfg = ProjCfg(width=width, height=height, tile_size=16, eps2d=eps2d, near_plane=near_plane, far_plane=far_plane,
                   antialiased=(rasterize_mode == "antialiased"), scales_are_log=not activated,
                   opacities_are_logit=not activated, sh_degree=int(sh_degree), with_depth=True,
-                  with_normals=predict_normals, want_normals_world=predict_normals)
+                  with_normals=predict_normals, want_normals_world=predict_normals, tight_tiles=_ops.TIGHT_TILES)
     nf = normal_frame_from_c2w(camera_to_world).to(means.device) if predict_normals else None
     pr = _ops.project(means, quats, scales, opacities.reshape(N), sh0=features_dc, shN=features_rest,
                       viewmat=viewmat, K=K, normal_frame=nf, cfg=cfg)
     bg = None
     if predict_normals:
         bg = torch.tensor([0.0, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0], device=means.device)
-    holder: Dict = {}
+    holder: Dict = {"tight_tiles": cfg.tight_tiles}      # the tile lists of this path are internal: tight tile boxes
     out, alphas = _ops.rasterize(pr["means2d"], pr["splats"], pr["depths"], pr["radii"], pr["tiles_per_gauss"],
                                  background=bg, width=width, height=height, tile_size=16, D=D, ed_channel=3,
                                  xy_split=4, absgrad=absgrad, holder=holder)
@@ -86,7 +86,7 @@ def render_dn(
         "tiles_per_gauss": pr["tiles_per_gauss"], "normals_world": None if pr["normals_world"] is None else pr["normals_world"][-1],
         "flatten_ids": b.flatten_ids[: b.n_isects], "isect_offsets": b.tile_offsets[:-1].reshape(1, b.tile_height, b.tile_width),
         "n_isects": b.n_isects, "tile_width": b.tile_width, "tile_height": b.tile_height,
-        "width": width, "height": height, "tile_size": 16, "n_cameras": 1,
+        "width": width, "height": height, "tile_size": 16, "n_cameras": 1, "tight_tiles": cfg.tight_tiles,
     }
     out, alphas = out.squeeze(0), alphas.squeeze(0)
     normals = out[..., 4:7] if predict_normals else None
