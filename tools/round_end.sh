@@ -8,8 +8,8 @@ echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q > $O/pyte
 echo "== PMC traffic (FETCH_SIZE / WRITE_SIZE in separate passes) for c2, c3, c5"
 for w in c2 c3 c5; do
   rm -rf gpurun_out/pmc_traffic; mkdir -p gpurun_out/pmc_traffic
-  BENCH_ARGS="--workload $w" bash tools/pmc_traffic.sh > $O/pmc_traffic_$w.log 2>&1
-  python tools/pmc_traffic.py gpurun_out/pmc_traffic/summary.json $w > /dev/null && cp gpurun_out/pmc_traffic/pmc_traffic.merged.json $O/pmc_traffic.merged.json
+  WORKLOAD=$w BENCH_ARGS="--workload $w" bash tools/pmc_traffic.sh > $O/pmc_traffic_$w.log 2>&1
+  cp gpurun_out/pmc_traffic/pmc_traffic.merged.json $O/pmc_traffic.merged.json
   cp gpurun_out/pmc_traffic/summary.json $O/pmc_traffic_summary_$w.json
 done
 python - <<'PY'
