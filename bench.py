@@ -251,8 +251,16 @@ def main():
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     q = lambda f: round(per_step[min(len(per_step) - 1, int(f * len(per_step)))], 4)   # noqa: E731
     info = renderer.last_info
-    I = int(info["n_isects"])
+    I_sorted = int(info["n_isects"])               # what this build bins: the fused path's tight tile boxes
     Nv = int((renderer.radii > 0).sum())
+    # I of SURVEY.md 8(d) is the workload's intersection count under the reference's rule (gsplat's 3-sigma tile box, A.3): the
+    # algorithmic bytes are priced on THAT, whatever share of the pairs an implementation manages not to touch
+    with torch.no_grad():
+        xy_, r_ = renderer.xys.detach().reshape(-1, 2), renderer.radii.reshape(-1).float()
+        tw_, th_ = (W + 15) // 16, (H + 15) // 16
+        bx0 = torch.floor((xy_[:, 0] - r_) / 16).clamp(0, tw_); bx1 = torch.ceil((xy_[:, 0] + r_) / 16).clamp(0, tw_)
+        by0 = torch.floor((xy_[:, 1] - r_) / 16).clamp(0, th_); by1 = torch.ceil((xy_[:, 1] + r_) / 16).clamp(0, th_)
+        I = int((((bx1 - bx0) * (by1 - by0)) * (r_ > 0)).double().sum().item())
     stats = timer.summary()
     stages = {}
     sb = stage_bytes(N, Nv, I, P, T)
@@ -363,7 +371,7 @@ def main():
                                    f"expected depth + per-Gaussian normals ({D_CH} channels, "
                                    f"{'two-call' if args.two_call else 'fused one-pass'}, post-ops in {'torch' if (args.torch_postops or args.two_call) else 'HIP'}), fx=fy={focal}, orbit r=8, "
                                    f"closed-form 3-NN scale init, {('dn-splatter loss stack (' + args.losses + ')') if args.losses else 'random dense cotangents'}",
-                       "N": N, "Nv": Nv, "n_isects": I, "mean_isects_per_rank": i_all / world,
+                       "N": N, "Nv": Nv, "n_isects": I, "n_isects_sorted": I_sorted, "mean_isects_per_rank": i_all / world,
                        "mean_tile_list_len": round(I / T, 1), "pixels": P, "bin_policy": args.bin_policy,
                        "allreduce_bytes_per_step": wire,
                        "grads_in_flat_bucket": bool(all(arena.holds(gp[k].grad) for k in dp.GRAD_KEYS)),
