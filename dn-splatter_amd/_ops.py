@@ -267,13 +267,13 @@ class _ProjectFn(torch.autograd.Function):
         if v_splats is None:
             v_splats = torch.zeros(C * N, RECORD_FLOATS, dtype=torch.float32, device=dev)
         v_splats = v_splats.contiguous()
-        # means2d's gradient normally IS columns 0-1 of the record (see _RasterFn.backward); only when the
-        # caller hung extra terms on info["means2d"] does a separate tensor arrive.
+        # The compositing backward leaves means2d's gradient in columns 0-1 of the gradient records and hands autograd no
+        # separate tensor for it (_hand_over_means2d_grad).  A tensor arriving here is therefore something ELSE the caller hung
+        # on info["means2d"] (or the legacy pass fed with non-detached xys): the kernel takes g.v_means2d INSTEAD of the
+        # record's columns, so the two are added here.
         v_m2d = None
         if v_means2d is not None:
-            same = (v_means2d.data_ptr() == v_splats.data_ptr() and v_means2d.stride()[-2:] == (RECORD_FLOATS, 1))
-            if not same:
-                v_m2d = v_means2d.reshape(C, N, 2).contiguous()
+            v_m2d = (v_means2d.reshape(C * N, 2) + v_splats[:, 0:2]).reshape(C, N, 2).contiguous()
         v_dep = v_depths.reshape(C, N).contiguous() if v_depths is not None else None
         v_con = v_conics.reshape(C, N, 3).contiguous() if v_conics is not None else None
         v_cmp = v_comp.reshape(C, N).contiguous() if (v_comp is not None and cfg.antialiased) else None
@@ -460,6 +460,19 @@ def isect_ids(b: Binning, depths: Tensor) -> Tensor:
 # stages 3/4: compositing
 
 
+
+def _hand_over_means2d_grad(means2d: Tensor, v_splats: Tensor):
+    """gsplat's contract (dn_model.py:517-519): after ``info["means2d"].retain_grad()`` the screen-space gradient is found in
+    ``info["means2d"].grad``.  Returning columns 0-1 of the gradient records as means2d's autograd gradient would make the
+    retain_grad hook CLONE that strided view (a 13 us copy kernel per frame at 1 M Gaussians) although the projection
+    backward reads the same numbers from the records anyway.  So autograd gets no separate gradient for means2d (None: the
+    records carry it) and the view itself is stored in ``.grad`` — added to whatever is already there, as the hook would."""
+    if not means2d.retains_grad:
+        return
+    view = v_splats[:, 0:2].view(means2d.shape)
+    means2d.grad = view if means2d.grad is None else means2d.grad + view
+
+
 class _RasterFn(torch.autograd.Function):
     """Bins, then composites D channels.  ``means2d`` is an input only so that autograd routes the
     xy-gradient through the tensor dn-splatter calls retain_grad() on (dn_model.py:517-519); the
@@ -504,7 +517,7 @@ class _RasterFn(torch.autograd.Function):
         dev = splats.device
         v_splats = torch.zeros(N, RECORD_FLOATS, dtype=torch.float32, device=dev)
         if v_render is None and v_alphas is None:
-            return (v_splats[:, 0:2].view(means2d.shape), v_splats) + (None,) * 12
+            return (None, v_splats) + (None,) * 12
         if v_render is None:
             v_render = torch.zeros_like(render)
         v_render = v_render.contiguous()
@@ -523,7 +536,8 @@ class _RasterFn(torch.autograd.Function):
         if absgrad:
             # gsplat contract (dn_model.py:512, consumed by nerfstudio after_train via self.xys.absgrad)
             means2d.absgrad = v_splats[:, 14:16].reshape(means2d.shape)
-        return (v_splats[:, 0:2].view(means2d.shape), v_splats) + (None,) * 12
+        _hand_over_means2d_grad(means2d, v_splats)
+        return (None, v_splats) + (None,) * 12
 
 
 def rasterize(means2d, splats, depths, radii, tiles, *, background=None, width, height, tile_size=16, D,
@@ -636,7 +650,7 @@ class _RasterDnFn(torch.autograd.Function):
         v_splats = torch.zeros(N, RECORD_FLOATS, dtype=torch.float32, device=dev)
         none = (None,) * 9
         if v_rgb is None and v_depth is None and v_normal is None and v_acc is None:
-            return (v_splats[:, 0:2].view(means2d.shape), v_splats) + none
+            return (None, v_splats) + none
         z = lambda t, c: torch.zeros(C, height, width, c, dtype=torch.float32, device=dev) if t is None else t.contiguous()  # noqa: E731
         v_rgb, v_depth, v_normal = z(v_rgb, 3), z(v_depth, 1), z(v_normal, 3)
         v_acc = v_acc.contiguous() if v_acc is not None else None
@@ -659,7 +673,8 @@ class _RasterDnFn(torch.autograd.Function):
         _lib.run("dnsplat_raster_bwd", _lib.lib().dnsplat_raster_bwd, ctypes.byref(a), _stream())
         if absgrad:
             means2d.absgrad = v_splats[:, 14:16].reshape(means2d.shape)
-        return (v_splats[:, 0:2].view(means2d.shape), v_splats) + none
+        _hand_over_means2d_grad(means2d, v_splats)
+        return (None, v_splats) + none
 
 
 def rasterize_dn(means2d, splats, depths, radii, tiles, *, background_rgb, width, height, intrinsics, absgrad=True,

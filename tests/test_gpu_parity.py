@@ -1236,3 +1236,31 @@ def test_tight_tile_boxes_change_the_lists_not_the_images(dns):
         assert torch.equal(o0[k], o1[k]), k
     for k in g0:
         assert_close(g1[k], g0[k], "tight vs gsplat boxes: grad " + k, tol=2e-6)
+
+
+def test_extra_terms_on_means2d_add_to_the_compositing_gradient(dns, orc):
+    """info["means2d"] is an autograd tensor like any other: a loss term hung on it directly must ADD to the screen-space
+    gradient the compositing backward leaves in the records (which reaches `.grad` without autograd's clone, _ops.py)."""
+    inp, viewmat, K, _ = gsplat_inputs(4000, 160, 128, focal=110.0, seed=9, anisotropic=True)
+    ci, gi = to_leaf(inp, "cpu"), to_leaf(inp, DEV)
+    kw = dict(width=160, height=128, packed=False, sh_degree=3, render_mode="RGB+ED", absgrad=True)
+    r_o, a_o, info_o = orc.rasterization(**ci, viewmats=viewmat, Ks=K, **kw)
+    r_g, a_g, info_g = dns.rasterization(**gi, viewmats=viewmat.to(DEV), Ks=K.to(DEV), **kw)
+    keep = keep_mask(info_o["borderline"], "extra means2d term")
+    v_r, = cotangents([r_o.shape], 5)
+    v_r = zero_borderline(v_r, keep)
+    w = cotangents([info_o["means2d"].shape], 6)[0] * 1e-3
+    info_o["means2d"].retain_grad(); info_g["means2d"].retain_grad()
+    ((r_o * v_r).sum() + (info_o["means2d"] * w).sum()).backward()
+    ((r_g * v_r.to(DEV)).sum() + (info_g["means2d"] * w.to(DEV)).sum()).backward()
+    assert_close(info_g["means2d"].grad, info_o["means2d"].grad, "means2d.grad with an extra term")
+    for k in ("means", "scales", "quats"):
+        assert_close(gi[k].grad, ci[k].grad, "grad " + k + " with an extra term on means2d")
+    # and without retain_grad() no .grad appears
+    gj = to_leaf(inp, DEV)
+    r2, _, info2 = dns.rasterization(**gj, viewmats=viewmat.to(DEV), Ks=K.to(DEV), **kw)
+    r2.sum().backward()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert info2["means2d"].grad is None
