@@ -18,7 +18,7 @@ _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["DNSPLAT_LIB"]).resolve() if os.environ.get("DNSPLAT_LIB") else _PKG_DIR / "libdnsplat.so"
 CSRC_DIR = _PKG_DIR / "csrc"
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 RECORD_FLOATS = 16
 MAX_CHANNELS = 8
 
@@ -53,7 +53,7 @@ class ProjOut(ctypes.Structure):
         ("radii", c_void_p), ("means2d", c_void_p), ("depths", c_void_p), ("conics", c_void_p),
         ("compensations", c_void_p), ("tiles_per_gauss", c_void_p), ("splats", c_void_p),
         ("normals_world", c_void_p),
-        ("with_depth_channel", c_int32), ("with_normal_channels", c_int32),
+        ("with_depth_channel", c_int32), ("with_normal_channels", c_int32), ("saturation_flag", c_void_p),
     ]
 
 
@@ -110,6 +110,7 @@ class RasterArgs(ctypes.Structure):
         ("v_splats", c_void_p),
         ("dn", ctypes.POINTER(DnPost)),
         ("n_cameras", c_int32), ("keep_masks", c_void_p), ("keep_mask_stride", c_int64), ("pair_counters", c_void_p),
+        ("saturation_flag", c_void_p),
     ]
 
 
@@ -187,7 +188,7 @@ def lib() -> ctypes.CDLL:
                                                     c_void_p, c_int32, c_void_p]
         L.dnsplat_dn_loss.argtypes = [ctypes.POINTER(DnLossArgs), c_void_p]
         L.dnsplat_camera_prepare.argtypes = [c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
-                                             c_void_p]
+                                             c_void_p, c_void_p]
         L.dnsplat_sh_factors.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         for name in EXPORTS:
             if name not in ("dnsplat_strerror", "dnsplat_bin_workspace_bytes", "dnsplat_bin_status_offset"):

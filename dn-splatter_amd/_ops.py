@@ -186,7 +186,8 @@ class _ProjectFn(torch.autograd.Function):
     ``shN`` [N,K-1,3] (the model's own features_dc / features_rest — no 192 B/Gaussian cat copy)."""
 
     @staticmethod
-    def forward(ctx, means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, cfg: ProjCfg):
+    def forward(ctx, means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, cfg: ProjCfg,
+                saturation_flag=None):
         means = _f32c(means, "means"); quats = _f32c(quats, "quats"); scales = _f32c(scales, "scales")
         opacities = _f32c(opacities, "opacities")
         viewmat = _f32c(viewmat, "viewmats"); K = _f32c(K, "Ks")
@@ -243,6 +244,7 @@ class _ProjectFn(torch.autograd.Function):
             out.normals_world = _ptr(nworld[c]) if nworld is not None else None
             out.with_depth_channel = int(cfg.with_depth)
             out.with_normal_channels = int(cfg.with_normals)
+            out.saturation_flag = _ptr(saturation_flag)      # one word for all cameras of the batch (zeroed by camera_prepare)
             _lib.run("dnsplat_project_fwd", _lib.lib().dnsplat_project_fwd, ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(out), _stream())
 
         ctx.cfg = cfg
@@ -342,15 +344,15 @@ class _ProjectFn(torch.autograd.Function):
                 for acc, t in zip(total, outs):
                     if acc is not None:
                         acc.add_(t)
-        return tuple(t if (t is not None and need[i]) else None for i, t in enumerate(total)) + (None, None, None, None)
+        return tuple(t if (t is not None and need[i]) else None for i, t in enumerate(total)) + (None, None, None, None, None)
 
 
 def project(means, quats, scales, opacities, *, coeffs=None, sh0=None, shN=None, colors=None, viewmat, K,
-            normal_frame=None, cfg: ProjCfg):
+            normal_frame=None, cfg: ProjCfg, saturation_flag: Optional[Tensor] = None):
     """``viewmat`` [4,4] or [C,4,4] (``K``, ``normal_frame`` alike) -> dict(means2d[C,N,2], depths[C,N], conics[C,N,3],
     compensations[C,N] | None, splats[C*N,16], radii[C,N], tiles_per_gauss[C,N], normals_world[C,N,3] | None)"""
     m2d, dep, con, comp, splats, radii, tiles, nworld = _ProjectFn.apply(
-        means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, cfg)
+        means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, cfg, saturation_flag)
     return dict(means2d=m2d, depths=dep, conics=con, compensations=comp if comp.numel() else None, splats=splats,
                 radii=radii, tiles_per_gauss=tiles, normals_world=nworld if nworld.numel() else None)
 
@@ -559,6 +561,8 @@ KEEP_MASKS = os.environ.get("DNSPLAT_KEEP_MASKS", "1") != "0"
 # ~1/3 fewer intersections on the benchmark scenes, same images and gradients).  DNSPLAT_TIGHT_TILES=0 (or setting this to
 # False) makes it use gsplat's boxes, as the drop-in calls always do.
 TIGHT_TILES = os.environ.get("DNSPLAT_TIGHT_TILES", "1") != "0"
+# dnsplat_raster_args.saturation_flag for the fused path's backward (DNSPLAT_SATURATION_FLAG=0: always the clamping loop)
+SATURATION_FLAG = os.environ.get("DNSPLAT_SATURATION_FLAG", "1") != "0"
 
 # Measurement hook (bench.py's VALU roofline): a uint64 [8] device tensor makes the fused pass run the COUNTING instantiation of
 # both compositing kernels, which tally list entries / splats walked / pairs evaluated / pairs blended / slots issued.
@@ -586,6 +590,7 @@ class _RasterDnFn(torch.autograd.Function):
     def forward(ctx, means2d, splats, depths, radii, tiles, bg_rgb, width, height, intr, absgrad, holder):
         dev = splats.device
         tight = bool(holder is not None and holder.get("tight_tiles"))
+        ctx.saturation_flag = holder.get("saturation_flag") if holder is not None else None
         C = means2d.shape[0]                     # cameras of the batch; intr = [(fx, fy, cx, cy)] * C
         f32 = dict(dtype=torch.float32, device=dev)
         render = torch.empty(C, height, width, 7, **f32)
@@ -670,6 +675,8 @@ class _RasterDnFn(torch.autograd.Function):
         a.pair_counters = _ptr(counters)
         if ctx.keep:
             a.keep_masks, a.keep_mask_stride = _ptr(ctx.keep["masks"]), ctx.keep["stride"]
+        # "no visible opacity above the alpha cap in this frame" (written by the projection): lets the kernel drop the clamp handling
+        a.saturation_flag = _ptr(ctx.saturation_flag) if SATURATION_FLAG else None
         _lib.run("dnsplat_raster_bwd", _lib.lib().dnsplat_raster_bwd, ctypes.byref(a), _stream())
         if absgrad:
             means2d.absgrad = v_splats[:, 14:16].reshape(means2d.shape)
@@ -689,26 +696,30 @@ def rasterize_dn(means2d, splats, depths, radii, tiles, *, background_rgb, width
                              holder)
 
 
-def camera_prepare(c2w: Tensor, fx: float, fy: float, cx: float, cy: float, with_normal_frame: bool = True):
+def camera_prepare(c2w: Tensor, fx: float, fy: float, cx: float, cy: float, with_normal_frame: bool = True, with_flag: bool = False):
     """One-launch replacement of get_viewmat + intrinsics + normal frame (dn_model.py:475-479, 550-560).
-    ``c2w`` [3,4] (or [1,3,4]) on the GPU -> viewmat[4,4], K[3,3], normal_frame[12] | None."""
+    ``c2w`` [3,4] (or [1,3,4]) on the GPU -> viewmat[4,4], K[3,3], normal_frame[12] | None
+    (+ with_flag: a zeroed int32 [1] device word, the frame's opacity-saturation flag for project(..., saturation_flag=))."""
     c2w = _f32c(c2w.reshape(-1)[:12], "camera_to_worlds")
     dev = c2w.device
-    out = torch.empty(16 + 9 + 12, dtype=torch.float32, device=dev)
+    out = torch.empty(16 + 9 + 12 + 1, dtype=torch.float32, device=dev)
     viewmat, K, nf = out[:16], out[16:25], out[25:37]
+    flag = out[37:38].view(torch.int32) if with_flag else None
     _lib.run("dnsplat_camera_prepare", _lib.lib().dnsplat_camera_prepare, _ptr(c2w), fx, fy, cx, cy, _ptr(viewmat), _ptr(K),
-             _ptr(nf) if with_normal_frame else None, _stream())
-    return viewmat.view(4, 4), K.view(3, 3), (nf if with_normal_frame else None)
+             _ptr(nf) if with_normal_frame else None, _ptr(flag), _stream())
+    res = (viewmat.view(4, 4), K.view(3, 3), (nf if with_normal_frame else None))
+    return res + (flag,) if with_flag else res
 
 
-def camera_prepare_batch(cameras, with_normal_frame: bool = True):
+def camera_prepare_batch(cameras, with_normal_frame: bool = True, with_flag: bool = False):
     """camera_prepare for a list of camera records (``camera_to_worlds`` [1,3,4], fx, fy, cx, cy) ->
-    viewmats[C,4,4], Ks[C,3,3], normal_frames[C,12] | None."""
-    parts = [camera_prepare(c.camera_to_worlds, float(c.fx), float(c.fy), float(c.cx), float(c.cy), with_normal_frame) for c in cameras]
+    viewmats[C,4,4], Ks[C,3,3], normal_frames[C,12] | None (+ with_flag: ONE zeroed flag word for the whole batch)."""
+    parts = [camera_prepare(c.camera_to_worlds, float(c.fx), float(c.fy), float(c.cx), float(c.cy), with_normal_frame,
+                            with_flag=(with_flag and i == 0)) for i, c in enumerate(cameras)]
     vm = torch.stack([p[0] for p in parts])
     K = torch.stack([p[1] for p in parts])
     nf = torch.stack([p[2] for p in parts]) if with_normal_frame else None
-    return vm, K, nf
+    return (vm, K, nf, parts[0][3]) if with_flag else (vm, K, nf)
 
 
 class _PackFn(torch.autograd.Function):

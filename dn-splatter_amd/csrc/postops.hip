@@ -58,9 +58,11 @@ __global__ __launch_bounds__(256) void dn_depth_normals_kernel(int W, int H, flo
 }
 
 __global__ void camera_prepare_kernel(const float *__restrict__ c2w, float fx, float fy, float cx, float cy,
-                                      float *__restrict__ viewmat, float *__restrict__ K, float *__restrict__ nf)
+                                      float *__restrict__ viewmat, float *__restrict__ K, float *__restrict__ nf,
+                                      uint32_t *__restrict__ zero_word)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (zero_word) *zero_word = 0u;
     // c2w [3,4] nerfstudio/OpenGL.  get_viewmat: flip the y and z camera axes, then invert analytically.
     float R[9], t[3];
     for (int r = 0; r < 3; ++r) {
@@ -231,11 +233,11 @@ extern "C" int dnsplat_dn_depth_normals(int32_t width, int32_t height, float fx,
 }
 
 extern "C" int dnsplat_camera_prepare(const float *c2w, float fx, float fy, float cx, float cy, float *viewmat, float *K,
-                                      float *normal_frame, dnsplat_stream_t stream)
+                                      float *normal_frame, uint32_t *zero_word, dnsplat_stream_t stream)
 {
     if (!c2w || !viewmat || !K) return DNSPLAT_ERR_INVALID_ARG;
     hipLaunchKernelGGL(camera_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c2w, fx, fy, cx, cy, viewmat, K,
-                       normal_frame);
+                       normal_frame, zero_word);
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;
 }

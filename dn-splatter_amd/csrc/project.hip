@@ -394,6 +394,9 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(FwdParams p)
     const int tw = (p.c.width + p.c.tile_size - 1) / p.c.tile_size;
     const int th = (p.c.height + p.c.tile_size - 1) / p.c.tile_size;
     if (p.c.antialiased) opac *= st.compensation;
+    // alpha = min(0.999, opacity x vis) can only clamp for a splat whose opacity exceeds the cap (vis <= 1): tell the compositing
+    // backward whether this frame holds one at all (dnsplat_proj_out.saturation_flag; many lanes may store the same 1)
+    if (p.o.saturation_flag && opac > (float)DNS_ALPHA_MAX) *p.o.saturation_flag = 1u;
     int x0, y0, x1, y1;
     if (p.c.tight_tiles)
         dns_snug_tile_bbox(st.mean2d[0], st.mean2d[1], st.conic[0], st.conic[1], st.conic[2], opac, st.radius, p.c.tile_size, tw, th,

@@ -138,6 +138,7 @@ struct BwdArgs {
     int n_cameras;
     const unsigned long long *__restrict__ keep_masks;   // MASKS instantiations: the forward's rectangle-test ballots (dnsplat.h)
     long long keep_mask_stride;
+    const uint32_t *sat_flag;                  // dnsplat_raster_args.saturation_flag: the launch runs as two kernels, one of which leaves at once
     const float4 *__restrict__ splats;
     const int32_t *__restrict__ flatten_ids;
     const int32_t *__restrict__ tile_offsets;
@@ -224,9 +225,15 @@ __device__ __forceinline__ float dpp_wave_shr1(float from_prev, float lane0_valu
 // MASKS: which list entries can contribute to this half tile comes from the forward (a.keep_masks) instead of being re-derived
 // with dns_cull_rect: same decisions (the forward ran the same test on the same records), no record gathers for rejected
 // entries, and the test's registers (the kernel's VGPR peak) are gone.
-template <int D, int SPLIT, bool DN, bool COUNT = false, bool MASKS = false>
+// CLAMP_LOOP = false: the step loop without the alpha cap (no min, no "gradient only where not clamped" compare and select: 82 instead
+// of 86 vector instructions per step, -3.6 % measured).  Only right when no splat of the launch has an opacity above the cap, which
+// the projection reports in a device word (dnsplat_proj_out.saturation_flag).  Nothing on the host knows the answer without a
+// sync, so both instantiations are launched and the one that does not apply leaves at its first instruction (a few us).  Two loop
+// bodies inside ONE kernel were tried in round 1 / 2: 154 VGPRs, or 36 spilled values under the 128-VGPR pin (+28 %).
+template <int D, int SPLIT, bool DN, bool COUNT = false, bool MASKS = false, bool CLAMP_LOOP = true>
 __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) void raster_bwd_kernel(BwdArgs a)
 {
+    if (a.sat_flag && (*a.sat_flag != 0u) != CLAMP_LOOP) return;
     __shared__ float4 pix[NPIX][3];            // [p][0..1] = v_k, [p][2] = (T, S_a, S_b, bin_final)
     // compacted list indices waiting for a bucket (never more than 127 + 64) + the 1 KiB staging area of the transposed flush, which
     // ALIASES queue entries >= 64: while a pass is flushed only the < 64 left-over entries at the front of the queue are
@@ -696,7 +703,7 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
             tl_steps += nsteps; if (grp == 0) tl_splats += take;
 #endif
 #if DNS_BWD_CLAMP_MODE == 1
-            step_loop(std::true_type{});
+            step_loop(std::integral_constant<bool, CLAMP_LOOP>{});
 #else
             if (dns_ballot(opac.x > (float)DNS_ALPHA_MAX || opac.y > (float)DNS_ALPHA_MAX) != 0ull) step_loop(std::true_type{});
             else step_loop(std::false_type{});
@@ -721,8 +728,12 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
 template <int D, int SPLIT, bool DN = false, bool COUNT = false, bool MASKS = false>
 int launch_bwd(const BwdArgs &ba, hipStream_t stream)
 {
-    hipLaunchKernelGGL((raster_bwd_kernel<D, SPLIT, DN, COUNT, MASKS>), dim3(ba.n_tiles * ba.n_cameras * PARTS), dim3(DNS_WAVE), 0, stream, ba);
+    hipLaunchKernelGGL((raster_bwd_kernel<D, SPLIT, DN, COUNT, MASKS, true>), dim3(ba.n_tiles * ba.n_cameras * PARTS), dim3(DNS_WAVE), 0, stream, ba);
     DNS_CHECK_LAUNCH();
+    if constexpr (DN && !COUNT) if (ba.sat_flag) {       // its clamp-free twin; exactly one of the two does the work
+        hipLaunchKernelGGL((raster_bwd_kernel<D, SPLIT, DN, COUNT, MASKS, false>), dim3(ba.n_tiles * ba.n_cameras * PARTS), dim3(DNS_WAVE), 0, stream, ba);
+        DNS_CHECK_LAUNCH();
+    }
     return DNSPLAT_OK;
 }
 
@@ -765,6 +776,8 @@ extern "C" int dnsplat_raster_bwd(const dnsplat_raster_args *a, dnsplat_stream_t
     ba.counters = reinterpret_cast<unsigned long long *>(a->pair_counters);
     ba.keep_masks = reinterpret_cast<const unsigned long long *>(a->keep_masks);
     ba.keep_mask_stride = a->keep_mask_stride;
+    // the fused pass only (the generic and the counting instantiations have no clamp-free twin and always clamp)
+    ba.sat_flag = (a->dn && !a->pair_counters) ? a->saturation_flag : nullptr;
     if (ba.keep_masks && a->keep_mask_stride <= 0) return DNSPLAT_ERR_INVALID_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     if (a->dn) {

@@ -105,10 +105,10 @@ def render_dn_outputs(
     depth->normal stencil; backward = compositing backward (taking the image cotangents directly) + fused
     projection backward.  Returns ``(outputs, info)`` with the output keys of dn_model.py:605-612 minus
     ``background``."""
-    viewmat, K, nf = _ops.camera_prepare(camera_to_world, fx, fy, cx, cy)
+    viewmat, K, nf, flag = _ops.camera_prepare(camera_to_world, fx, fy, cx, cy, with_flag=True)
     outs, info = _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest, viewmat[None], K[None], nf[None],
                                   [(fx, fy, cx, cy)], width, height, sh_degree, background_rgb, near_plane, far_plane, eps2d,
-                                  absgrad, pair_counters)
+                                  absgrad, pair_counters, flag)
     # squeeze, not [0]: the backward of a select would zero-fill a full-size gradient and copy the slice into it (a fill + a copy
     # kernel per output image, ~60 us per frame at 1080p); the backward of a squeeze is a view
     return {k: v.squeeze(0) for k, v in outs.items()}, info
@@ -122,22 +122,23 @@ def render_dn_outputs_batch(
     """``render_dn_outputs`` for C cameras (records with camera_to_worlds [1,3,4], fx, fy, cx, cy; one image size) in ONE
     binning pass and ONE compositing launch: outputs are [C,H,W,.] stacks whose slices equal the
     per-camera results bit for bit."""
-    viewmats, Ks, nfs = _ops.camera_prepare_batch(cameras)
+    viewmats, Ks, nfs, flag = _ops.camera_prepare_batch(cameras, with_flag=True)
     intr = [(float(c.fx), float(c.fy), float(c.cx), float(c.cy)) for c in cameras]
     return _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest, viewmats, Ks, nfs, intr, width, height,
-                            sh_degree, background_rgb, near_plane, far_plane, eps2d, absgrad, None)
+                            sh_degree, background_rgb, near_plane, far_plane, eps2d, absgrad, None, flag)
 
 
 def _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest, viewmats, Ks, nfs, intr, width, height,
-                     sh_degree, background_rgb, near_plane, far_plane, eps2d, absgrad, pair_counters):
+                     sh_degree, background_rgb, near_plane, far_plane, eps2d, absgrad, pair_counters, saturation_flag=None):
     N = means.shape[0]
     C = viewmats.shape[0]
     cfg = ProjCfg(width=width, height=height, tile_size=16, eps2d=eps2d, near_plane=near_plane, far_plane=far_plane,
                   antialiased=False, scales_are_log=True, opacities_are_logit=True, sh_degree=int(sh_degree),
                   with_depth=True, with_normals=True, want_normals_world=True, tight_tiles=_ops.TIGHT_TILES)
     pr = _ops.project(means, quats, scales, opacities.reshape(N), sh0=features_dc, shN=features_rest, viewmat=viewmats,
-                      K=Ks, normal_frame=nfs, cfg=cfg)
-    holder: Dict = {"tight_tiles": cfg.tight_tiles}      # the tile lists of this path are internal: tight tile boxes
+                      K=Ks, normal_frame=nfs, cfg=cfg, saturation_flag=saturation_flag)
+    # the tile lists of this path are internal: tight tile boxes; the projection's "some visible opacity > 0.999" word
+    holder: Dict = {"tight_tiles": cfg.tight_tiles, "saturation_flag": saturation_flag}
     if pair_counters is not None:
         holder["pair_counters"] = pair_counters
     rgb, depth, normal, acc, surface_normal = _ops.rasterize_dn(
@@ -150,5 +151,6 @@ def _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest
         "flatten_ids": b.flatten_ids[: b.n_isects], "isect_offsets": b.tile_offsets[:-1].reshape(C, b.tile_height, b.tile_width),
         "n_isects": b.n_isects, "tile_width": b.tile_width, "tile_height": b.tile_height,
         "width": width, "height": height, "tile_size": 16, "n_cameras": C, "_binning": b, "tight_tiles": cfg.tight_tiles,
+        "_saturation_flag": saturation_flag,
     }
     return {"rgb": rgb, "depth": depth, "normal": normal, "surface_normal": surface_normal, "accumulation": acc}, info

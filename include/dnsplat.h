@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DNSPLAT_ABI_VERSION 6
+#define DNSPLAT_ABI_VERSION 7
 #define DNSPLAT_RECORD_FLOATS 16
 #define DNSPLAT_MAX_CHANNELS 8
 
@@ -108,6 +108,9 @@ typedef struct dnsplat_proj_out {
     float *normals_world;      /* [N,3] or NULL: what dn_model.py:558 stores into gauss_params["normals"] */
     int32_t with_depth_channel;   /* append camera-space depth as a channel (RGB+D / RGB+ED) */
     int32_t with_normal_channels; /* append the 3 camera-frame normal channels (needs camera.normal_frame) */
+    uint32_t *saturation_flag;    /* NULL, or a device word the caller zeroed: set to 1 when a visible Gaussian's opacity (after
+                                     the antialiasing compensation) exceeds 0.999, i.e. when alpha = min(0.999, o x vis) can clamp
+                                     at all in this frame (A.5).  dnsplat_raster_args.saturation_flag takes it. */
 } dnsplat_proj_out;
 
 int dnsplat_project_fwd(const dnsplat_scene *scene, const dnsplat_camera *cam,
@@ -221,6 +224,9 @@ typedef struct dnsplat_raster_args {
                                            forward  [0] list entries examined  [1] splats walked (kept by the rectangle test)
                                                     [2] live (pixel, splat) pairs evaluated  [3] pairs blended
                                            backward [4] (pixel, splat) slots issued (steps x 128)  [5] pairs replayed */
+    const uint32_t *saturation_flag;    /* NULL, or dnsplat_proj_out.saturation_flag of the projection(s) behind `splats`: if the word
+                                           is 0 no pair of this launch can clamp and dnsplat_raster_bwd runs its step loop without
+                                           the clamp handling (same results, ~3.6 % fewer cycles); read on the device, no host sync */
 } dnsplat_raster_args;
 
 int dnsplat_raster_fwd(const dnsplat_raster_args *args, dnsplat_stream_t stream);
@@ -239,9 +245,11 @@ int dnsplat_dn_depth_normals(int32_t width, int32_t height, float fx, float fy, 
 
 /* nerfstudio get_viewmat + intrinsics + normal frame in one launch: from the camera-to-world matrix
  * c2w [3,4] (OpenGL axes, device) writes viewmat[16] (world->camera, OpenCV), K[9] and
- * normal_frame[12] (see dnsplat_camera).  Replaces ~20 tiny torch kernels per frame (dn_model.py:475-479). */
+ * normal_frame[12] (see dnsplat_camera).  Replaces ~20 tiny torch kernels per frame (dn_model.py:475-479).
+ * zero_word (optional): a device word set to 0 by the same launch — the frame's dnsplat_proj_out.saturation_flag starts
+ * here without a fill launch of its own. */
 int dnsplat_camera_prepare(const float *c2w, float fx, float fy, float cx, float cy,
-                           float *viewmat, float *K, float *normal_frame, dnsplat_stream_t stream);
+                           float *viewmat, float *K, float *normal_frame, uint32_t *zero_word, dnsplat_stream_t stream);
 
 /* Multi-view data parallelism, compact exchange of the SH gradients.  For one camera the gradient of Gaussian g's SH
  * coefficients is an outer product  v_coeff[g][k][c] = basis_k(dir_g) * v_colour[g][c]  (k < (degree+1)^2, c < 3): 6 numbers

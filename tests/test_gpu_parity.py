@@ -434,6 +434,8 @@ def test_saturated_opacities_take_the_alpha_clamp(dns, orc):
     gp["opacities"][::3] = 12.0                                   # sigmoid(12) = 0.999994
     cam = synthetic.orbit_camera(3, width=144, height=112, focal=100.0)
     hip, ora, keep = _mirror_pair(dns, orc, gp, cam, dict(fused=True), cot_seed=4, what="clamped fused")
+    # the projection reported "some visible opacity above the cap": the backward ran its clamping loop
+    assert int(hip[2].last_info["_saturation_flag"].item()) == 1
     _check_mirror(hip, ora, keep, "clamped fused")
 
 
@@ -519,6 +521,8 @@ def test_get_outputs_mirror_matches_reference_sequence(dns, orc, mode):
     out_g, p_g, m_g = hip
     out_o, p_o, m_o = ora
     assert set(out_g) == {"rgb", "depth", "normal", "surface_normal", "accumulation", "background"}
+    if "_saturation_flag" in m_g.last_info:      # fused + HIP post-ops: no opacity above the cap here, the clamp-free twin ran
+        assert int(m_g.last_info["_saturation_flag"].item()) == 0
     _check_mirror(hip, ora, keep, "mirror " + mode, ints=False)
     assert_equal_int(m_g.radii, m_o.radii, "radii")
     if m_g.last_info.get("tight_tiles"):      # the fused path counts the tiles of its tight boxes (dnsplat_camera.tight_tiles)
@@ -1235,7 +1239,8 @@ def test_tight_tile_boxes_change_the_lists_not_the_images(dns):
     for k in keys:
         assert torch.equal(o0[k], o1[k]), k
     for k in g0:
-        assert_close(g1[k], g0[k], "tight vs gsplat boxes: grad " + k, tol=2e-6)
+        # two runs of the same atomic sums in different orders (the shorter lists shift which wave adds first): a few 1e-6
+        assert_close(g1[k], g0[k], "tight vs gsplat boxes: grad " + k, tol=1e-5)
 
 
 def test_extra_terms_on_means2d_add_to_the_compositing_gradient(dns, orc):
