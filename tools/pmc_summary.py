@@ -9,13 +9,20 @@ out = {}
 for f in sorted(glob.glob(root + "/*/p_counter_collection.csv")):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); ids = collections.defaultdict(set)
     meta = {}
+    calls = set()
     for row in csv.DictReader(open(f)):
         k = next((n for n in names if n in row["Kernel_Name"]), None)
         if k is None: continue
+        # dnsplat_raster_bwd launches its clamping kernel (last template argument true) and, for the fused pass, the clamp-free
+        # twin (false); one of the two leaves at once.  Per CALL of the entry point their counters add up, and a call is
+        # counted by its one `true` dispatch.
+        m = re.search(r"raster_bwd_kernel<([^>]*)>", row["Kernel_Name"])
+        if m and m.group(1).split(",")[-1].strip() == "true": calls.add(row["Dispatch_Id"])
         acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); ids[k].add(row["Dispatch_Id"])
         meta[k] = dict(VGPR=row["VGPR_Count"], SGPR=row["SGPR_Count"], LDS=row["LDS_Block_Size"], grid=row["Grid_Size"], wg=row["Workgroup_Size"])
     for k in acc:
         n = len(ids[k])
+        if k == "raster_bwd_kernel" and calls: n = len(calls)
         out.setdefault(k, {}).update({c: v / n for c, v in acc[k].items()})
         out[k]["launches_seen"] = n; out[k].update(meta[k])
 print(json.dumps(out, indent=1))
