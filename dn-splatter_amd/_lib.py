@@ -18,7 +18,7 @@ _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["DNSPLAT_LIB"]).resolve() if os.environ.get("DNSPLAT_LIB") else _PKG_DIR / "libdnsplat.so"
 CSRC_DIR = _PKG_DIR / "csrc"
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 RECORD_FLOATS = 16
 MAX_CHANNELS = 8
 
@@ -110,7 +110,7 @@ class RasterArgs(ctypes.Structure):
         ("v_splats", c_void_p),
         ("dn", ctypes.POINTER(DnPost)),
         ("n_cameras", c_int32), ("keep_masks", c_void_p), ("keep_mask_stride", c_int64), ("pair_counters", c_void_p),
-        ("saturation_flag", c_void_p),
+        ("saturation_flag", c_void_p), ("zero_fill", c_void_p), ("zero_fill_bytes", c_int64),
     ]
 
 

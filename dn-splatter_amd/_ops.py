@@ -563,6 +563,8 @@ KEEP_MASKS = os.environ.get("DNSPLAT_KEEP_MASKS", "1") != "0"
 TIGHT_TILES = os.environ.get("DNSPLAT_TIGHT_TILES", "1") != "0"
 # dnsplat_raster_args.saturation_flag for the fused path's backward (DNSPLAT_SATURATION_FLAG=0: always the clamping loop)
 SATURATION_FLAG = os.environ.get("DNSPLAT_SATURATION_FLAG", "1") != "0"
+# dnsplat_raster_args.zero_fill: the fused forward clears the gradient records its backward accumulates into
+FORWARD_ZERO_FILL = os.environ.get("DNSPLAT_FORWARD_ZERO_FILL", "1") != "0"
 
 # Measurement hook (bench.py's VALU roofline): a uint64 [8] device tensor makes the fused pass run the COUNTING instantiation of
 # both compositing kernels, which tally list entries / splats walked / pairs evaluated / pairs blended / slots issued.
@@ -611,6 +613,10 @@ class _RasterDnFn(torch.autograd.Function):
         if counters is None:
             counters = PAIR_COUNTERS
         keep = {}
+        # gradient records of the backward (atomically accumulated, so they must start at zero): allocated here and cleared by the
+        # forward kernel itself when a backward can follow (FORWARD_ZERO_FILL = False: torch.zeros in the backward)
+        fill = {"v_splats": torch.empty(splats.shape[0], RECORD_FLOATS, **f32)
+                if (FORWARD_ZERO_FILL and ctx.needs_input_grad[1] and counters is None) else None}
 
         def composite(b: Binning):
             depth_max.zero_()
@@ -629,6 +635,8 @@ class _RasterDnFn(torch.autograd.Function):
             a.render, a.alphas, a.last_ids = _ptr(render), _ptr(alphas), _ptr(last_ids)
             a.dn = ctypes.pointer(dn)
             a.pair_counters = _ptr(counters)
+            if fill["v_splats"] is not None:      # the backward's accumulation buffer, cleared by this launch on the way
+                a.zero_fill, a.zero_fill_bytes = _ptr(fill["v_splats"]), fill["v_splats"].numel() * 4
             _lib.run("dnsplat_raster_fwd", _lib.lib().dnsplat_raster_fwd, ctypes.byref(a), _stream())
 
         b = bin_tiles(means2d.detach().reshape(-1, 2), radii.reshape(-1), depths.detach().reshape(-1), tiles.reshape(-1), width,
@@ -641,6 +649,7 @@ class _RasterDnFn(torch.autograd.Function):
             holder["binning"] = b
         ctx.save_for_backward(means2d, splats, b.flatten_ids, b.tile_offsets, render, alphas, last_ids, bg_rgb)
         ctx.keep = keep
+        ctx.v_splats = fill["v_splats"]
         ctx.cfg = (width, height, absgrad, C, counters)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(surface_normal)
@@ -652,7 +661,10 @@ class _RasterDnFn(torch.autograd.Function):
         width, height, absgrad, C, counters = ctx.cfg
         N = splats.shape[0]
         dev = splats.device
-        v_splats = torch.zeros(N, RECORD_FLOATS, dtype=torch.float32, device=dev)
+        # cleared by the forward launch of this frame; a second backward through the same graph gets a fresh one
+        v_splats, ctx.v_splats = ctx.v_splats, None
+        if v_splats is None:
+            v_splats = torch.zeros(N, RECORD_FLOATS, dtype=torch.float32, device=dev)
         none = (None,) * 9
         if v_rgb is None and v_depth is None and v_normal is None and v_acc is None:
             return (None, v_splats) + none

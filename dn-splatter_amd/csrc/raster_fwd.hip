@@ -47,6 +47,8 @@ struct FwdArgs {
     float *__restrict__ dn_depth;
     float *__restrict__ dn_normal;
     float *__restrict__ dn_depth_max;
+    float4 *zero_fill;                         // dnsplat_raster_args.zero_fill: cleared by this launch, zero_fill_vec4 16-byte pieces
+    long long zero_fill_vec4;
 };
 
 // The dn-splatter per-pixel post-ops (dn_model.py:526-528, 577-578) applied to one finished pixel.
@@ -93,11 +95,22 @@ __device__ __forceinline__ float sel0(uint64_t mask, float a)
 
 // COUNT: measurement build of the fused pass — also tallies list entries examined, splats walked, live (pixel, splat) pairs
 // evaluated and pairs blended into a.counters (bench.py's VALU roofline); never the instantiation that is timed.
+// (A clamp-free twin as in raster_bwd.hip was measured here too: the two `min` it drops from 43 vector instructions per splat
+// bought nothing — 0.562 vs 0.561 ms — and its differently scheduled code broke the bit-identity of the raw composite between
+// the instantiations, which tests/test_reference_golden.py relies on.  Removed.)
 template <int D, bool DN, bool COUNT = false>
 __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kernel(FwdArgs a)
 {
     // one 64-record slice per wave: [wave][splat][4 x float4]
     __shared__ float4 lds[FWD_WAVES][DNS_WAVE][4];
+    // The backward's accumulation buffer (one 64-byte gradient record per splat, added to with atomics) has to start at zero.
+    // This kernel is bound by vector issue and leaves the memory system idle: every workgroup clears its share on the way
+    // (4 stores per lane at C2) instead of a 10 us fill launch in front of the backward.
+    if (a.zero_fill) {
+        const long long per = (a.zero_fill_vec4 + gridDim.x - 1) / gridDim.x;
+        const long long lo = (long long)blockIdx.x * per, hi = min(lo + per, a.zero_fill_vec4);
+        for (long long i = lo + threadIdx.x; i < hi; i += FWD_THREADS) a.zero_fill[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
     // batch of cameras: block b works on tile b % n_tiles of camera b / n_tiles; its lists are tile_offsets[b .. b + 1] and its
     // pixels live in image `cam` of the stacked [C,H,W,.] outputs
@@ -311,6 +324,9 @@ extern "C" int dnsplat_raster_fwd(const dnsplat_raster_args *a, dnsplat_stream_t
     fa.bg_rgb = nullptr; fa.dn_rgb = fa.dn_depth = fa.dn_normal = fa.dn_depth_max = nullptr;
     fa.counters = reinterpret_cast<unsigned long long *>(a->pair_counters);
     fa.keep_masks = reinterpret_cast<unsigned long long *>(a->keep_masks);
+    if (a->zero_fill_bytes < 0 || (a->zero_fill_bytes & 15) || (a->zero_fill_bytes > 0 && !a->zero_fill)) return DNSPLAT_ERR_INVALID_ARG;
+    fa.zero_fill = a->zero_fill_bytes > 0 ? reinterpret_cast<float4 *>(a->zero_fill) : nullptr;
+    fa.zero_fill_vec4 = a->zero_fill_bytes >> 4;
     fa.keep_mask_stride = a->keep_mask_stride;
     if (a->n_cameras < 0) return DNSPLAT_ERR_INVALID_ARG;
     const int C = a->n_cameras > 1 ? a->n_cameras : 1;

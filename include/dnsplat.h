@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DNSPLAT_ABI_VERSION 7
+#define DNSPLAT_ABI_VERSION 8
 #define DNSPLAT_RECORD_FLOATS 16
 #define DNSPLAT_MAX_CHANNELS 8
 
@@ -225,8 +225,11 @@ typedef struct dnsplat_raster_args {
                                                     [2] live (pixel, splat) pairs evaluated  [3] pairs blended
                                            backward [4] (pixel, splat) slots issued (steps x 128)  [5] pairs replayed */
     const uint32_t *saturation_flag;    /* NULL, or dnsplat_proj_out.saturation_flag of the projection(s) behind `splats`: if the word
-                                           is 0 no pair of this launch can clamp and dnsplat_raster_bwd runs its step loop without
+                                           is 0 no pair of this launch can clamp and dnsplat_raster_bwd (only; the forward ignores it) runs its step loop without
                                            the clamp handling (same results, ~3.6 % fewer cycles); read on the device, no host sync */
+    void *zero_fill;                    /* dnsplat_raster_fwd only: NULL, or a device buffer of zero_fill_bytes (multiple of 16) the launch clears
+                                           on the way — meant for the v_splats buffer the backward of the same frame accumulates into */
+    int64_t zero_fill_bytes;
 } dnsplat_raster_args;
 
 int dnsplat_raster_fwd(const dnsplat_raster_args *args, dnsplat_stream_t stream);

@@ -1269,3 +1269,22 @@ def test_extra_terms_on_means2d_add_to_the_compositing_gradient(dns, orc):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         assert info2["means2d"].grad is None
+
+
+def test_second_backward_through_the_same_frame_gets_fresh_gradient_records(dns):
+    """The fused forward clears the gradient records its backward accumulates into (dnsplat_raster_args.zero_fill); a second
+    backward through the same graph must not add onto the first one's sums."""
+    from dn_splatter_amd import synthetic
+
+    gp = synthetic.make_gauss_params(5000, sh_rest_std=0.1, seed=2, device=DEV)
+    cam = synthetic.orbit_camera(1, width=160, height=112, focal=100.0).to(DEV)
+    r = dns.DNSplatterRenderer(gp, fused=True)
+    out = r.get_outputs(cam)
+    loss = out["rgb"].sum() + out["depth"].mean() + out["normal"].sum()
+    loss.backward(retain_graph=True)
+    g1 = {k: v.grad.clone() for k, v in gp.items() if v.grad is not None}
+    for v in gp.values():
+        v.grad = None
+    loss.backward()
+    for k in g1:
+        assert_close(gp[k].grad, g1[k], "second backward: grad " + k, tol=1e-5)
