@@ -261,7 +261,10 @@ class DNSplatterRenderer:
             quats_n = quats / quats.norm(dim=-1, keepdim=True)
             normals = F.one_hot(torch.argmin(scales, dim=-1), num_classes=3).to(scales.dtype)   # .float() in the reference
             rots = quat_to_rotmat(quats_n)
-            normals = torch.bmm(rots, normals[:, :, None]).squeeze(-1)
+            # the reference's torch.bmm(rots, normals[:, :, None]).squeeze(-1): hipBLASLt runs a batch of 1 M 3x3 matrices as one
+            # 13 ms launch (+ 9 ms in the backward); `normals` is one-hot, so the same products summed elementwise give the
+            # same bits in 0.1 ms
+            normals = (rots * normals[:, None, :]).sum(-1)
             normals = F.normalize(normals, dim=1)
             viewdirs = -means.detach() + c2w.detach()[..., :3, 3]
             viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
