@@ -225,3 +225,49 @@ def test_projection_edge_flags_cover_last_place_jitter(orc):
     assert int(changed.sum()) > 0, "the jitter moved no integer at all: the test scene is too easy"
     assert int((changed & ~edge).sum()) == 0
     assert int(edge.sum()) < 0.02 * edge.numel()
+
+
+def test_tight_tile_boxes_only_leave_out_unreachable_tiles(orc):
+    """The tile rule of the product's fused path (dnsplat_camera.tight_tiles, restated in oracle.tight_tile_boxes): inside gsplat's
+    3-sigma box, and every tile of gsplat's box it drops has min sigma over the tile's pixel-centre rectangle >= ln(255 opacity)
+    (closed form, float64) — no pixel of it can pass the alpha >= 1/255 test of A.5."""
+    import math
+    import torch
+    from _scenes import gsplat_inputs
+
+    W, H = 320, 240
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    kept_total = loose_total = 0
+    for seed, aniso in ((3, False), (4, True), (5, True)):
+        inp, viewmat, K, _ = gsplat_inputs(6000, W, H, focal=200.0, seed=seed, anisotropic=aniso)
+        g = torch.Generator().manual_seed(seed)
+        opac = torch.rand(6000, generator=g) ** 3                    # many faint splats, some near 1, some below 1/255
+        radii, means2d, depths, conics = orc.project_fwd(inp["means"], inp["quats"], inp["scales"], viewmat[0], K[0], W, H)[:4]
+        x0, y0, x1, y1 = orc.tight_tile_boxes(means2d, conics, opac, radii, 16, tw, th)
+        r = radii.float()
+        lx0 = torch.floor((means2d[:, 0] - r) / 16).clamp(0, tw).long(); lx1 = torch.ceil((means2d[:, 0] + r) / 16).clamp(0, tw).long()
+        ly0 = torch.floor((means2d[:, 1] - r) / 16).clamp(0, th).long(); ly1 = torch.ceil((means2d[:, 1] + r) / 16).clamp(0, th).long()
+        vis = radii > 0
+        assert bool(((x0 >= lx0) & (x1 <= lx1) & (y0 >= ly0) & (y1 <= ly1))[vis].all())
+        kept_total += int(((x1 - x0) * (y1 - y0))[vis].sum()); loose_total += int(((lx1 - lx0) * (ly1 - ly0))[vis].sum())
+        m, c, o = means2d.double(), conics.double(), opac.double()
+        for gi in torch.nonzero(vis).reshape(-1).tolist():
+            if o[gi] * 255.0 <= 1.0:
+                continue
+            tau = math.log(255.0 * o[gi])
+            a_, b_, c_ = c[gi].tolist()
+            for ty in range(int(ly0[gi]), int(ly1[gi])):
+                for tx in range(int(lx0[gi]), int(lx1[gi])):
+                    if int(x0[gi]) <= tx < int(x1[gi]) and int(y0[gi]) <= ty < int(y1[gi]):
+                        continue
+                    lox, hix = tx * 16 + 0.5 - m[gi, 0].item(), tx * 16 + 15.5 - m[gi, 0].item()
+                    loy, hiy = ty * 16 + 0.5 - m[gi, 1].item(), ty * 16 + 15.5 - m[gi, 1].item()
+                    sig = lambda dx, dy: 0.5 * (a_ * dx * dx + c_ * dy * dy) + b_ * dx * dy   # noqa: E731
+                    clip = lambda v, lo, hi: min(max(v, lo), hi)                                 # noqa: E731
+                    if lox <= 0 <= hix and loy <= 0 <= hiy:
+                        smin = 0.0
+                    else:
+                        smin = min([sig(dx, clip(-b_ * dx / c_, loy, hiy)) for dx in (lox, hix)] +
+                                   [sig(clip(-b_ * dy / a_, lox, hix), dy) for dy in (loy, hiy)])
+                    assert smin >= tau - 1e-9, (seed, gi, tx, ty, smin, tau)
+    assert kept_total < 0.8 * loose_total, (kept_total, loose_total)
