@@ -373,6 +373,8 @@ def main():
                                    f"closed-form 3-NN scale init, {('dn-splatter loss stack (' + args.losses + ')') if args.losses else 'random dense cotangents'}",
                        "N": N, "Nv": Nv, "n_isects": I, "n_isects_sorted": I_sorted, "mean_isects_per_rank": i_all / world,
                        "mean_tile_list_len": round(I / T, 1), "pixels": P, "bin_policy": args.bin_policy,
+                       # every result row reports Nv, I and the mean number of Gaussians blended per pixel
+                       "mean_blended_gaussians_per_pixel": (round(counts[3] / P, 1) if counts else None),
                        "allreduce_bytes_per_step": wire,
                        "grads_in_flat_bucket": bool(all(arena.holds(gp[k].grad) for k in dp.GRAD_KEYS)),
                        "parallelism": (f"dp{world} (camera per GPU; per step {wire} B exchanged per GPU over RCCL: "
