@@ -28,6 +28,7 @@ For N > 1 also `multi_gpu`: exchange time exposed / hidden, bytes per GPU and pe
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -234,9 +235,15 @@ def main():
     torch.cuda.synchronize()
     timer = _lib.StageTimer(only=live)
     _lib.TIMER = timer
-    t0 = time.perf_counter()
     wire = 0
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # Python's cyclic garbage collector off for the timed region (as timeit does): a generation-2 pass over the interpreter's
+    # objects stalls the host for ~10 ms, i.e. four frames' worth of launches — seen as single 10 ms steps in a 30-step run
+    gc.collect()
+    gc.disable()
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
         wire = step()
@@ -245,6 +252,7 @@ def main():
     dp.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     _lib.TIMER = None
     elapsed = dp.max_over_ranks(elapsed, dev)
 
@@ -365,7 +373,8 @@ def main():
             "metric": "fwd+bwd frames/sec @1M Gaussians 1080p; HBM GB/s vs roofline",
             "value": round(fps_total, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "gpu_ms_per_step_p10_p50_p90": [q(0.1), q(0.5), q(0.9)], "higher_is_better": True,
+            "gpu_ms_per_step_p10_p50_p90": [q(0.1), q(0.5), q(0.9)], "gpu_ms_per_step_max": round(per_step[-1], 4),
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {N} random-init Gaussians, 1 camera/GPU {W}x{H}, SH degree 3 + "
                                    f"expected depth + per-Gaussian normals ({D_CH} channels, "
