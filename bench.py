@@ -59,6 +59,12 @@ WORKLOADS = {
 OUT_KEYS = ("rgb", "depth", "normal", "accumulation")
 STAGE_NAMES = ("dnsplat_project_fwd", "binning", "dnsplat_raster_fwd", "dnsplat_raster_bwd", "dnsplat_project_bwd")
 PROBE_STEPS = 3
+FIRST_TOUCH_STEPS = 2
+# The chip clocks down within milliseconds of idling and needs ~30 ms of load to come back (first steps after an idle gap:
+# 2.9, 3.06, 2.84, 2.79 ... ms against 2.53 ms from the twelfth on).  Everything untimed that makes the GPU wait for the host
+# (instrumented probe steps, the graph capture, gc.collect) therefore comes BEFORE this many untimed pre-roll steps, which are
+# followed without a gap by the W warm-up steps, the barrier + synchronize and the timed region.
+PREROLL_STEPS = 12
 SH_K = 16
 D_CH = 7
 
@@ -143,9 +149,14 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", type=int, default=None, help="time the CPU baseline on a centre crop of this size instead of a full frame")
-    ap.add_argument("--bin-policy", default="capacity", choices=["sync", "capacity"])
+    ap.add_argument("--bin-policy", default="deferred", choices=["sync", "capacity", "deferred"],
+                    help="how the host learns the frame's intersection count (dn-splatter_amd/_ops.py BIN_POLICY): 'deferred' never "
+                         "waits for it in the steady state (verified as soon as it has arrived, an overflow raises)")
     ap.add_argument("--dense-allreduce", action="store_true",
                     help="all-reduce the full 236 B/Gaussian bucket instead of exchanging the SH gradients as factors")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step (get_outputs + backward) as a captured HIP graph (dn-splatter_amd/graph.py): 'auto' = when the "
+                         "step has no collective in it (one rank) and runs the fused path; falls back to eager launches if the capture fails")
     ap.add_argument("--two-call", action="store_true", help="reference's two-pass sequence instead of the fused pass")
     ap.add_argument("--torch-postops", action="store_true", help="keep dn_model.py:526-603 in torch instead of the HIP epilogue")
     ap.add_argument("--losses", nargs="?", const="torch", default=None, choices=["torch", "fused"],
@@ -200,7 +211,7 @@ def main():
             torch.autograd.backward([out[k] for k in OUT_KEYS], [cot[k] for k in OUT_KEYS])
         return dp.allreduce_gradients(gp, arena, exchange=exchange)
 
-    for _ in range(args.warmup):
+    for _ in range(FIRST_TOUCH_STEPS):     # allocations, capacity guesses, code objects (the W warm-up steps come right before the timed region)
         step()
     # Stage breakdown: PROBE_STEPS fully instrumented steps OUTSIDE the timed region.  Bracketing all six stages with
     # HIP events costs ~80 us of stream time per frame (a ~6 us bubble per event pair, seen in the rocprofv3 timeline),
@@ -233,22 +244,89 @@ def main():
     live = ("dnsplat_bin_prepare", "dnsplat_bin_emit_sort") if dominant == "binning" else (dominant,)
     dp.barrier()
     torch.cuda.synchronize()
+    # ---- the step as a replayed HIP graph -------------------------------------------------------------------------------
+    # The bracket around the dominant stage is part of the graph: two one-thread kernels that append the device's wall clock to a
+    # ring (HIP events cannot be recorded into a graph under capture on ROCm 7.2).  Every replay of the timed region leaves its
+    # pair; the tick is calibrated below against HIP events around a stamped interval.
+    gstep, graph_note, stamps, tick_ms = None, None, None, None
+    want_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and exchange is None and not args.two_call
+                                        and not args.torch_postops)
+    if want_graph:
+        from dn_splatter_amd.graph import GraphedStep
+
+        def compute():
+            for k in dp.GRAD_KEYS:
+                gp[k].grad = None
+            out = renderer.get_outputs(cam)
+            if batch is not None and args.losses == "fused":
+                fused_loss.dn_loss_fused(out, batch, gp["scales"], counts=loss_counts).backward()
+            elif batch is not None:
+                torch_losses.dn_loss(out, batch, gp["scales"]).backward()
+            else:
+                torch.autograd.backward([out[k] for k in OUT_KEYS], [cot[k] for k in OUT_KEYS])
+
+        stamps = _lib.StampTimer(live, dev)
+
+        def before_capture(c):
+            _lib.TIMER = stamps
+
+        try:
+            renderer.forget()          # the autograd graph of the last eager frame (its AccumulateGrad nodes live on the eager stream)
+            gstep = GraphedStep(compute, params={k: gp[k] for k in dp.GRAD_KEYS}, before_capture=before_capture)
+        except Exception as e:      # the eager path is always there
+            if args.graph == "on":
+                raise
+            gstep, graph_note = None, f"graph capture failed, eager launches instead: {e!r}"
+            dns.set_bin_policy(args.bin_policy)
+        finally:
+            _lib.TIMER = None
+        if gstep is not None:
+            def step():     # noqa: F811
+                gstep()
+                return 0
     timer = _lib.StageTimer(only=live)
-    _lib.TIMER = timer
+    _lib.TIMER = None
     wire = 0
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     # Python's cyclic garbage collector off for the timed region (as timeit does): a generation-2 pass over the interpreter's
     # objects stalls the host for ~10 ms, i.e. four frames' worth of launches — seen as single 10 ms steps in a 30-step run
     gc.collect()
     gc.disable()
+    # pre-roll (see PREROLL_STEPS); with the graph it doubles as the calibration interval of the stamp clock: HIP events around
+    # an interval that two extra stamps delimit
+    if gstep is not None:
+        torch.cuda.synchronize()
+        stamps.reset()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        stamps.stamp(); c0.record()
+    for _ in range(PREROLL_STEPS):
+        step()
+    if gstep is not None:
+        c1.record(); stamps.stamp()
+        torch.cuda.synchronize()
+        r = stamps.ring[:int(stamps.cursor.item())].tolist()
+        tick_ms = c0.elapsed_time(c1) / float(r[-1] - r[0])
+    _lib.TIMER = None
+    for _ in range(args.warmup):
+        step()
+    if gstep is not None:
+        stamps.reset()
+    _lib.TIMER = timer if gstep is None else None
     dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks[0].record()
+    host_s = 0.0
     for i in range(args.steps):
+        h0 = time.perf_counter()
         wire = step()
+        host_s += time.perf_counter() - h0
         marks[i + 1].record()
     torch.cuda.synchronize()
+    from dn_splatter_amd import _ops as _ops_mod
+    _ops_mod.verify_pending_counts(dev, block=True)     # "deferred" bin policy: every frame's intersection count checked inside the timed region
+    if gstep is not None:
+        gstep.check()                                   # graph replays: no frame of the timed region overflowed its buffers
     dp.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -270,10 +348,16 @@ def main():
         by0 = torch.floor((xy_[:, 1] - r_) / 16).clamp(0, th_); by1 = torch.ceil((xy_[:, 1] + r_) / 16).clamp(0, th_)
         I = int((((bx1 - bx0) * (by1 - by0)) * (r_ > 0)).double().sum().item())
     stats = timer.summary()
+    live_ms = []
+    if gstep is not None:
+        live_ms = [t * tick_ms for t in stamps.intervals_ticks()]     # one bracket per entry point of the dominant stage and step
     stages = {}
     sb = stage_bytes(N, Nv, I, P, T)
     for name, b in sb.items():
-        ms = stage_ms(stats, name, args.steps) if name == dominant else probe_ms.get(name)
+        if name == dominant and gstep is not None:
+            ms = sum(live_ms) / max(args.steps, 1)
+        else:
+            ms = stage_ms(stats, name, args.steps) if name == dominant else probe_ms.get(name)
         if ms is None:
             continue
         stages[name] = {"ms": round(ms, 4), "alg_bytes": b, "GBps": round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
@@ -297,6 +381,10 @@ def main():
     for name, t in stage_traffic.items():
         if name in stages:
             stages[name]["hbm_traffic"] = t
+    if "binning" in stages:      # its two entry points (depth sort + counts | pair generation + tile sort), from the instrumented steps
+        for k in ("dnsplat_bin_prepare", "dnsplat_bin_emit_sort"):
+            if k in pstats:
+                stages["binning"][k + "_ms"] = round(pstats[k][1], 4)
     ach = stages[dominant]["GBps"]
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic,
@@ -374,6 +462,13 @@ def main():
             "value": round(fps_total, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "gpu_ms_per_step_p10_p50_p90": [q(0.1), q(0.5), q(0.9)], "gpu_ms_per_step_max": round(per_step[-1], 4),
+            "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 4),
+            "gpu_ms_per_step_series": [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(args.steps)],
+            "dominant_stage_ms_series": [round(x, 3) for x in live_ms] if live_ms else None,
+            "launch": ("one HIP graph replay per step; the dominant stage is bracketed inside the graph by device wall-clock stamps "
+                       f"(s_memrealtime, {1e6 * tick_ms:.3f} ns per tick calibrated against HIP events; {len(live_ms)} brackets in the "
+                       f"{args.steps} timed steps)") if gstep is not None
+                      else ("eager launches from Python" + (f" ({graph_note})" if graph_note else "")),
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {N} random-init Gaussians, 1 camera/GPU {W}x{H}, SH degree 3 + "

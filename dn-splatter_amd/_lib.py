@@ -18,7 +18,7 @@ _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["DNSPLAT_LIB"]).resolve() if os.environ.get("DNSPLAT_LIB") else _PKG_DIR / "libdnsplat.so"
 CSRC_DIR = _PKG_DIR / "csrc"
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 RECORD_FLOATS = 16
 MAX_CHANNELS = 8
 
@@ -66,6 +66,7 @@ class BinArgs(ctypes.Structure):
         ("n_isects", c_void_p), ("n_isects_host", c_void_p),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("splats", c_void_p), ("tight_tiles", c_int32),
+        ("tile_ends", c_void_p), ("skip_offsets_fill", c_int32), ("n_isects_max", c_void_p),
     ]
 
 
@@ -110,7 +111,7 @@ class RasterArgs(ctypes.Structure):
         ("v_splats", c_void_p),
         ("dn", ctypes.POINTER(DnPost)),
         ("n_cameras", c_int32), ("keep_masks", c_void_p), ("keep_mask_stride", c_int64), ("pair_counters", c_void_p),
-        ("saturation_flag", c_void_p), ("zero_fill", c_void_p), ("zero_fill_bytes", c_int64),
+        ("saturation_flag", c_void_p), ("tile_ends", c_void_p), ("zero_fill", c_void_p), ("zero_fill_bytes", c_int64),
     ]
 
 
@@ -130,6 +131,7 @@ class ProjGrads(ctypes.Structure):
 # every symbol include/dnsplat.h declares (tests/test_abi.py checks the .so exports all of them)
 EXPORTS = [
     "dnsplat_strerror", "dnsplat_abi_version",
+    "dnsplat_stamp",
     "dnsplat_project_fwd", "dnsplat_pack_splats",
     "dnsplat_bin_workspace_bytes", "dnsplat_bin_status_offset", "dnsplat_bin_prepare", "dnsplat_bin_emit_sort", "dnsplat_bin_isect_ids",
     "dnsplat_raster_fwd", "dnsplat_raster_bwd",
@@ -165,6 +167,7 @@ def lib() -> ctypes.CDLL:
         L.dnsplat_strerror.restype = ctypes.c_char_p
         L.dnsplat_strerror.argtypes = [ctypes.c_int]
         L.dnsplat_abi_version.restype = ctypes.c_int
+        L.dnsplat_stamp.argtypes = [c_void_p, c_void_p, ctypes.c_uint32, c_void_p]
         L.dnsplat_bin_workspace_bytes.restype = c_size_t
         L.dnsplat_bin_workspace_bytes.argtypes = [c_int32, c_int64, c_int32]
         L.dnsplat_bin_status_offset.restype = c_size_t
@@ -224,6 +227,32 @@ class StageTimer:
         return out
 
 
+class StampTimer:
+    """Brackets entry points with device time stamps instead of HIP events (dnsplat_stamp): the only bracket that can be part of
+    a frame captured into a HIP graph on ROCm 7.2.  Every call — and every REPLAY of a captured call — appends two stamps to a
+    ring on the device; ``intervals_ticks()`` returns them pairwise after a synchronize."""
+
+    RING = 1 << 14
+
+    def __init__(self, only, device):
+        self.only = set(only)
+        self.ring = torch.zeros(self.RING, dtype=torch.int64, device=device)
+        self.cursor = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def stamp(self) -> None:
+        check(lib().dnsplat_stamp(c_void_p(self.ring.data_ptr()), c_void_p(self.cursor.data_ptr()), self.RING,
+                                  c_void_p(torch.cuda.current_stream().cuda_stream)), "dnsplat_stamp")
+
+    def reset(self) -> None:
+        self.cursor.zero_()
+
+    def intervals_ticks(self):
+        n = int(self.cursor.item())
+        assert n <= self.RING and n % 2 == 0, n
+        r = self.ring[:n].tolist()
+        return [r[i + 1] - r[i] for i in range(0, n, 2)]
+
+
 TIMER = None  # set to a StageTimer to record
 
 
@@ -232,6 +261,12 @@ def run(name: str, fn, *args) -> None:
     t = TIMER
     if t is None or (t.only is not None and name not in t.only):
         check(fn(*args), name)
+        return
+    if isinstance(t, StampTimer):
+        t.stamp()
+        rc = fn(*args)
+        t.stamp()
+        check(rc, name)
         return
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)

@@ -79,6 +79,8 @@ class _Buffers:
     def __init__(self):
         self.ws: Dict[torch.device, Tensor] = {}
         self.pinned: Dict[torch.device, Tensor] = {}
+        self.ring: Dict[tuple, dict] = {}
+        self.n_max: Dict[tuple, Tensor] = {}     # "static" bin policy: running maximum of n_isects per (device, stream)
         self.capacity_hint: Dict[tuple, int] = {}
 
     @staticmethod
@@ -102,6 +104,24 @@ class _Buffers:
             cur = torch.zeros(1, dtype=torch.int64).pin_memory()
             self.pinned[key] = cur
         return cur
+
+    RING = 8
+
+    def ring_slot(self, device):
+        """("deferred" bin policy) the next (pinned int64 [1], event) pair of a small per-(device, stream) ring: the count of a
+        frame is copied into its own slot, so several frames can be in flight before the host looks at any of them."""
+        key = self._key(device)
+        ring = self.ring.get(key)
+        if ring is None:
+            mem = torch.zeros(self.RING, dtype=torch.int64).pin_memory()
+            ring = {"mem": mem, "events": [torch.cuda.Event() for _ in range(self.RING)], "next": 0, "pending": []}
+            self.ring[key] = ring
+        i = ring["next"]
+        ring["next"] = (i + 1) % self.RING
+        # the slot about to be reused must have been looked at: at most RING - 1 frames are ever unverified
+        while len(ring["pending"]) >= self.RING - 1:
+            ring["pending"][0].resolve()
+        return ring, ring["mem"][i:i + 1], ring["events"][i]
 
 
 BUFFERS = _Buffers()
@@ -142,13 +162,70 @@ def _grad_like(param: Tensor) -> Tensor:
 # "capacity": size the intersection buffers from the previous frames (x1.25), enqueue everything,
 #             then verify n_isects <= capacity while the compositing kernel already runs; an overflow
 #             re-runs the emit+composite with exact sizes.  No GPU bubble, always correct.
+# "deferred": as "capacity", but the host does not wait for the count at all: it is copied into a pinned ring slot and
+#             verified as soon as it has arrived (the frame's own backward, the next frame's binning, or whoever asks for
+#             n_isects first — whichever comes first, none of them blocks in the steady state).  The host can run a whole
+#             frame ahead of the GPU.  An overflow cannot be repaired after the fact: it RAISES (never silently wrong) and
+#             enlarges the capacity, so that re-running the step succeeds.  The first frame of a size runs in "sync" mode.
+# "static":   for frames captured into a HIP graph (graph.GraphedStep): the capacity is whatever earlier eager frames established
+#             and NOTHING on the host looks at the count; the device keeps a running maximum (dnsplat_bin_args.n_isects_max)
+#             that static_overflow() reads on demand.
 BIN_POLICY = {"mode": "sync"}
 
 
 def set_bin_policy(mode: str) -> None:
-    if mode not in ("sync", "capacity"):
+    if mode not in ("sync", "capacity", "deferred", "static"):
         raise ValueError(mode)
     BIN_POLICY["mode"] = mode
+
+
+class _PendingCount:
+    """The intersection count of one frame binned under the "deferred" policy, until the host has looked at it."""
+
+    def __init__(self, ring, slot, event, capacity, key):
+        self.ring, self.slot, self.event, self.capacity, self.key = ring, slot, event, capacity, key
+        self.n: Optional[int] = None
+
+    def ready(self) -> bool:
+        return self.n is not None or self.event.query()
+
+    def resolve(self) -> int:
+        """Waits for the count if it has not arrived yet, verifies it, returns it.  Raises on overflow."""
+        if self.n is None:
+            self.event.synchronize()
+            self.n = int(self.slot.item())
+            if self in self.ring["pending"]:
+                self.ring["pending"].remove(self)
+            hint = BUFFERS.capacity_hint.get(self.key, 0)
+            BUFFERS.capacity_hint[self.key] = max(hint, int(self.n * 1.25) + 4096)
+            if self.n > self.capacity:
+                raise _lib.DnsplatError(
+                    f"tile binning: {self.n} intersections exceed the capacity {self.capacity} guessed from earlier frames "
+                    "(bin policy 'deferred' verifies the count after the fact): the outputs and gradients of that frame are "
+                    "invalid. The capacity has been enlarged; run the step again (or use set_bin_policy('capacity'), which "
+                    "repairs an overflow itself at the price of one host wait per frame)")
+        return self.n
+
+
+def static_overflow(device, width: int, height: int, n_entries: int) -> Optional[int]:
+    """ "static" bin policy: the largest intersection count any frame of the current stream produced, if it exceeded the
+    capacity those frames ran with (their lists were then truncated), else None.  Synchronises."""
+    t = BUFFERS.n_max.get(_Buffers._key(device))
+    if t is None:
+        return None
+    n = int(t.item())
+    cap = BUFFERS.capacity_hint.get((device, n_entries, width, height), 0)
+    return n if n > cap else None
+
+
+def verify_pending_counts(device, block: bool = False) -> None:
+    """Looks at every deferred intersection count of the current stream that has arrived (all of them with ``block``)."""
+    ring = BUFFERS.ring.get(_Buffers._key(device))
+    if ring is None:
+        return
+    for p in list(ring["pending"]):
+        if block or p.ready():
+            p.resolve()
 
 
 # --------------------------------------------------------------------------------------------------
@@ -361,18 +438,50 @@ def project(means, quats, scales, opacities, *, coeffs=None, sh0=None, shN=None,
 # stage 2: binning
 
 
-@dataclass
 class Binning:
-    flatten_ids: Tensor      # [capacity] int32 (first n_isects valid); entry = camera * N + gaussian
-    tile_offsets: Tensor     # [C*T+1] int32
-    n_isects: int
-    tile_width: int
-    tile_height: int
-    n_cameras: int = 1
+    """flatten_ids [capacity] int32 (first n_isects valid; entry = camera * N + gaussian), tile_offsets [C*T+1] int32.
+    ``n_isects`` is known on return under the "sync" / "capacity" policies; under "deferred" reading it is what waits."""
+
+    def __init__(self, flatten_ids: Tensor, tile_offsets: Tensor, n_isects, tile_width: int, tile_height: int,
+                 n_cameras: int = 1, pending: Optional["_PendingCount"] = None, tile_ends: Optional[Tensor] = None,
+                 n_dev: Optional[Tensor] = None):
+        self.flatten_ids, self.tile_offsets = flatten_ids, tile_offsets
+        # tile_ends [C*T] (fused path): the list of tile t is [tile_offsets[t], tile_ends[t]); tile_offsets of EMPTY tiles are then
+        # not gsplat's (filled_offsets() gives those)
+        self.tile_ends, self._n_dev = tile_ends, n_dev
+        self._n, self.pending = n_isects, pending
+        self.tile_width, self.tile_height, self.n_cameras = tile_width, tile_height, n_cameras
+
+    @property
+    def n_isects(self) -> int:
+        if self.pending is not None:
+            self._n = self.pending.resolve()
+            self.pending = None
+        if self._n is None:                      # "static" policy: nobody has asked yet — read the device scalar (synchronises)
+            self._n = int(self._n_dev.item())
+            if self._n > self.flatten_ids.numel():
+                raise _lib.DnsplatError(f"tile binning: {self._n} intersections exceed the static capacity {self.flatten_ids.numel()}")
+        return self._n
+
+    def filled_offsets(self) -> Tensor:
+        """gsplat's isect_offsets [C*T+1]: an empty tile carries the offset of the next non-empty one."""
+        if self.tile_ends is None:
+            return self.tile_offsets
+        # the kernels left n_isects in the entries of the empty tiles: a suffix minimum is the same number
+        return torch.flip(torch.cummin(torch.flip(self.tile_offsets, [0]), 0).values, [0])
+
+    @n_isects.setter
+    def n_isects(self, v) -> None:
+        self._n, self.pending = v, None
+
+    def verify_if_ready(self) -> None:
+        if self.pending is not None and self.pending.ready():
+            _ = self.n_isects
 
 
 def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, width: int, height: int,
-              tile_size: int, after_emit=None, n_cameras: int = 1, tight_splats: Optional[Tensor] = None) -> Binning:
+              tile_size: int, after_emit=None, n_cameras: int = 1, tight_splats: Optional[Tensor] = None,
+              defer_ok: bool = False, want_ends: bool = False) -> Binning:
     """Stage 2 over ``n_cameras`` stacked projections (inputs flattened to [C*N, ...]).  ``after_emit(binning)`` (optional)
     is called right after the emit/sort kernels are enqueued and BEFORE any host wait, so the caller can queue the
     compositing kernel behind them; in "capacity" mode it is called again if the capacity guess turned out too small."""
@@ -397,11 +506,50 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
         a.workspace, a.workspace_bytes = _ptr(ws), ws.numel()
         # ``tiles`` were counted over the tight boxes (ProjCfg.tight_tiles): the emit kernel rebuilds them from the records
         a.splats, a.tight_tiles = _ptr(tight_splats), int(tight_splats is not None)
+        # the fused path keeps its lists to itself: [start, end) per tile instead of gsplat's offsets (no fill launch)
+        a.tile_ends, a.skip_offsets_fill = _ptr(tile_ends), int(tile_ends is not None)
+        a.n_isects_max = _ptr(BUFFERS.n_max.get(_Buffers._key(dev)))
         return a, ws
 
     tile_offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
+    tile_ends = torch.empty(T, dtype=torch.int32, device=dev) if want_ends else None
     mode = BIN_POLICY["mode"]
+    if mode == "deferred" and not defer_ok:
+        mode = "capacity"      # callers that hand n_isects / flatten_ids[:n] straight back (the drop-in calls) gain nothing from deferring
     hint = BUFFERS.capacity_hint.get(key, 0)
+    if mode == "static" and not defer_ok:
+        mode = "capacity"
+    if mode == "static" and hint:
+        # nothing on the host depends on the count (a frame captured into a HIP graph): the capacity is the hint, and the
+        # device keeps a running maximum of n_isects that static_overflow() compares with it whenever the caller likes
+        if _Buffers._key(dev) not in BUFFERS.n_max:
+            BUFFERS.n_max[_Buffers._key(dev)] = torch.zeros(1, dtype=torch.int64, device=dev)
+        capacity = hint
+        flatten_ids = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+        args, _ = make_args(capacity, flatten_ids, tile_offsets)
+        args.n_isects_host = None
+        _lib.run("dnsplat_bin_prepare", _lib.lib().dnsplat_bin_prepare, ctypes.byref(args), _stream())
+        _lib.run("dnsplat_bin_emit_sort", _lib.lib().dnsplat_bin_emit_sort, ctypes.byref(args), _stream())
+        b = Binning(flatten_ids, tile_offsets, None, tw, th, n_cameras, tile_ends=tile_ends, n_dev=n_dev)
+        if after_emit is not None:
+            after_emit(b)
+        return b
+    if mode == "deferred" and hint:
+        verify_pending_counts(dev)                     # earlier frames whose count has arrived meanwhile (no wait)
+        ring, slot, ev = BUFFERS.ring_slot(dev)
+        n_host = slot
+        capacity = hint
+        flatten_ids = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
+        args, _ = make_args(capacity, flatten_ids, tile_offsets)
+        _lib.run("dnsplat_bin_prepare", _lib.lib().dnsplat_bin_prepare, ctypes.byref(args), _stream())
+        ev.record()
+        _lib.run("dnsplat_bin_emit_sort", _lib.lib().dnsplat_bin_emit_sort, ctypes.byref(args), _stream())
+        pend = _PendingCount(ring, slot, ev, capacity, key)
+        ring["pending"].append(pend)
+        b = Binning(flatten_ids, tile_offsets, None, tw, th, n_cameras, pending=pend, tile_ends=tile_ends)
+        if after_emit is not None:
+            after_emit(b)
+        return b
     if mode == "capacity" and hint:
         capacity = hint
         flatten_ids = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
@@ -410,7 +558,7 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
         ev = torch.cuda.Event()
         ev.record()
         _lib.run("dnsplat_bin_emit_sort", _lib.lib().dnsplat_bin_emit_sort, ctypes.byref(args), _stream())
-        b = Binning(flatten_ids, tile_offsets, -1, tw, th, n_cameras)
+        b = Binning(flatten_ids, tile_offsets, -1, tw, th, n_cameras, tile_ends=tile_ends)
         if after_emit is not None:
             after_emit(b)
         ev.synchronize()  # waits for the (early) depth sort only; compositing keeps running
@@ -434,10 +582,46 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
     if ws1.data_ptr() != ws0.data_ptr():
         _lib.run("dnsplat_bin_prepare", _lib.lib().dnsplat_bin_prepare, ctypes.byref(args), _stream())
     _lib.run("dnsplat_bin_emit_sort", _lib.lib().dnsplat_bin_emit_sort, ctypes.byref(args), _stream())
-    b = Binning(flatten_ids, tile_offsets, n, tw, th, n_cameras)
+    b = Binning(flatten_ids, tile_offsets, n, tw, th, n_cameras, tile_ends=tile_ends)
     if after_emit is not None:
         after_emit(b)
     return b
+
+
+class LazyInfo(dict):
+    """An ``info`` dict some of whose entries are only computed when read (``lazy``: key -> thunk).  The fused path under the
+    "deferred" bin policy uses it for ``n_isects`` / ``flatten_ids[:n_isects]``, which need the intersection count on the
+    host: reading them is what waits for it, rendering a frame is not."""
+
+    def __init__(self, eager: dict, lazy: dict):
+        super().__init__(eager)
+        self._lazy = dict(lazy)
+        for k in lazy:
+            super().__setitem__(k, None)
+
+    def _force(self, k):
+        thunk = self._lazy.pop(k, None)
+        if thunk is not None:
+            super().__setitem__(k, thunk())
+
+    def __getitem__(self, k):
+        self._force(k)
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        if k in self:
+            return self[k]
+        return default
+
+    def items(self):
+        for k in list(self._lazy):
+            self._force(k)
+        return super().items()
+
+    def values(self):
+        for k in list(self._lazy):
+            self._force(k)
+        return super().values()
 
 
 def binning_status(b: Binning, n_entries: int) -> int:
@@ -630,6 +814,7 @@ class _RasterDnFn(torch.autograd.Function):
                 a.keep_masks, a.keep_mask_stride = _ptr(keep["masks"]), stride
             a.width, a.height, a.tile_size, a.D = width, height, 16, 7
             a.splats, a.flatten_ids, a.tile_offsets = _ptr(splats), _ptr(b.flatten_ids), _ptr(b.tile_offsets)
+            a.tile_ends = _ptr(b.tile_ends)
             a.background = _ptr(bg7)
             a.ed_channel = 3
             a.render, a.alphas, a.last_ids = _ptr(render), _ptr(alphas), _ptr(last_ids)
@@ -640,7 +825,8 @@ class _RasterDnFn(torch.autograd.Function):
             _lib.run("dnsplat_raster_fwd", _lib.lib().dnsplat_raster_fwd, ctypes.byref(a), _stream())
 
         b = bin_tiles(means2d.detach().reshape(-1, 2), radii.reshape(-1), depths.detach().reshape(-1), tiles.reshape(-1), width,
-                      height, 16, after_emit=composite, n_cameras=C, tight_splats=splats.detach() if tight else None)
+                      height, 16, after_emit=composite, n_cameras=C, tight_splats=splats.detach() if tight else None,
+                      defer_ok=True, want_ends=True)
         for c in range(C):
             fx, fy, cx, cy = intr[c]
             _lib.run("dnsplat_dn_depth_normals", _lib.lib().dnsplat_dn_depth_normals, width, height, fx, fy, cx, cy,
@@ -649,6 +835,7 @@ class _RasterDnFn(torch.autograd.Function):
             holder["binning"] = b
         ctx.save_for_backward(means2d, splats, b.flatten_ids, b.tile_offsets, render, alphas, last_ids, bg_rgb)
         ctx.keep = keep
+        ctx.binning = b
         ctx.v_splats = fill["v_splats"]
         ctx.cfg = (width, height, absgrad, C, counters)
         ctx.set_materialize_grads(False)
@@ -661,6 +848,7 @@ class _RasterDnFn(torch.autograd.Function):
         width, height, absgrad, C, counters = ctx.cfg
         N = splats.shape[0]
         dev = splats.device
+        ctx.binning.verify_if_ready()     # "deferred" bin policy: the frame's count has normally arrived by now (never waits)
         # cleared by the forward launch of this frame; a second backward through the same graph gets a fresh one
         v_splats, ctx.v_splats = ctx.v_splats, None
         if v_splats is None:
@@ -678,6 +866,7 @@ class _RasterDnFn(torch.autograd.Function):
         a.n_cameras = C
         a.width, a.height, a.tile_size, a.D = width, height, 16, 7
         a.splats, a.flatten_ids, a.tile_offsets = _ptr(splats), _ptr(flatten_ids), _ptr(tile_offsets)
+        a.tile_ends = _ptr(ctx.binning.tile_ends)
         a.background = _ptr(_bg7(dev))
         a.ed_channel = 3
         a.render, a.alphas, a.last_ids = _ptr(render), _ptr(alphas), _ptr(last_ids)

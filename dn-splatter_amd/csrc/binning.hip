@@ -7,13 +7,16 @@
 // Same result, different route.  The reference sorts I = n_isects 12-byte pairs on ~45 key bits
 // (6 radix passes over I).  Here:
 //   1. the N Gaussians are stably radix-sorted once by their 32 depth bits (4 passes over N, N << I);
-//   2. (tile, gaussian) pairs are emitted in that depth order — one wave per 64 Gaussians, lanes
-//      write a Gaussian's tiles cooperatively so stores are coalesced;
+//   2. the (tile, gaussian) pairs of that depth order are never written out as such: the FIRST pass of the tile
+//      sort generates them on the fly — once to count its digits, once to place them (each workgroup owns 4096
+//      consecutive pairs of the emission order and finds the Gaussians they belong to through a 16-byte record
+//      per depth-ordered Gaussian and an LDS prefix maximum) — so the emission costs neither a launch nor the
+//      12 B/pair round trip through HBM;
 //   3. the pairs are stably radix-sorted on the tile id alone (ceil(log2(T)/8) = 2 passes over I),
 //      with 16-bit tile keys; the last pass stores no keys and yields the tile offsets on the way.
 // A stable sort by tile of a depth-ordered stream is exactly the (tile, depth, emission index)
 // order the reference's stable 64-bit sort yields, so flatten_ids / tile offsets are bit-identical
-// while the I-sized traffic drops from 6 passes x 12 B to 2 passes x 6 B (4 B in the last one).
+// while the I-sized traffic drops from 6 passes x 12 B to one 6-byte store, one 6-byte load and a 4-byte store.
 //
 // All ranking inside a radix pass is done with wave64 ballots (match-by-digit) and LDS counters:
 // no atomics on the data path (the tile offsets are an atomicMin per (chunk, tile) run), fully
@@ -87,30 +90,125 @@ __device__ __forceinline__ uint32_t depth_key(const int32_t *__restrict__ radii,
     return radii[g] > 0 ? __float_as_uint(depths[g]) : 0xFFFFFFFFu;
 }
 
+// Everything a workgroup needs to re-create "its" 4096 consecutive pairs of the emission order (GEN instantiations of the
+// histogram and scatter kernels = the first pass of the tile sort).
+struct __align__(16) EmitRec {
+    uint32_t gid;        // entry index (camera * N + gaussian): the pair's value
+    uint32_t start;      // position of the Gaussian's first pair in the emission order (= cum[j - 1])
+    uint32_t base_tile;  // tile id of the first tile of its box (row-major over the stacked tile grids of the batch)
+    uint32_t bw;         // box width in tiles
+};
+struct GenArgs {
+    const EmitRec *__restrict__ jrec;        // [N] by depth rank j
+    const uint32_t *__restrict__ cum;        // [N] inclusive pair counts by depth rank
+    const uint32_t *__restrict__ chunk_first;   // [nb] depth rank of the Gaussian that holds pair chunk * CHUNK
+    int N, tw;
+    int exact;                               // floor((t + 0.5) / bw) through an fp32 reciprocal is exact (see gen_pair)
+};
+
+constexpr int gen_pad(int i) { return i + (i >> 5); }      // one pad word per 32: a thread's 16 consecutive slots stay conflict-free
+
+// owner[gen_pad(i)], i < CHUNK := 1 + (depth rank - j0) of the Gaussian that emits pair q0 + i.  Every Gaussian marks the slot of
+// its first pair inside the chunk, a prefix maximum spreads the mark over its pairs.  Returns j0.
+template <int ITEMS>
+__device__ __forceinline__ uint32_t gen_owners(uint32_t *owner, uint32_t *lds_wave /*[4]*/, const GenArgs &g, uint32_t chunk,
+                                               uint32_t q0, uint32_t n_valid)
+{
+    constexpr int CHUNK = RS_THREADS * ITEMS;
+    for (int i = threadIdx.x; i < gen_pad(CHUNK); i += RS_THREADS) owner[i] = 0u;
+    const uint32_t j0 = g.chunk_first[chunk];
+    __syncthreads();
+    for (uint32_t jb = j0;; jb += RS_THREADS) {
+        const uint32_t jj = jb + threadIdx.x;
+        bool inside = false;       // this Gaussian starts before the end of the chunk (cum is non-decreasing: so do all before it)
+        if (jj < (uint32_t)g.N) {
+            const uint32_t e = g.cum[jj], s = jj ? g.cum[jj - 1] : 0u;
+            inside = s < q0 + n_valid;
+            if (inside && e > s && e > q0) owner[gen_pad((int)(max(s, q0) - q0))] = jj - j0 + 1u;
+        }
+        // another round only if the last Gaussian of this one still started inside the chunk
+        if (!__syncthreads_or(inside && threadIdx.x == RS_THREADS - 1)) break;
+    }
+    // prefix maximum: thread t owns slots [t * ITEMS, (t + 1) * ITEMS)
+    uint32_t loc[ITEMS];
+    uint32_t m = 0u;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        m = max(m, owner[gen_pad(threadIdx.x * ITEMS + i)]);
+        loc[i] = m;
+    }
+    uint32_t inc = m;
+#pragma unroll
+    for (int off = 1; off < DNS_WAVE; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off, DNS_WAVE);
+        if ((int)lane_id() >= off) inc = max(inc, t);
+    }
+    const int w = threadIdx.x / DNS_WAVE;
+    if (lane_id() == DNS_WAVE - 1) lds_wave[w] = inc;
+    __syncthreads();
+    uint32_t before = __shfl_up(inc, 1, DNS_WAVE);
+    if (lane_id() == 0) before = 0u;
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; ++i)
+        if (i < w) before = max(before, lds_wave[i]);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) owner[gen_pad(threadIdx.x * ITEMS + i)] = max(loc[i], before);
+    __syncthreads();
+    return j0;
+}
+
+// pair q0 + i of the emission order: (tile id, entry).  The Gaussian's tiles are emitted row-major over its box, the
+// reference's order; floor((t + 0.5) / bw) through an fp32 reciprocal is exact for t < 2^16 tiles and bw <= 256 tile columns
+// (far inside the 0.5 / bw margin), otherwise the integer division is used.
+__device__ __forceinline__ void gen_pair(const uint32_t *owner, const GenArgs &g, uint32_t j0, uint32_t q0, uint32_t i,
+                                         uint32_t &key, uint32_t &val)
+{
+    const uint32_t o = owner[gen_pad((int)i)];
+    const uint4 r = *reinterpret_cast<const uint4 *>(g.jrec + (j0 + o - 1u));
+    const uint32_t t = q0 + i - r.y;
+    uint32_t row;
+    if (g.exact) row = (uint32_t)(((float)t + 0.5f) * (1.f / (float)r.w));
+    else row = t / r.w;
+    key = r.z + row * (uint32_t)g.tw + (t - row * r.w);
+    val = r.x;
+}
+
 // FIRST = first pass of the depth sort (keys synthesised from radii / depths, n given by value: n_ptr may be NULL)
-template <typename K, int ITEMS, bool FIRST = false>
+// GEN = first pass of the tile sort: the keys are the tile ids of the pairs the workgroup re-creates (see GenArgs)
+template <typename K, int ITEMS, bool FIRST = false, bool GEN = false>
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const K *__restrict__ keys,
                                                                 const uint32_t *__restrict__ n_ptr, uint32_t n_cap,
                                                                 int shift, uint32_t mask, uint32_t *__restrict__ table,
                                                                 int nb, const int32_t *__restrict__ radii = nullptr,
                                                                 const float *__restrict__ depths = nullptr,
-                                                                int32_t *__restrict__ tile_first = nullptr, int n_tiles = 0)
+                                                                int32_t *__restrict__ tile_first = nullptr, int n_tiles = 0,
+                                                                int32_t *__restrict__ tile_end = nullptr, GenArgs gen = GenArgs{},
+                                                                uint32_t *__restrict__ status = nullptr)
 {
     __shared__ uint32_t hist[RS_DIGITS];
+    __shared__ uint32_t owner[GEN ? gen_pad(RS_THREADS * ITEMS) : 1];
+    __shared__ uint32_t lds_wave[RS_WAVES];
     const uint32_t n = n_ptr ? min(*n_ptr, n_cap) : n_cap;
     // first pass of the tile sort: also presets the tile offsets to n (the last scatter pass lowers the non-empty tiles'
-    // entries with atomicMin, tile_offsets_fill gives the empty ones the offset of the next non-empty tile)
+    // entries with atomicMin, tile_offsets_fill gives the empty ones the offset of the next non-empty tile) and the tile ends to 0
     if (tile_first)
         for (int i = blockIdx.x * RS_THREADS + threadIdx.x; i <= n_tiles; i += gridDim.x * RS_THREADS) tile_first[i] = (int32_t)n;
+    if (tile_end)
+        for (int i = blockIdx.x * RS_THREADS + threadIdx.x; i < n_tiles; i += gridDim.x * RS_THREADS) tile_end[i] = 0;
+    if (status && blockIdx.x == 0 && threadIdx.x == 0) *status = 0u;
     hist[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * (RS_THREADS * ITEMS);
     if (base < n) {
+        uint32_t j0 = 0;
+        if (GEN) j0 = gen_owners<ITEMS>(owner, lds_wave, gen, blockIdx.x, base, min((uint32_t)(RS_THREADS * ITEMS), n - base));
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             uint32_t idx = base + i * RS_THREADS + threadIdx.x;
             if (idx < n) {
-                const uint32_t k = FIRST ? depth_key(radii, depths, idx) : (uint32_t)keys[idx];
+                uint32_t k;
+                if (GEN) { uint32_t v; gen_pair(owner, gen, j0, base, idx - base, k, v); }
+                else k = FIRST ? depth_key(radii, depths, idx) : (uint32_t)keys[idx];
                 atomicAdd(&hist[(k >> shift) & mask], 1u);
             }
         }
@@ -149,80 +247,6 @@ __global__ __launch_bounds__(SC_THREADS) void radix_scan_kernel(uint32_t *__rest
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Decoupled look-back (DNS_BIN_LOOKBACK, the I-sized tile passes).  The table-based pass needs, per radix pass, a histogram
-// launch that reads every key again and a scan launch over (digits x chunks) counters before the scatter can place anything.
-// With look-back a chunk publishes its own per-digit counts ("aggregate"), then walks back over the chunks before it,
-// adding their aggregates until it meets one that already knows its inclusive prefix, and publishes its own inclusive prefix:
-// the prefix over chunks is computed INSIDE the scatter launch.  What it needs from outside are only the GLOBAL digit totals
-// of every pass, which one launch computes for all passes at once (tile_digit_totals_kernel).
-//   * A chunk's number is a ticket drawn at workgroup start, so every chunk a workgroup waits for has started before it:
-//     waiting never depends on a workgroup that is not resident yet, whatever order the dispatcher uses.
-//   * A descriptor is ONE 64-bit word (2 status bits + count) written and read with agent-scope atomics — it is its own
-//     payload, nothing else has to become visible with it (the per-XCD L2s are not coherent with each other).
-//   * Every spin is bounded by the 100 MHz wall clock; on expiry the chunk records it in *fail and carries on with what it
-//     has (wrong lists, but the launch always ends).
-constexpr unsigned long long LB_AGG = 1ull << 62, LB_INC = 2ull << 62, LB_VAL = (1ull << 62) - 1ull;
-constexpr unsigned long long LB_SPIN_TICKS = 20ull * 100000ull;      // 20 ms
-
-__device__ __forceinline__ void lb_store(unsigned long long *p, unsigned long long v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long lb_load(const unsigned long long *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Global digit totals of up to three passes over the emitted tile keys (one read of the keys), and the zero state of the
-// look-back descriptors and tickets of those passes.  totals: [3][256], tickets: [3], desc: [n_desc] words.
-template <typename K, int ITEMS>
-__global__ __launch_bounds__(RS_THREADS) void tile_digit_totals_kernel(const K *__restrict__ keys, const uint32_t *__restrict__ n_ptr,
-                                                                       uint32_t n_cap, int passes, int shift1, int shift2,
-                                                                       uint32_t mask0, uint32_t mask1, uint32_t mask2,
-                                                                       uint32_t *__restrict__ totals,
-                                                                       unsigned long long *__restrict__ desc, size_t n_desc,
-                                                                       int32_t *__restrict__ tile_first, int n_tiles)
-{
-    __shared__ uint32_t hist[3][RS_DIGITS];
-    const uint32_t n = min(*n_ptr, n_cap);
-    for (size_t i = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; i < n_desc; i += (size_t)gridDim.x * RS_THREADS) desc[i] = 0ull;
-    // the tile offsets start at n (the last scatter pass lowers the non-empty tiles' entries with atomicMin)
-    for (int i = blockIdx.x * RS_THREADS + threadIdx.x; i <= n_tiles; i += gridDim.x * RS_THREADS) tile_first[i] = (int32_t)n;
-    hist[0][threadIdx.x] = 0; hist[1][threadIdx.x] = 0; hist[2][threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * (RS_THREADS * ITEMS);
-    if (base < n) {
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const uint32_t idx = base + i * RS_THREADS + threadIdx.x;
-            if (idx < n) {
-                const uint32_t k = (uint32_t)keys[idx];
-                atomicAdd(&hist[0][k & mask0], 1u);
-                if (passes > 1) {
-                    // consecutive entries share their high digits almost always: count once per run of equal digits in the wave
-                    const uint32_t d1 = (k >> shift1) & mask1;
-                    const uint32_t prev1 = __shfl_up(d1, 1, DNS_WAVE);
-                    const bool head1 = lane_id() == 0 || prev1 != d1;
-                    const uint64_t heads = dns_ballot(head1);
-                    const int n_act = __popcll(dns_ballot(true));                           // the active lanes are lanes 0 .. n_act-1
-                    if (head1) {
-                        const uint64_t after = heads & ~((2ull << lane_id()) - 1ull);       // next run head above this lane
-                        const int end = after ? __ffsll((unsigned long long)after) - 1 : n_act;
-                        atomicAdd(&hist[1][d1], (uint32_t)(end - (int)lane_id()));
-                    }
-                }
-                if (passes > 2) atomicAdd(&hist[2][(k >> shift2) & mask2], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    for (int p = 0; p < passes; ++p) {
-        const uint32_t c = hist[p][threadIdx.x];
-        if (c) atomicAdd(&totals[p * RS_DIGITS + threadIdx.x], c);
-    }
-}
-
 // DBITS = digit width of this pass (<= 8): the tile passes split their 13 bits 7 + 6 instead of 8 + 8 — fewer
 // ballots per key and longer per-digit runs for the coalesced run stores.
 //
@@ -230,15 +254,16 @@ __global__ __launch_bounds__(RS_THREADS) void tile_digit_totals_kernel(const K *
 // a tile's entries start is.  Inside one digit's run of the LDS-sorted chunk the keys are non-decreasing (the stream
 // was already sorted on the lower bits and the pass is stable), so "key differs from its left neighbour" marks the
 // chunk-local first entry of a tile; the minimum of those positions over the chunks is the tile's offset.
-// LOOKBACK: the count of the chunks before this one comes from the descriptors of those chunks (see above) instead of a
-// precomputed table; `totals` are then the pass's global digit totals from tile_digit_totals_kernel.
-template <typename K, bool LAST, int DBITS, int ITEMS, bool FIRST = false, bool LOOKBACK = false>
+// GEN: the first pass of the tile sort — keys / values are the pairs the workgroup re-creates (GenArgs), nothing is read.
+// tile_end (LAST, optional): one past the last entry of every non-empty tile, so that a consumer that takes both arrays needs
+// no suffix-minimum fill of the offsets of the empty tiles.
+template <typename K, bool LAST, int DBITS, int ITEMS, bool FIRST = false, bool GEN = false>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ n_ptr, uint32_t n_cap, int shift,
     const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nb, int32_t *__restrict__ tile_first,
     const int32_t *__restrict__ radii = nullptr, const float *__restrict__ depths = nullptr,
-    unsigned long long *__restrict__ desc = nullptr, uint32_t *__restrict__ ticket = nullptr, uint32_t *__restrict__ fail = nullptr)
+    int32_t *__restrict__ tile_end = nullptr, GenArgs gen = GenArgs{})
 {
     // The chunk is first sorted by digit INSIDE LDS (stable), then written out run by run: consecutive lanes
     // store to consecutive addresses of one digit's run, so the stores coalesce.  A direct scatter from the
@@ -250,17 +275,12 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     __shared__ uint32_t gbase[RS_DIGITS];                // global start of this chunk's run of a digit
     constexpr int CHUNK = RS_THREADS * ITEMS;
     __shared__ K keys_s[CHUNK];
-    __shared__ uint32_t vals_s[CHUNK];
+    // GEN: the owner table (dead once the pairs sit in registers) shares the memory of the value staging area
+    __shared__ uint32_t vals_s[GEN ? gen_pad(CHUNK) : CHUNK];
     __shared__ uint32_t lds_wave[4];
     constexpr uint32_t DMASK = (1u << DBITS) - 1u;
     const uint32_t n = n_ptr ? min(*n_ptr, n_cap) : n_cap;
-    uint32_t chunk = blockIdx.x;
-    if (LOOKBACK) {
-        __shared__ uint32_t ticket_s;
-        if (threadIdx.x == 0) ticket_s = atomicAdd(ticket, 1u);
-        __syncthreads();
-        chunk = ticket_s;
-    }
+    const uint32_t chunk = blockIdx.x;
     const uint32_t base = chunk * CHUNK;
     if (base >= n) return;
     const uint32_t n_valid = min((uint32_t)CHUNK, n - base);
@@ -271,14 +291,25 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     // after the ranking (two loads that depend on nothing and otherwise sit exposed between two barriers)
     const bool is_digit = threadIdx.x <= DMASK;
     const uint32_t pre_tot = is_digit ? totals[threadIdx.x] : 0u;
-    const uint32_t pre_tab = (is_digit && !LOOKBACK) ? table[(size_t)threadIdx.x * nb + blockIdx.x] : 0u;
+    const uint32_t pre_tab = is_digit ? table[(size_t)threadIdx.x * nb + blockIdx.x] : 0u;
 
 #pragma unroll
     for (int i = 0; i < RS_WAVES; ++i) wave_cnt[i][threadIdx.x] = 0;
-    __syncthreads();
+    uint32_t j0 = 0;
+    if (GEN) j0 = gen_owners<ITEMS>(vals_s, lds_wave, gen, chunk, base, n_valid);
+    else __syncthreads();
 
     uint32_t key[ITEMS], val[ITEMS], rnk[ITEMS];
     const uint32_t wave_start = base + w * (DNS_WAVE * ITEMS);
+    if (GEN) {
+        // all pairs first: the owner table is overwritten by the staging stores below
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const uint32_t idx = wave_start + r * DNS_WAVE + lane;
+            key[r] = 0u; val[r] = 0u;
+            if (idx < n) gen_pair(vals_s, gen, j0, base, idx - base, key[r], val[r]);
+        }
+    }
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const uint32_t idx = wave_start + r * DNS_WAVE + lane;
@@ -286,7 +317,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         if (FIRST) {
             key[r] = valid ? depth_key(radii, depths, idx) : 0u;
             val[r] = idx;
-        } else {
+        } else if (!GEN) {
             key[r] = valid ? (uint32_t)keys_in[idx] : 0u;
             val[r] = valid ? vals_in[idx] : 0u;
         }
@@ -321,32 +352,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         // global base = (#keys with smaller digit) + (#same digit in earlier chunks)
         const uint32_t tot = pre_tot;
         const uint32_t ginc = block_incl_scan_256(tot, lds_wave, t2);
-        uint32_t before = pre_tab;
-        if (LOOKBACK && is_digit) {
-            constexpr int DIGITS = 1 << DBITS;
-            unsigned long long *mine = desc + (size_t)chunk * DIGITS + threadIdx.x;
-            if (chunk == 0) {
-                lb_store(mine, LB_INC | cnt);
-            } else {
-                lb_store(mine, LB_AGG | cnt);
-                unsigned long long sum = 0;
-                const unsigned long long t_end = wall_clock64() + LB_SPIN_TICKS;
-                for (int c = (int)chunk - 1; c >= 0; --c) {
-                    const unsigned long long *theirs = desc + (size_t)c * DIGITS + threadIdx.x;
-                    unsigned long long v = lb_load(theirs);
-                    while ((v >> 62) == 0ull) {
-                        if (wall_clock64() > t_end) { atomicOr(fail, 1u); v = LB_INC; break; }
-                        __builtin_amdgcn_s_sleep(1);
-                        v = lb_load(theirs);
-                    }
-                    sum += v & LB_VAL;
-                    if ((v >> 62) == 2ull) break;
-                }
-                before = (uint32_t)sum;
-                lb_store(mine, LB_INC | (sum + cnt));
-            }
-        }
-        gbase[threadIdx.x] = is_digit ? (ginc - tot) + before : 0u;
+        gbase[threadIdx.x] = is_digit ? (ginc - tot) + pre_tab : 0u;
     }
     __syncthreads();
 #pragma unroll
@@ -370,6 +376,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
             if (!LAST) keys_out[dst] = (K)k;
             vals_out[dst] = vals_s[i];
             if (LAST && (i == 0 || (uint32_t)keys_s[i - 1] != k)) atomicMin(&tile_first[k], (int32_t)dst);
+            if (LAST && tile_end && (i + 1 == n_valid || (uint32_t)keys_s[i + 1] != k)) atomicMax(&tile_end[k], (int32_t)dst + 1);
         }
     }
 }
@@ -393,11 +400,23 @@ __global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(int N, const uint
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
 
+// What the pair generators of the tile sort's first pass need per Gaussian (EmitRec, by depth rank) and per 4096-pair chunk
+// (the depth rank of the Gaussian that holds the chunk's first pair) is written by the same kernel.
+struct EmitPrep {
+    EmitRec *__restrict__ jrec;
+    uint32_t *__restrict__ chunk_first;
+    int nb_chunks, chunk;                // chunk = pairs per workgroup of the tile passes
+    int n_per_cam, tile_size, tw, th;
+    const float *__restrict__ means2d;
+    const int32_t *__restrict__ radii;
+    const float4 *__restrict__ splats;   // tight tile boxes (dnsplat_bin_args.tight_tiles): the box the projection kernel counted
+};
+
 __global__ __launch_bounds__(SC_THREADS) void scan_final_kernel(int N, const uint32_t *__restrict__ order,
                                                                 const int32_t *__restrict__ tiles,
                                                                 const uint32_t *__restrict__ sums,
                                                                 uint32_t *__restrict__ cum, uint32_t *__restrict__ total_u32,
-                                                                int64_t *__restrict__ total_i64)
+                                                                int64_t *__restrict__ total_i64, int64_t *__restrict__ total_max)
 {
     __shared__ uint32_t lds_wave[4];
     const int base = blockIdx.x * SC_CHUNK + threadIdx.x * SC_ITEMS;
@@ -424,80 +443,39 @@ __global__ __launch_bounds__(SC_THREADS) void scan_final_kernel(int N, const uin
         run += v[i];
         if (j < N) {
             cum[j] = run;
-            if (j == N - 1) { *total_u32 = run; *total_i64 = (int64_t)run; }
+            if (j == N - 1) {
+                *total_u32 = run; *total_i64 = (int64_t)run;
+                // sticky maximum over the frames since the caller last cleared it: lets a host that never waits for a single
+                // frame's count (captured HIP graphs) still find out, later, whether any frame exceeded its capacity
+                if (total_max) atomicMax(reinterpret_cast<unsigned long long *>(total_max), (unsigned long long)run);
+            }
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// 4. emission in depth order.  One wave owns 64 consecutive sorted Gaussians; those that hit tiles are taken two at
-// a time, each half of the wave writing one Gaussian's (tile, gaussian) pairs side by side (row-major over its tile
-// bbox, the reference's emission order).  The kernel is instruction-bound (a visible Gaussian covers ~30 tiles, less
-// than a wave), hence two per round and a float reciprocal instead of the integer division for (row, column):
-// floor((t + 0.5) / bw) is exact in fp32 for t < 2^16 tiles and bw <= 256 tile columns, far inside the 0.5 / bw margin.
-template <typename K>
-__global__ __launch_bounds__(256) void emit_kernel(int N, int n_per_cam, const uint32_t *__restrict__ order,
-                                                   const uint32_t *__restrict__ cum,
-                                                   const float *__restrict__ means2d, const int32_t *__restrict__ radii,
-                                                   int tile_size, int tw, int th, uint32_t cap,
-                                                   K *__restrict__ tkeys, uint32_t *__restrict__ tvals,
-                                                   uint32_t *__restrict__ lb_ctl = nullptr, int lb_ctl_words = 0,
-                                                   const float4 *__restrict__ splats = nullptr)
+// one thread per depth rank j: the Gaussian's EmitRec and the heads of the pair chunks that start inside its pairs
+__global__ __launch_bounds__(256) void emit_prep_kernel(int N, const uint32_t *__restrict__ order, const uint32_t *__restrict__ cum,
+                                                        EmitPrep ep)
 {
-    // the look-back control words (digit totals, tickets, failure flag) of the tile passes that follow start at zero
-    if (lb_ctl && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < lb_ctl_words; i += blockDim.x) lb_ctl[i] = 0u;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lane = lane_id();
-    uint32_t gid = 0, end = 0, start = 0;
-    int x0 = 0, y0 = 0, bw = 1;
-    if (j < N) {
-        gid = order[j];
-        end = cum[j];
-        start = (j == 0) ? 0u : cum[j - 1];
-        if (end > start) {
-            int x1, y1;
-            if (splats) {      // tight tile boxes (dnsplat_bin_args.tight_tiles): the box the projection kernel counted
-                const float4 r0 = splats[(size_t)gid * 4], r1 = splats[(size_t)gid * 4 + 1];
-                dns_snug_tile_bbox(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, (float)radii[gid], tile_size, tw, th, x0, y0, x1, y1);
-            } else
-                dns_tile_bbox(means2d[2 * gid], means2d[2 * gid + 1], (float)radii[gid], tile_size, tw, th, x0, y0, x1, y1);
-            bw = x1 - x0;
-            // batch of cameras: entry gid belongs to camera gid / n_per_cam, whose tile grid is stacked below the previous
-            // cameras' (tile id = camera * tw * th + row * tw + column) — folded into the first tile row of the box
-            if (n_per_cam < N) y0 += (int)(gid / (uint32_t)n_per_cam) * th;
-        }
-    }
-    const bool exact = tw <= 256 && (N / n_per_cam) * tw * th <= 65536;      // the fp32 reciprocal route is exact
-    uint64_t todo = dns_ballot(end > start);
-    const uint32_t half = lane >> 5, hl = lane & 31;
-    while (todo) {
-        const int src0 = __ffsll((unsigned long long)todo) - 1;
-        todo &= todo - 1;
-        int src1 = -1;
-        if (todo) { src1 = __ffsll((unsigned long long)todo) - 1; todo &= todo - 1; }
-        const int src = half ? src1 : src0;
-        const int from = src < 0 ? 0 : src;
-        const uint32_t s_gid = __shfl(gid, from, DNS_WAVE);
-        const uint32_t s_start = __shfl(start, from, DNS_WAVE);
-        // every shuffle is executed by the whole wave: under a lane-dependent branch the lanes that skip it are inactive
-        // SOURCES as well, and ds_bpermute returns 0 for them
-        const uint32_t s_end = __shfl(end, from, DNS_WAVE);
-        const uint32_t s_cnt = src < 0 ? 0u : s_end - s_start;
-        const int s_x0 = __shfl(x0, from, DNS_WAVE), s_y0 = __shfl(y0, from, DNS_WAVE), s_bw = __shfl(bw, from, DNS_WAVE);
-        const float inv_bw = 1.f / (float)s_bw;
-        for (uint32_t t = hl; t < s_cnt; t += 32) {
-            const uint32_t dst = s_start + t;
-            if (dst < cap) {
-                int row;
-                if (exact) row = (int)(((float)t + 0.5f) * inv_bw);
-                else row = (int)(t / (uint32_t)s_bw);
-                const int colm = (int)t - row * s_bw;
-                tkeys[dst] = (K)((s_y0 + row) * tw + s_x0 + colm);
-                tvals[dst] = s_gid;
-            }
-        }
-    }
+    if (j >= N) return;
+    const uint32_t end = cum[j], start = j ? cum[j - 1] : 0u;
+    if (end <= start) return;
+    const uint32_t gid = order[j];
+    int x0, y0, x1, y1;
+    if (ep.splats) {
+        const float4 r0 = ep.splats[(size_t)gid * 4], r1 = ep.splats[(size_t)gid * 4 + 1];
+        dns_snug_tile_bbox(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, (float)ep.radii[gid], ep.tile_size, ep.tw, ep.th, x0, y0, x1, y1);
+    } else
+        dns_tile_bbox(ep.means2d[2 * gid], ep.means2d[2 * gid + 1], (float)ep.radii[gid], ep.tile_size, ep.tw, ep.th, x0, y0, x1, y1);
+    // batch of cameras: entry gid belongs to camera gid / n_per_cam, whose tile grid is stacked below the previous
+    // cameras' (tile id = camera * tw * th + row * tw + column) — folded into the first tile row of the box
+    if (ep.n_per_cam < N) y0 += (int)(gid / (uint32_t)ep.n_per_cam) * ep.th;
+    EmitRec r;
+    r.gid = gid; r.start = start; r.base_tile = (uint32_t)(y0 * ep.tw + x0); r.bw = (uint32_t)(x1 - x0);
+    ep.jrec[j] = r;
+    const uint32_t c_lo = (start + (uint32_t)ep.chunk - 1u) / (uint32_t)ep.chunk, c_hi = (end - 1u) / (uint32_t)ep.chunk;
+    for (uint32_t c = c_lo; c <= c_hi && c < (uint32_t)ep.nb_chunks; ++c) ep.chunk_first[c] = (uint32_t)j;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -547,30 +525,23 @@ __global__ __launch_bounds__(256) void isect_ids_kernel(int n_tiles, int tile_bi
 }
 
 // ------------------------------------------------------------------------------------------------
-constexpr int LB_CTL_WORDS = 3 * RS_DIGITS + 4;
-
-// Tile sort by decoupled look-back (1) or with per-pass histogram + scan launches (0).  MEASURED AND REJECTED (paired A/B of
-// dnsplat_bin_emit_sort, bit-identical lists, no wait ever hit its bound): C2 0.319 -> 0.475 ms, C5 0.82 -> 1.13 ms.  ~1000
-// chunks run concurrently and all start together, so at the start of a pass the look-back of chunk c walks back through up
-// to c descriptors one at a time, each an agent-scope (sc1) load of ~1 us across the non-coherent L2s: a serial chain that
-// costs more than the two launches (histogram 22 us + scan 10 us) it removes.  The classic remedy — a whole wave inspecting
-// 32-64 predecessors per step — does not fit a layout in which every lane owns a digit.  Kept compiled out as the record.
-#ifndef DNS_BIN_LOOKBACK
-#define DNS_BIN_LOOKBACK 0
-#endif
+// chunks of the largest intersection count the 32-bit positions allow: the per-chunk head table is sized for it so that the
+// N-sized front of the workspace (written by dnsplat_bin_prepare) does not depend on the capacity guess
+constexpr int MAX_CHUNKS = (int)((0x80000000ull + RS_THREADS * RS_ITEMS_I - 1) / (RS_THREADS * RS_ITEMS_I));
 
 struct BinWs {
     uint32_t *key_a, *key_b, *val_a, *val_b;  // [N]
     uint32_t *cum;                            // [N]
+    EmitRec *jrec;                            // [N]
+    uint32_t *chunk_first;                    // [MAX_CHUNKS]
     uint32_t *tab_n;                          // [256 * nb_n]
     uint32_t *totals;                         // [256]
     uint32_t *sums;                           // [nb_scan]
-    uint32_t *n_gauss;                        // [1] = N (device copy so the radix kernels are generic)
     uint32_t *total;                          // [1] n_isects as u32
-    uint32_t *tkey_a, *tkey_b, *tval_a, *tval_b;  // [cap]
+    uint32_t *status;                         // [1] reserved status word (dnsplat_bin_status_offset): 0
+    uint32_t *tkey_b, *tval_b;                // [cap] pairs between the two tile passes
+    uint32_t *tkey_c, *tval_c;                // [cap] only with three tile passes (> 65536 tiles)
     uint32_t *tab_i;                          // [256 * nb_i]
-    uint32_t *lb_ctl;                         // look-back control: [3][256] digit totals | [3] tickets | [1] failure flag
-    unsigned long long *lb_desc;              // look-back descriptors, [3][nb_i][256] at most
     int nb_n, nb_i, nb_scan;
     size_t bytes;
 };
@@ -594,28 +565,33 @@ BinWs carve(void *ws, int N, int64_t cap)
         return p;
     };
     size_t n = (size_t)(N > 0 ? N : 1), c = (size_t)(cap > 0 ? cap : 1);
+    // N-sized front: same layout for every capacity
     b.key_a = take(n); b.key_b = take(n); b.val_a = take(n); b.val_b = take(n);
     b.cum = take(n);
+    b.jrec = reinterpret_cast<EmitRec *>(take(4 * n));
+    b.chunk_first = take(MAX_CHUNKS);
     b.tab_n = take((size_t)RS_DIGITS * b.nb_n);
     b.totals = take(RS_DIGITS);
     b.sums = take(b.nb_scan);
-    b.n_gauss = take(1);
     b.total = take(1);
-    b.tkey_a = take(c); b.tkey_b = take(c); b.tval_a = take(c); b.tval_b = take(c);
+    b.status = take(1);
+    // capacity-sized part
+    b.tkey_b = take(c); b.tval_b = take(c);
+    b.tkey_c = take(c); b.tval_c = take(c);
     b.tab_i = take((size_t)RS_DIGITS * b.nb_i);
-    b.lb_ctl = take(LB_CTL_WORDS);
-    b.lb_desc = reinterpret_cast<unsigned long long *>(take((size_t)3 * RS_DIGITS * b.nb_i * 2));
     b.bytes = off;
     return b;
 }
 
 int tile_bits(int n_tiles);
 
-// one LSD pass over `dbits` bits at `shift`; tile_first != nullptr marks the last pass of the tile sort
+// one LSD pass over `dbits` bits at `shift`; tile_first != nullptr marks the last pass of the tile sort;
+// gen != nullptr: the first pass of the tile sort, whose input is generated (no ka / va)
 template <typename K, int ITEMS>
 void radix_pass(hipStream_t stream, const K *ka, const uint32_t *va, K *kb, uint32_t *vb, const uint32_t *n_ptr,
                 uint32_t n_cap, int shift, int dbits, uint32_t *table, uint32_t *totals, int nb, int32_t *tile_first = nullptr,
-                const int32_t *radii = nullptr, const float *depths = nullptr, int32_t *init_offsets = nullptr, int n_tiles = 0)
+                const int32_t *radii = nullptr, const float *depths = nullptr, int32_t *init_offsets = nullptr, int n_tiles = 0,
+                int32_t *tile_end = nullptr, const GenArgs *gen = nullptr, uint32_t *status = nullptr)
 {
     const uint32_t mask = (1u << dbits) - 1u;
     if (radii) {   // first pass of the depth sort: 8-bit digit, keys synthesised from (radii, depths)
@@ -625,17 +601,22 @@ void radix_pass(hipStream_t stream, const K *ka, const uint32_t *va, K *kb, uint
                            n_ptr, n_cap, shift, table, totals, nb, tile_first, radii, depths);
         return;
     }
-    hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb,
-                       (const int32_t *)nullptr, (const float *)nullptr, init_offsets, n_tiles);
+    const GenArgs g = gen ? *gen : GenArgs{};
+    if (gen)
+        hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS, false, true>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n_ptr, n_cap, shift, mask,
+                           table, nb, (const int32_t *)nullptr, (const float *)nullptr, init_offsets, n_tiles, init_offsets ? tile_end : nullptr, g, status);
+    else
+        hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb,
+                           (const int32_t *)nullptr, (const float *)nullptr, init_offsets, n_tiles, init_offsets ? tile_end : nullptr, g, status);
     hipLaunchKernelGGL(radix_scan_kernel, dim3(1 << dbits), dim3(SC_THREADS), 0, stream, table, nb, totals);
+#define DNS_SCATTER3(B, L, G)                                                                                               \
+    hipLaunchKernelGGL((radix_scatter_kernel<K, L, B, ITEMS, false, G>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb,    \
+                       n_ptr, n_cap, shift, table, totals, nb, tile_first, (const int32_t *)nullptr, (const float *)nullptr, \
+                       tile_end, g)
 #define DNS_SCATTER(B)                                                                                                      \
     do {                                                                                                                    \
-        if (tile_first)                                                                                                     \
-            hipLaunchKernelGGL((radix_scatter_kernel<K, true, B, ITEMS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb,   \
-                               n_ptr, n_cap, shift, table, totals, nb, tile_first);                                         \
-        else                                                                                                                \
-            hipLaunchKernelGGL((radix_scatter_kernel<K, false, B, ITEMS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb,  \
-                               n_ptr, n_cap, shift, table, totals, nb, tile_first);                                         \
+        if (tile_first) { if (gen) DNS_SCATTER3(B, true, true); else DNS_SCATTER3(B, true, false); }                        \
+        else { if (gen) DNS_SCATTER3(B, false, true); else DNS_SCATTER3(B, false, false); }                                 \
     } while (0)
     switch (dbits) {
         case 1: DNS_SCATTER(1); break;
@@ -648,78 +629,40 @@ void radix_pass(hipStream_t stream, const K *ka, const uint32_t *va, K *kb, uint
         default: DNS_SCATTER(8); break;
     }
 #undef DNS_SCATTER
+#undef DNS_SCATTER3
 }
 
-// emission + stable sort of the (tile, gaussian) pairs by tile id + tile offsets
+// stable sort of the (tile, gaussian) pairs of the emission order by tile id + tile offsets; the first pass generates the pairs
 // n_tiles = tiles of the whole batch (cameras x tiles per image)
 template <typename K>
 void emit_and_sort(hipStream_t stream, const dnsplat_bin_args *a, const BinWs &w, int tw, int th, int n_tiles, uint32_t cap)
 {
-    K *ka = reinterpret_cast<K *>(w.tkey_a), *kb = reinterpret_cast<K *>(w.tkey_b);
-    uint32_t *va = w.tval_a, *vb = w.tval_b;
+    K *kb = reinterpret_cast<K *>(w.tkey_b), *kc = reinterpret_cast<K *>(w.tkey_c);
+    uint32_t *vb = w.tval_b, *vc = w.tval_c;
     const int n_cam = a->n_cameras > 1 ? a->n_cameras : 1;
     const int bits = tile_bits(n_tiles);
     const int passes = (bits + 7) / 8;
-#if DNS_BIN_LOOKBACK
-    {
-        hipLaunchKernelGGL(emit_kernel<K>, dim3((a->N + 255) / 256), dim3(256), 0, stream, a->N, a->N / n_cam, w.val_a, w.cum,
-                           a->means2d, a->radii, a->tile_size, tw, th, cap, ka, va, w.lb_ctl, LB_CTL_WORDS,
-                           a->tight_tiles ? reinterpret_cast<const float4 *>(a->splats) : nullptr);
-        int dbits[3] = {0, 0, 0}, shifts[3] = {0, 0, 0};
-        size_t desc_off[4] = {0, 0, 0, 0};
-        for (int pass = 0, sh = 0; pass < passes; ++pass) {
-            dbits[pass] = (bits - sh + (passes - pass) - 1) / (passes - pass);       // 13 bits -> 7 + 6
-            shifts[pass] = sh;
-            sh += dbits[pass];
-            desc_off[pass + 1] = desc_off[pass] + ((size_t)w.nb_i << dbits[pass]);
-        }
-        uint32_t *totals = w.lb_ctl, *tickets = w.lb_ctl + 3 * RS_DIGITS, *fail = tickets + 3;
-        hipLaunchKernelGGL((tile_digit_totals_kernel<K, RS_ITEMS_I>), dim3(w.nb_i), dim3(RS_THREADS), 0, stream, ka, w.total, cap, passes,
-                           shifts[1], shifts[2], (1u << dbits[0]) - 1u, (1u << dbits[1]) - 1u, (1u << dbits[2]) - 1u, totals,
-                           w.lb_desc, desc_off[passes], a->tile_offsets, n_tiles);
-        for (int pass = 0; pass < passes; ++pass) {
-            const bool last = pass == passes - 1;
-            uint32_t *vout = last ? (uint32_t *)a->flatten_ids : vb;
-#define DNS_LB(B, L)                                                                                                              \
-            hipLaunchKernelGGL((radix_scatter_kernel<K, L, B, RS_ITEMS_I, false, true>), dim3(w.nb_i), dim3(RS_THREADS), 0, stream, ka, va, \
-                               kb, vout, w.total, cap, shifts[pass], (const uint32_t *)nullptr, totals + pass * RS_DIGITS, w.nb_i,  \
-                               last ? a->tile_offsets : (int32_t *)nullptr, (const int32_t *)nullptr, (const float *)nullptr,      \
-                               w.lb_desc + desc_off[pass], tickets + pass, fail)
-#define DNS_LB2(B) do { if (last) DNS_LB(B, true); else DNS_LB(B, false); } while (0)
-            switch (dbits[pass]) {
-                case 1: DNS_LB2(1); break;
-                case 2: DNS_LB2(2); break;
-                case 3: DNS_LB2(3); break;
-                case 4: DNS_LB2(4); break;
-                case 5: DNS_LB2(5); break;
-                case 6: DNS_LB2(6); break;
-                case 7: DNS_LB2(7); break;
-                default: DNS_LB2(8); break;
-            }
-#undef DNS_LB2
-#undef DNS_LB
-            K *t = ka; ka = kb; kb = t;
-            uint32_t *u = va; va = vb; vb = u;
-        }
-        hipLaunchKernelGGL(tile_offsets_fill_kernel, dim3(1), dim3(TO_THREADS), 0, stream, n_tiles, a->tile_offsets);
-        return;
-    }
-#endif
-    hipLaunchKernelGGL(emit_kernel<K>, dim3((a->N + 255) / 256), dim3(256), 0, stream, a->N, a->N / n_cam, w.val_a, w.cum,
-                       a->means2d, a->radii, a->tile_size, tw, th, cap, ka, va, w.lb_ctl, LB_CTL_WORDS,
-                       a->tight_tiles ? reinterpret_cast<const float4 *>(a->splats) : nullptr);   // status word := 0
+    GenArgs g;
+    g.jrec = w.jrec; g.cum = w.cum; g.chunk_first = w.chunk_first;
+    g.N = a->N; g.tw = tw;
+    g.exact = (tw <= 256 && (int64_t)n_cam * tw * th <= 65536) ? 1 : 0;
+    const K *ka = nullptr;
+    const uint32_t *va = nullptr;
     int shift = 0;
     for (int pass = 0; pass < passes; ++pass) {
         const int dbits = (bits - shift + (passes - pass) - 1) / (passes - pass);   // 13 bits -> 7 + 6
         const bool last = pass == passes - 1;
-        uint32_t *vout = last ? (uint32_t *)a->flatten_ids : vb;
-        radix_pass<K, RS_ITEMS_I>(stream, ka, va, kb, vout, w.total, cap, shift, dbits, w.tab_i, w.totals, w.nb_i,
-                      last ? a->tile_offsets : nullptr, nullptr, nullptr, pass == 0 ? a->tile_offsets : nullptr, n_tiles);
+        K *kout = (pass & 1) ? kc : kb;
+        uint32_t *vout = last ? (uint32_t *)a->flatten_ids : ((pass & 1) ? vc : vb);
+        radix_pass<K, RS_ITEMS_I>(stream, ka, va, kout, vout, w.total, cap, shift, dbits, w.tab_i, w.totals, w.nb_i,
+                                  last ? a->tile_offsets : nullptr, nullptr, nullptr, pass == 0 ? a->tile_offsets : nullptr, n_tiles,
+                                  a->tile_ends, pass == 0 ? &g : nullptr, pass == 0 ? w.status : nullptr);
         shift += dbits;
-        K *t = ka; ka = kb; kb = t;
-        uint32_t *u = va; va = vb; vb = u;
+        ka = kout; va = vout;
     }
-    hipLaunchKernelGGL(tile_offsets_fill_kernel, dim3(1), dim3(TO_THREADS), 0, stream, n_tiles, a->tile_offsets);
+    // the offsets of the empty tiles (gsplat's isect_offsets): a consumer that takes tile_ends as well does not need them
+    if (!(a->tile_ends && a->skip_offsets_fill))
+        hipLaunchKernelGGL(tile_offsets_fill_kernel, dim3(1), dim3(TO_THREADS), 0, stream, n_tiles, a->tile_offsets);
 }
 
 int tile_bits(int n_tiles)
@@ -742,7 +685,7 @@ extern "C" size_t dnsplat_bin_status_offset(int32_t N, int64_t isect_capacity)
 {
     if (N < 0 || isect_capacity < 0) return 0;
     const BinWs w = carve(nullptr, N, isect_capacity);
-    return (size_t)((char *)(w.lb_ctl + 3 * RS_DIGITS + 3) - (char *)nullptr);
+    return (size_t)((char *)w.status - (char *)nullptr);
 }
 
 static int check_bin(const dnsplat_bin_args *a)
@@ -764,6 +707,7 @@ extern "C" int dnsplat_bin_prepare(const dnsplat_bin_args *a, dnsplat_stream_t s
     hipStream_t stream = (hipStream_t)stream_;
     BinWs w = carve(a->workspace, a->N, a->isect_capacity);
     const int N = a->N;
+    if (a->tight_tiles && !a->splats && N > 0) return DNSPLAT_ERR_INVALID_ARG;
     if (N == 0) {
         if (hipMemsetAsync(a->n_isects, 0, sizeof(int64_t), stream) != hipSuccess) return DNSPLAT_ERR_LAUNCH;
         if (hipMemsetAsync(w.total, 0, sizeof(uint32_t), stream) != hipSuccess) return DNSPLAT_ERR_LAUNCH;
@@ -781,8 +725,16 @@ extern "C" int dnsplat_bin_prepare(const dnsplat_bin_args *a, dnsplat_stream_t s
         // after 4 passes the sorted order is back in val_a
         hipLaunchKernelGGL(scan_sums_kernel, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.val_a, a->tiles_per_gauss,
                            w.sums);
+        EmitPrep ep;
+        ep.jrec = w.jrec; ep.chunk_first = w.chunk_first; ep.nb_chunks = MAX_CHUNKS; ep.chunk = RS_THREADS * RS_ITEMS_I;
+        ep.n_per_cam = N / (a->n_cameras > 1 ? a->n_cameras : 1);
+        ep.tile_size = a->tile_size;
+        ep.tw = dns_tiles_w(a->width, a->tile_size); ep.th = dns_tiles_h(a->height, a->tile_size);
+        ep.means2d = a->means2d; ep.radii = a->radii;
+        ep.splats = a->tight_tiles ? reinterpret_cast<const float4 *>(a->splats) : nullptr;
         hipLaunchKernelGGL(scan_final_kernel, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.val_a,
-                           a->tiles_per_gauss, w.sums, w.cum, w.total, a->n_isects);
+                           a->tiles_per_gauss, w.sums, w.cum, w.total, a->n_isects, a->n_isects_max);
+        hipLaunchKernelGGL(emit_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, w.val_a, w.cum, ep);
         DNS_CHECK_LAUNCH();
     }
     if (a->n_isects_host) {

@@ -142,6 +142,7 @@ struct BwdArgs {
     const float4 *__restrict__ splats;
     const int32_t *__restrict__ flatten_ids;
     const int32_t *__restrict__ tile_offsets;
+    const int32_t *__restrict__ tile_ends;     // or NULL: the list of tile t ends at tile_offsets[t + 1]
     const float *__restrict__ background;
     int ed_channel;
     const float *__restrict__ render;
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
     const int part = blockIdx.x % PARTS;
     const int lane = threadIdx.x;
     const int range_start = a.tile_offsets[cam * a.n_tiles + tile];
-    const int range_end = a.tile_offsets[cam * a.n_tiles + tile + 1];
+    const int range_end = a.tile_ends ? a.tile_ends[cam * a.n_tiles + tile] : a.tile_offsets[cam * a.n_tiles + tile + 1];
     if (range_end <= range_start) return;
     [[maybe_unused]] unsigned long long n_slots = 0, n_pairs = 0;
 #ifdef DNS_BWD_TIMELINE
@@ -764,6 +765,7 @@ extern "C" int dnsplat_raster_bwd(const dnsplat_raster_args *a, dnsplat_stream_t
     ba.splats = reinterpret_cast<const float4 *>(a->splats);
     ba.flatten_ids = a->flatten_ids;
     ba.tile_offsets = a->tile_offsets;
+    ba.tile_ends = a->tile_ends;
     ba.background = a->background;
     ba.ed_channel = a->ed_channel;
     ba.render = a->render; ba.alphas = a->alphas; ba.last_ids = a->last_ids;

@@ -36,6 +36,7 @@ struct FwdArgs {
     const float4 *__restrict__ splats;
     const int32_t *__restrict__ flatten_ids;
     const int32_t *__restrict__ tile_offsets;
+    const int32_t *__restrict__ tile_ends;     // or NULL: the list of tile t ends at tile_offsets[t + 1]
     const float *__restrict__ background;
     int ed_channel;
     float *__restrict__ render;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
     const bool in1 = px_i < a.width && py_i1 < a.height;
 
     const int range_start = a.tile_offsets[list];
-    const int range_end = a.tile_offsets[list + 1];
+    const int range_end = a.tile_ends ? a.tile_ends[list] : a.tile_offsets[list + 1];
 
     float T0 = 1.f, T1 = 1.f;
     float acc0[D], acc1[D];
@@ -318,6 +319,7 @@ extern "C" int dnsplat_raster_fwd(const dnsplat_raster_args *a, dnsplat_stream_t
     fa.splats = reinterpret_cast<const float4 *>(a->splats);
     fa.flatten_ids = a->flatten_ids;
     fa.tile_offsets = a->tile_offsets;
+    fa.tile_ends = a->tile_ends;
     fa.background = a->background;
     fa.ed_channel = a->ed_channel;
     fa.render = a->render; fa.alphas = a->alphas; fa.last_ids = a->last_ids;

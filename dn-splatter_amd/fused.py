@@ -145,12 +145,15 @@ def _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest
         pr["means2d"], pr["splats"], pr["depths"], pr["radii"], pr["tiles_per_gauss"], background_rgb=background_rgb,
         width=width, height=height, intrinsics=intr, absgrad=absgrad, holder=holder)
     b = holder["binning"]
-    info = {
+    info = _ops.LazyInfo({
         "means2d": pr["means2d"], "radii": pr["radii"], "depths": pr["depths"], "conics": pr["conics"],
         "tiles_per_gauss": pr["tiles_per_gauss"], "normals_world": pr["normals_world"][-1],      # dn_model.py:558 keeps the last camera's
-        "flatten_ids": b.flatten_ids[: b.n_isects], "isect_offsets": b.tile_offsets[:-1].reshape(C, b.tile_height, b.tile_width),
-        "n_isects": b.n_isects, "tile_width": b.tile_width, "tile_height": b.tile_height,
+        "tile_width": b.tile_width, "tile_height": b.tile_height,
         "width": width, "height": height, "tile_size": 16, "n_cameras": C, "_binning": b, "tight_tiles": cfg.tight_tiles,
         "_saturation_flag": saturation_flag,
-    }
+    }, lazy={     # need the intersection count on the host: under the "deferred" bin policy reading them is what waits for it
+        "flatten_ids": lambda: b.flatten_ids[: b.n_isects], "n_isects": lambda: b.n_isects,
+        # this path keeps [start, end) per tile; gsplat's offsets of the empty tiles are filled in when somebody asks
+        "isect_offsets": lambda: b.filled_offsets()[:-1].reshape(C, b.tile_height, b.tile_width),
+    })
     return {"rgb": rgb, "depth": depth, "normal": normal, "surface_normal": surface_normal, "accumulation": acc}, info

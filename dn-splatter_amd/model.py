@@ -121,6 +121,12 @@ class DNSplatterRenderer:
         self.xys = self.radii = self.depths = self.conics = self.num_tiles_hit = None
         self.last_info: Dict = {}
 
+    def forget(self) -> None:
+        """Drops what the last get_outputs left on the renderer (xys, depths, last_info ...), and with it the autograd graph of
+        that frame — e.g. before the step is captured into a HIP graph on another stream (graph.GraphedStep)."""
+        self.xys = self.radii = self.depths = self.conics = self.num_tiles_hit = None
+        self.last_info = {}
+
     @torch.no_grad()
     def get_outputs_batch(self, cameras, max_batch: int = 8):
         """Forward-only rendering of several cameras of one image size (the render loops of the offline

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DNSPLAT_ABI_VERSION 8
+#define DNSPLAT_ABI_VERSION 9
 #define DNSPLAT_RECORD_FLOATS 16
 #define DNSPLAT_MAX_CHANNELS 8
 
@@ -56,6 +56,11 @@ typedef void *dnsplat_stream_t; /* hipStream_t */
 
 const char *dnsplat_strerror(int code);
 int dnsplat_abi_version(void);
+
+/* Appends the device's constant-rate wall clock (s_memrealtime ticks) to ring[(*cursor)++ % ring_size] from a one-thread kernel on
+ * `stream`.  Works inside a frame captured into a HIP graph, where events cannot be recorded (ROCm 7.2): bench.py brackets the
+ * dominant stage with two stamps per replay and calibrates the tick against HIP events. */
+int dnsplat_stamp(uint64_t *ring, uint32_t *cursor, uint32_t ring_size, dnsplat_stream_t stream);
 
 /* ------------------------------------------------------------------ stage 1
  * Fused per-Gaussian front end: activations (A0) + fully-fused projection (A1)
@@ -154,6 +159,12 @@ typedef struct dnsplat_bin_args {
     size_t workspace_bytes;
     const float *splats;             /* [N,16] records of stage 1; read only when tight_tiles != 0 */
     int32_t tight_tiles;             /* as dnsplat_camera.tight_tiles of the projection that produced tiles_per_gauss */
+    int32_t *tile_ends;              /* optional out [n_cameras*n_tiles]: one past the last sorted index of every non-empty tile (0 for an
+                                        empty one).  dnsplat_raster_args.tile_ends takes it. */
+    int32_t skip_offsets_fill;       /* with tile_ends: leave tile_offsets[t] of EMPTY tiles undefined (>= the tile's end) instead of
+                                        giving them gsplat's value (the offset of the next non-empty tile) — one launch less */
+    int64_t *n_isects_max;           /* optional device scalar the caller zeroes once: running maximum of n_isects over the frames binned
+                                        since.  For a host that never waits on a single frame's count (replayed HIP graphs). */
 } dnsplat_bin_args;
 
 /* 2a: depth sort + inclusive offsets + total.  After this (and a stream sync or
@@ -227,6 +238,8 @@ typedef struct dnsplat_raster_args {
     const uint32_t *saturation_flag;    /* NULL, or dnsplat_proj_out.saturation_flag of the projection(s) behind `splats`: if the word
                                            is 0 no pair of this launch can clamp and dnsplat_raster_bwd (only; the forward ignores it) runs its step loop without
                                            the clamp handling (same results, ~3.6 % fewer cycles); read on the device, no host sync */
+    const int32_t *tile_ends;           /* NULL: tile t's list is [tile_offsets[t], tile_offsets[t+1]).  Else dnsplat_bin_args.tile_ends:
+                                           the list is [tile_offsets[t], tile_ends[t]) and empty where tile_ends[t] <= tile_offsets[t] */
     void *zero_fill;                    /* dnsplat_raster_fwd only: NULL, or a device buffer of zero_fill_bytes (multiple of 16) the launch clears
                                            on the way — meant for the v_splats buffer the backward of the same frame accumulates into */
     int64_t zero_fill_bytes;
