@@ -381,6 +381,9 @@ def main():
     for name, t in stage_traffic.items():
         if name in stages:
             stages[name]["hbm_traffic"] = t
+    if "dnsplat_project_fwd_colours" in pstats and "dnsplat_project_fwd" in stages:
+        # the SH colour half of the projection runs on a side stream beside the binning kernels (ProjCfg.split_colours)
+        stages["dnsplat_project_fwd"]["colour_phase_on_side_stream_ms"] = round(pstats["dnsplat_project_fwd_colours"][1], 4)
     if "binning" in stages:      # its two entry points (depth sort + counts | pair generation + tile sort), from the instrumented steps
         for k in ("dnsplat_bin_prepare", "dnsplat_bin_emit_sort"):
             if k in pstats:

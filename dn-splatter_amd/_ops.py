@@ -66,6 +66,7 @@ class ProjCfg:
     with_normals: bool = False
     want_normals_world: bool = False
     tight_tiles: bool = False    # dnsplat_camera.tight_tiles: tile counts over the alpha >= 1/255 box instead of gsplat's 3-sigma box
+    split_colours: bool = False  # dnsplat_proj_out.phase 1 + 2: the SH colours on a side stream, beside the binning kernels
 
     @property
     def tiles(self):
@@ -80,6 +81,7 @@ class _Buffers:
         self.ws: Dict[torch.device, Tensor] = {}
         self.pinned: Dict[torch.device, Tensor] = {}
         self.ring: Dict[tuple, dict] = {}
+        self.side: Dict[tuple, "torch.cuda.Stream"] = {}
         self.n_max: Dict[tuple, Tensor] = {}     # "static" bin policy: running maximum of n_isects per (device, stream)
         self.capacity_hint: Dict[tuple, int] = {}
 
@@ -88,6 +90,17 @@ class _Buffers:
         # one set of scratch per (device, stream): frames rendered concurrently on different HIP streams
         # (model.get_outputs_batch) must not share the binning workspace or the pinned counter
         return (device, torch.cuda.current_stream(device).cuda_stream)
+
+    def side_stream(self, device) -> "torch.cuda.Stream":
+        """The stream work that may overlap the current stream's is put on (one per device and current stream)."""
+        key = self._key(device)
+        st = self.side.get(key)
+        if st is None:
+            # lowest priority: what runs there is meant to fill the gaps the current stream leaves, not to compete with it
+            prio = int(os.environ.get("DNSPLAT_SIDE_PRIORITY", "1"))
+            st = torch.cuda.Stream(device, priority=prio)
+            self.side[key] = st
+        return st
 
     def workspace(self, device, nbytes: int) -> Tensor:
         key = self._key(device)
@@ -264,7 +277,7 @@ class _ProjectFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, cfg: ProjCfg,
-                saturation_flag=None):
+                saturation_flag=None, side=None):
         means = _f32c(means, "means"); quats = _f32c(quats, "quats"); scales = _f32c(scales, "scales")
         opacities = _f32c(opacities, "opacities")
         viewmat = _f32c(viewmat, "viewmats"); K = _f32c(K, "Ks")
@@ -312,6 +325,10 @@ class _ProjectFn(torch.autograd.Function):
         nworld = torch.empty(C, N, 3, dtype=torch.float32, device=dev) if cfg.want_normals_world else None
 
         scene = _scene_struct(N, means, quats, scales, opacities, cfg, p_sh0, s0, p_shN, sN, sh_K, colors)
+        # phase 1 here, phase 2 (the SH colours: most of the bytes) on a side stream while this stream goes on to the binning
+        # kernels, which leave most of the chip idle; whoever reads the colour channels of the records waits for side["colours_ready"]
+        split = bool(cfg.split_colours and side is not None and cfg.sh_degree >= 0)
+        outs = []
         for c in range(C):
             cam = _camera_struct(viewmat[c], K[c], None if normal_frame is None else normal_frame[c], cfg)
             out = ProjOut()
@@ -322,7 +339,21 @@ class _ProjectFn(torch.autograd.Function):
             out.with_depth_channel = int(cfg.with_depth)
             out.with_normal_channels = int(cfg.with_normals)
             out.saturation_flag = _ptr(saturation_flag)      # one word for all cameras of the batch (zeroed by camera_prepare)
+            out.phase = 1 if split else 0
             _lib.run("dnsplat_project_fwd", _lib.lib().dnsplat_project_fwd, ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(out), _stream())
+            outs.append((cam, out))
+        if split:
+            main = torch.cuda.current_stream(dev)
+            s2 = BUFFERS.side_stream(dev)
+            s2.wait_stream(main)
+            with torch.cuda.stream(s2):
+                for cam, out in outs:
+                    out.phase = 2
+                    _lib.run("dnsplat_project_fwd_colours", _lib.lib().dnsplat_project_fwd, ctypes.byref(scene), ctypes.byref(cam),
+                             ctypes.byref(out), _stream())
+                ev = torch.cuda.Event()
+                ev.record(s2)
+            side["colours_ready"] = ev
 
         ctx.cfg = cfg
         ctx.sh_K = sh_K
@@ -421,15 +452,15 @@ class _ProjectFn(torch.autograd.Function):
                 for acc, t in zip(total, outs):
                     if acc is not None:
                         acc.add_(t)
-        return tuple(t if (t is not None and need[i]) else None for i, t in enumerate(total)) + (None, None, None, None, None)
+        return tuple(t if (t is not None and need[i]) else None for i, t in enumerate(total)) + (None, None, None, None, None, None)
 
 
 def project(means, quats, scales, opacities, *, coeffs=None, sh0=None, shN=None, colors=None, viewmat, K,
-            normal_frame=None, cfg: ProjCfg, saturation_flag: Optional[Tensor] = None):
+            normal_frame=None, cfg: ProjCfg, saturation_flag: Optional[Tensor] = None, side: Optional[dict] = None):
     """``viewmat`` [4,4] or [C,4,4] (``K``, ``normal_frame`` alike) -> dict(means2d[C,N,2], depths[C,N], conics[C,N,3],
     compensations[C,N] | None, splats[C*N,16], radii[C,N], tiles_per_gauss[C,N], normals_world[C,N,3] | None)"""
     m2d, dep, con, comp, splats, radii, tiles, nworld = _ProjectFn.apply(
-        means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, cfg, saturation_flag)
+        means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, cfg, saturation_flag, side)
     return dict(means2d=m2d, depths=dep, conics=con, compensations=comp if comp.numel() else None, splats=splats,
                 radii=radii, tiles_per_gauss=tiles, normals_world=nworld if nworld.numel() else None)
 
@@ -749,6 +780,8 @@ TIGHT_TILES = os.environ.get("DNSPLAT_TIGHT_TILES", "1") != "0"
 SATURATION_FLAG = os.environ.get("DNSPLAT_SATURATION_FLAG", "1") != "0"
 # dnsplat_raster_args.zero_fill: the fused forward clears the gradient records its backward accumulates into
 FORWARD_ZERO_FILL = os.environ.get("DNSPLAT_FORWARD_ZERO_FILL", "1") != "0"
+# the fused path's projection as two launches, the SH colour half on a side stream beside the binning kernels (ProjCfg.split_colours)
+SPLIT_COLOURS = os.environ.get("DNSPLAT_SPLIT_COLOURS", "0") != "0"
 
 # Measurement hook (bench.py's VALU roofline): a uint64 [8] device tensor makes the fused pass run the COUNTING instantiation of
 # both compositing kernels, which tally list entries / splats walked / pairs evaluated / pairs blended / slots issued.
@@ -804,6 +837,9 @@ class _RasterDnFn(torch.autograd.Function):
 
         def composite(b: Binning):
             depth_max.zero_()
+            ready = holder.get("colours_ready") if holder is not None else None
+            if ready is not None:          # the projection's colour phase runs on a side stream (ProjCfg.split_colours)
+                torch.cuda.current_stream(dev).wait_event(ready)
             a = RasterArgs()
             a.n_cameras = C
             if KEEP_MASKS:

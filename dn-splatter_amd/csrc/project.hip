@@ -14,8 +14,9 @@
 // oracle/oracle_impl.inc spells out, without FMA contraction.  The kernel is bandwidth-trivial
 // (one thread per Gaussian, ~0.3 KB each way), so nothing is lost.
 //
-// Mapping: one lane per Gaussian, 256-thread workgroups (4 waves).  Camera constants are read
-// through wave-uniform pointers, i.e. they live in SGPRs.
+// Mapping: one lane per Gaussian, one wave per workgroup (DNS_PROJ_THREADS = 64: paired A/B against 128 / 256 threads at 1 M
+// Gaussians: project_fwd -2 %, project_bwd -4 % — more workgroups per CU overlap their load / compute / store phases).  Camera
+// constants are read through wave-uniform pointers, i.e. they live in SGPRs.
 
 #include "splat_common.h"
 
@@ -275,7 +276,10 @@ __device__ __forceinline__ void gaussian_normal(const float *Rq, const float *sc
 // each lane walk its own LDS row (odd row stride => conflict-free ds_read_b32).  Two layouts:
 //   SPLIT  features_dc [N,3] + features_rest [N,15,3]   rows of 45 floats, span = features_rest
 //   CAT    colours [N,16,3] (gsplat layout)               rows of 48 floats incl. band 0, LDS stride 49
-constexpr int SH_STAGE_THREADS = 256;
+#ifndef DNS_PROJ_THREADS
+#define DNS_PROJ_THREADS 64
+#endif
+constexpr int SH_STAGE_THREADS = DNS_PROJ_THREADS;      // threads (= Gaussians) per workgroup of the staged kernels
 enum ShLayout { SH_DIRECT = 0, SH_SPLIT = 1, SH_CAT = 2 };
 template <int L> struct ShRowTraits { static constexpr int ROW = 45, LDS_ROW = 45; };
 template <> struct ShRowTraits<SH_CAT> { static constexpr int ROW = 48, LDS_ROW = 49; };
@@ -334,26 +338,62 @@ struct FwdParams {
     dnsplat_scene s;
     dnsplat_camera c;
     dnsplat_proj_out o;
+    int blocks;          // blocks of 256 Gaussians (phase 2 walks them with fewer workgroups)
 };
 
-template <int L>
-__global__ __launch_bounds__(256) void project_fwd_kernel(FwdParams p)
+// PHASE (dnsplat_proj_out.phase): 0 = everything in one launch; 1 = geometry only (the SH colour channels of the records stay
+// zero: no coefficient is read, L is ignored); 2 = the SH colours of the Gaussians phase 1 found visible, written into their
+// records (channels 0-2).  1 + 2 on two streams let the bandwidth-bound colour half (228 of the 304 B a visible Gaussian costs)
+// run beside the latency-bound binning kernels, which need nothing but phase 1's outputs.
+template <int L, int PHASE = 0>
+__global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams p)
 {
-    __shared__ float sh_lds[L == SH_DIRECT ? 1 : SH_STAGE_THREADS * ShRowTraits<L>::LDS_ROW];
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (L != SH_DIRECT) {
-        const int g0 = blockIdx.x * SH_STAGE_THREADS;
+    __shared__ float sh_lds[(L == SH_DIRECT || PHASE == 1) ? 1 : SH_STAGE_THREADS * ShRowTraits<L>::LDS_ROW];
+    // PHASE 2 is launched with a FEW resident workgroups that walk the blocks of 256 Gaussians (p.blocks of them): it is meant to
+    // run beside other kernels and must leave them most of the wave slots.  The other phases: one block per workgroup.
+    for (int vb = blockIdx.x; vb < (PHASE == 2 ? p.blocks : (int)blockIdx.x + 1); vb += gridDim.x) {
+    if (PHASE == 2 && vb != (int)blockIdx.x) __syncthreads();      // the previous block's rows are still being read
+    const int g = vb * blockDim.x + threadIdx.x;
+    if (L != SH_DIRECT && PHASE != 1) {
+        const int g0 = vb * SH_STAGE_THREADS;
         const int nG = min(SH_STAGE_THREADS, p.s.N - g0);
         const float *base = (L == SH_CAT ? p.s.sh0 : p.s.shN) + (size_t)g0 * ShRowTraits<L>::ROW;
         sh_stage_in<L>(base, nG * ShRowTraits<L>::ROW, sh_lds);
         __syncthreads();
     }
+    if (PHASE == 2 && (g >= p.s.N || p.o.radii[g] <= 0)) continue;
     if (g >= p.s.N) return;
     const Cam cam = load_cam(p.c.viewmat, p.c.K);
 
     float mean[3], quat[4], sc_raw[3], sc[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) mean[i] = p.s.means[3 * g + i];
+    if (PHASE == 2) {
+        // colours only: same arithmetic, in the same order, as the one-launch kernel below
+        float dx = mean[0] - cam.pos[0], dy = mean[1] - cam.pos[1], dz = mean[2] - cam.pos[2];
+        float inorm = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+        dx *= inorm; dy *= inorm; dz *= inorm;
+        float bas[16];
+        sh_basis(p.s.sh_degree, dx, dy, dz, bas);
+        const int nb = (p.s.sh_degree + 1) * (p.s.sh_degree + 1);
+        float col[3];
+        const float *row = sh_lds + threadIdx.x * ShRowTraits<L>::LDS_ROW;
+        const float *c0 = (L == SH_CAT) ? row : p.s.sh0 + (size_t)g * p.s.sh0_stride;
+        const float *cN = (L == SH_DIRECT) ? p.s.shN + (size_t)g * p.s.shN_stride : (L == SH_CAT ? row + 3 : row);
+        col[0] = bas[0] * c0[0]; col[1] = bas[0] * c0[1]; col[2] = bas[0] * c0[2];
+#pragma unroll
+        for (int k = 1; k < 16; ++k)
+            if (k < nb) {
+                col[0] += bas[k] * cN[3 * (k - 1) + 0];
+                col[1] += bas[k] * cN[3 * (k - 1) + 1];
+                col[2] += bas[k] * cN[3 * (k - 1) + 2];
+            }
+        float *rec = p.o.splats + (size_t)g * DNS_REC;
+        rec[REC_CH0 + 0] = fmaxf(col[0] + 0.5f, 0.f);
+        rec[REC_CH0 + 1] = fmaxf(col[1] + 0.5f, 0.f);
+        rec[REC_CH0 + 2] = fmaxf(col[2] + 0.5f, 0.f);
+        continue;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) quat[i] = p.s.quats[4 * g + i];
 #pragma unroll
@@ -418,7 +458,9 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(FwdParams p)
     r[REC_CA] = st.conic[0]; r[REC_CB] = st.conic[1]; r[REC_CC] = st.conic[2];
     r[REC_OPAC] = opac;
     int ch = 0;
-    if (p.s.sh_degree >= 0) {
+    if (PHASE == 1) {
+        ch = 3;                      // the three colour channels are phase 2's
+    } else if (p.s.sh_degree >= 0) {
         float dx = mean[0] - cam.pos[0], dy = mean[1] - cam.pos[1], dz = mean[2] - cam.pos[2];
         float inorm = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
         dx *= inorm; dy *= inorm; dz *= inorm;
@@ -484,6 +526,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(FwdParams p)
     rec4[1] = make_float4(r[4], r[5], r[6], r[7]);
     rec4[2] = make_float4(r[8], r[9], r[10], r[11]);
     rec4[3] = make_float4(r[12], r[13], r[14], r[15]);
+    }
 }
 
 struct BwdParams {
@@ -494,7 +537,7 @@ struct BwdParams {
 };
 
 template <int L>
-__global__ __launch_bounds__(256) void project_bwd_kernel(BwdParams p)
+__global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams p)
 {
     __shared__ float sh_lds[L == SH_DIRECT ? 1 : SH_STAGE_THREADS * ShRowTraits<L>::LDS_ROW];
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -821,7 +864,7 @@ __global__ __launch_bounds__(256) void pack_splats_kernel(int N, const float *__
 
 // v_coeff = scale * sum over views of basis(dir_view) (x) v_colour_view  — see dnsplat_sh_grads_from_factors
 template <int L>
-__global__ __launch_bounds__(256) void sh_from_factors_kernel(int N, int n_views, const float *__restrict__ factors, int degree,
+__global__ __launch_bounds__(SH_STAGE_THREADS) void sh_from_factors_kernel(int N, int n_views, const float *__restrict__ factors, int degree,
                                                               float scale, float *__restrict__ v_sh0, int s0,
                                                               float *__restrict__ v_shN, int sN, int restK)
 {
@@ -920,12 +963,25 @@ extern "C" int dnsplat_project_fwd(const dnsplat_scene *scene, const dnsplat_cam
     int rc = check_scene(scene, cam, out);
     if (rc != DNSPLAT_OK) return rc;
     if (scene->N == 0) return DNSPLAT_OK;
-    FwdParams p{*scene, *cam, *out};
-    dim3 block(256), grid((scene->N + 255) / 256);
-    switch (sh_layout(scene, scene->sh0, scene->sh0_stride, scene->shN, scene->shN_stride)) {
-        case SH_SPLIT: hipLaunchKernelGGL(project_fwd_kernel<SH_SPLIT>, grid, block, 0, (hipStream_t)stream, p); break;
-        case SH_CAT: hipLaunchKernelGGL(project_fwd_kernel<SH_CAT>, grid, block, 0, (hipStream_t)stream, p); break;
-        default: hipLaunchKernelGGL(project_fwd_kernel<SH_DIRECT>, grid, block, 0, (hipStream_t)stream, p);
+    FwdParams p{*scene, *cam, *out, (scene->N + SH_STAGE_THREADS - 1) / SH_STAGE_THREADS};
+    dim3 block(SH_STAGE_THREADS), grid((scene->N + SH_STAGE_THREADS - 1) / SH_STAGE_THREADS);
+    if (out->phase < 0 || out->phase > 2 || (out->phase != 0 && scene->sh_degree < 0)) return DNSPLAT_ERR_INVALID_ARG;
+    if (out->phase == 1) {
+        hipLaunchKernelGGL((project_fwd_kernel<SH_DIRECT, 1>), grid, block, 0, (hipStream_t)stream, p);
+    } else if (out->phase == 2) {
+        const char *e = getenv("DNSPLAT_COLOUR_WGS");
+        grid = dim3(min((int)grid.x, e ? atoi(e) : 512));
+        switch (sh_layout(scene, scene->sh0, scene->sh0_stride, scene->shN, scene->shN_stride)) {
+            case SH_SPLIT: hipLaunchKernelGGL((project_fwd_kernel<SH_SPLIT, 2>), grid, block, 0, (hipStream_t)stream, p); break;
+            case SH_CAT: hipLaunchKernelGGL((project_fwd_kernel<SH_CAT, 2>), grid, block, 0, (hipStream_t)stream, p); break;
+            default: hipLaunchKernelGGL((project_fwd_kernel<SH_DIRECT, 2>), grid, block, 0, (hipStream_t)stream, p);
+        }
+    } else {
+        switch (sh_layout(scene, scene->sh0, scene->sh0_stride, scene->shN, scene->shN_stride)) {
+            case SH_SPLIT: hipLaunchKernelGGL(project_fwd_kernel<SH_SPLIT>, grid, block, 0, (hipStream_t)stream, p); break;
+            case SH_CAT: hipLaunchKernelGGL(project_fwd_kernel<SH_CAT>, grid, block, 0, (hipStream_t)stream, p); break;
+            default: hipLaunchKernelGGL(project_fwd_kernel<SH_DIRECT>, grid, block, 0, (hipStream_t)stream, p);
+        }
     }
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;
@@ -943,7 +999,7 @@ extern "C" int dnsplat_project_bwd(const dnsplat_scene *scene, const dnsplat_cam
     if (scene->sh_degree > 3) return DNSPLAT_ERR_UNSUPPORTED;
     if (fwd->with_normal_channels && !cam->normal_frame) return DNSPLAT_ERR_INVALID_ARG;
     BwdParams p{*scene, *cam, *fwd, *grads};
-    dim3 block(256), grid((scene->N + 255) / 256);
+    dim3 block(SH_STAGE_THREADS), grid((scene->N + SH_STAGE_THREADS - 1) / SH_STAGE_THREADS);
     // the staged kernels need the gradient tensors in the same layout as the coefficients
     int layout = sh_layout(scene, scene->sh0, scene->sh0_stride, scene->shN, scene->shN_stride);
     if (layout != SH_DIRECT && layout != sh_layout(scene, grads->v_sh0, grads->v_sh0_stride, grads->v_shN, grads->v_shN_stride))
@@ -1012,7 +1068,7 @@ extern "C" int dnsplat_sh_grads_from_factors(int32_t N, int32_t n_views, const f
     dnsplat_scene fake{};
     fake.sh_degree = sh_degree; fake.sh_K = sh_K;
     const int layout = sh_layout(&fake, v_sh0, v_sh0_stride, v_shN, v_shN_stride);
-    dim3 block(256), grid((N + 255) / 256);
+    dim3 block(SH_STAGE_THREADS), grid((N + SH_STAGE_THREADS - 1) / SH_STAGE_THREADS);
     const int restK = sh_K - 1;
     switch (layout) {
         case SH_SPLIT:

@@ -138,7 +138,10 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
     float acc0[D], acc1[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
-    float last0 = 0.f, last1 = 0.f;                  // list index of the last blended splat, as raw bits (sel() moves floats)
+    // last_ids: for a pixel that saturated the index before the saturating entry, else the end of the last batch it blended anything
+    // of; in both cases no entry in (last blended, last_ids] applies to the pixel.  Raw bits (sel() moves floats).
+    float last0 = 0.f, last1 = 0.f;
+    uint64_t any0 = 0ull, any1 = 0ull;               // pixels that blended an entry of the current batch
     uint64_t done0 = ~dns_ballot(in0), done1 = ~dns_ballot(in1);   // wave masks: pixel saturated (or outside the image)
 
     float4(*my)[4] = lds[wave];
@@ -219,29 +222,60 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
             const float alpha1 = fminf((float)DNS_ALPHA_MAX, g1.y * dns_exp2(e1));
             const uint64_t valid0 = dns_ballot(e0 <= 0.f) & dns_ballot(alpha0 >= (float)DNS_ALPHA_MIN) & ~done0;
             const uint64_t valid1 = dns_ballot(e1 <= 0.f) & dns_ballot(alpha1 >= (float)DNS_ALPHA_MIN) & ~done1;
-            const float nT0 = T0 * (1.f - alpha0), nT1 = T1 * (1.f - alpha1);
-            const uint64_t stop0 = valid0 & dns_ballot(nT0 <= (float)DNS_T_MIN);
-            const uint64_t stop1 = valid1 & dns_ballot(nT1 <= (float)DNS_T_MIN);
-            done0 |= stop0;
-            done1 |= stop1;
-            const uint64_t c0 = valid0 & ~stop0, c1 = valid1 & ~stop1;
+            // a skipped pair takes alpha = 0: its weight is 0 and T x (1 - 0) is T itself, so the blend and the transmittance update
+            // below are unconditional.  Only a valid pair can lower T, so "T' <= 1e-4" alone says "this pair saturates the pixel".
+            const float a0 = sel0(valid0, alpha0), a1 = sel0(valid1, alpha1);
+            float nT0 = T0 * (1.f - a0), nT1 = T1 * (1.f - a1);
+            const uint64_t stop0 = dns_ballot(nT0 <= (float)DNS_T_MIN), stop1 = dns_ballot(nT1 <= (float)DNS_T_MIN);
+            float v0 = a0 * T0, v1 = a1 * T1;
+            any0 |= valid0; any1 |= valid1;
             if (COUNT) {
                 n_walked += 1;
-                n_live += __popcll(~(done0 & ~stop0)) + __popcll(~(done1 & ~stop1));   // pixels still open when the splat arrived
-                n_blend += __popcll(c0) + __popcll(c1);
+                n_live += __popcll(~done0) + __popcll(~done1);            // pixels still open when the splat arrived
+                n_blend += __popcll(valid0 & ~stop0) + __popcll(valid1 & ~stop1);
             }
             float ch[8];
             ch[0] = g1.z; ch[1] = g1.w;
             if (D > 2) { ch[2] = g2.x; ch[3] = g2.y; ch[4] = g2.z; ch[5] = g2.w; }
             if (D > 6) { ch[6] = g3.x; ch[7] = g3.y; }
-            const float v0 = sel0(c0, alpha0 * T0);
-            const float v1 = sel0(c1, alpha1 * T1);
+            // Some pixel saturates at this splat only about one splat in four: then the splat is NOT applied to it (weight 0), its T
+            // stays, and the last index the backward has to visit for it is the one before (exactly: this entry must not be replayed).
+            // The six selects sit behind a wave-uniform branch INSIDE one asm statement: written as a C++ `if`, hipcc copies every
+            // accumulator where the two paths meet (14 v_mov per splat), as a straight line they cost 30 cycles per splat.
+            {
+                const int before = batch_start + t - 1;
+                float tmp;
+                asm volatile(
+                    "s_or_b64 vcc, %9, %10\n\t"
+                    "s_cmp_eq_u64 vcc, 0\n\t"
+                    "s_cbranch_scc1 1f\n\t"
+                    "v_mov_b32_e32 %8, %13\n\t"
+                    "v_cndmask_b32_e64 %0, %0, 0, %9\n\t"
+                    "v_cndmask_b32_e64 %1, %1, 0, %10\n\t"
+                    "v_cndmask_b32_e64 %2, %2, %11, %9\n\t"
+                    "v_cndmask_b32_e64 %3, %3, %12, %10\n\t"
+                    "v_cndmask_b32_e64 %4, %4, %8, %9\n\t"
+                    "v_cndmask_b32_e64 %5, %5, %8, %10\n\t"
+                    "s_or_b64 %6, %6, %9\n\t"
+                    "s_or_b64 %7, %7, %10\n\t"
+                    "1:"
+                    : "+v"(v0), "+v"(v1), "+v"(nT0), "+v"(nT1), "+v"(last0), "+v"(last1), "+s"(done0), "+s"(done1), "=&v"(tmp)
+                    : "s"(stop0), "s"(stop1), "v"(T0), "v"(T1), "s"(before)
+                    : "vcc", "scc");
+                if ((done0 & done1) == ~0ull) todo = 0;      // all 128 pixels saturated (not a `break`: a second loop exit makes hipcc copy every accumulator at the latch)
+            }
 #pragma unroll
             for (int k = 0; k < D; ++k) { acc0[k] += ch[k] * v0; acc1[k] += ch[k] * v1; }
-            const float idx = __int_as_float(batch_start + t);
-            T0 = sel(c0, nT0, T0); last0 = sel(c0, idx, last0);
-            T1 = sel(c1, nT1, T1); last1 = sel(c1, idx, last1);
-            if ((done0 & done1) == ~0ull) todo = 0;      // all 128 pixels saturated (not a `break`: a second loop exit makes hipcc copy every accumulator at the latch)
+            T0 = nT0; T1 = nT1;
+        }
+        // A pixel that blended anything in this batch and is still open: every entry of the batch behind its last blended one was
+        // skipped for it, so the END of the batch serves as its "last index" — the backward replays a few no-ops more, and the loop
+        // above does not have to remember the index splat by splat (two selects per splat).
+        {
+            const float bend = __int_as_float(min(batch_start + DNS_WAVE, range_end) - 1);
+            last0 = sel(any0 & ~done0, bend, last0);
+            last1 = sel(any1 & ~done1, bend, last1);
+            any0 = 0ull; any1 = 0ull;
         }
         __builtin_amdgcn_wave_barrier();
     }

@@ -134,11 +134,13 @@ def _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest
     C = viewmats.shape[0]
     cfg = ProjCfg(width=width, height=height, tile_size=16, eps2d=eps2d, near_plane=near_plane, far_plane=far_plane,
                   antialiased=False, scales_are_log=True, opacities_are_logit=True, sh_degree=int(sh_degree),
-                  with_depth=True, with_normals=True, want_normals_world=True, tight_tiles=_ops.TIGHT_TILES)
+                  with_depth=True, with_normals=True, want_normals_world=True, tight_tiles=_ops.TIGHT_TILES,
+                  split_colours=_ops.SPLIT_COLOURS)
+    side: Dict = {}
     pr = _ops.project(means, quats, scales, opacities.reshape(N), sh0=features_dc, shN=features_rest, viewmat=viewmats,
-                      K=Ks, normal_frame=nfs, cfg=cfg, saturation_flag=saturation_flag)
+                      K=Ks, normal_frame=nfs, cfg=cfg, saturation_flag=saturation_flag, side=side)
     # the tile lists of this path are internal: tight tile boxes; the projection's "some visible opacity > 0.999" word
-    holder: Dict = {"tight_tiles": cfg.tight_tiles, "saturation_flag": saturation_flag}
+    holder: Dict = {"tight_tiles": cfg.tight_tiles, "saturation_flag": saturation_flag, "colours_ready": side.get("colours_ready")}
     if pair_counters is not None:
         holder["pair_counters"] = pair_counters
     rgb, depth, normal, acc, surface_normal = _ops.rasterize_dn(

@@ -116,6 +116,10 @@ typedef struct dnsplat_proj_out {
     uint32_t *saturation_flag;    /* NULL, or a device word the caller zeroed: set to 1 when a visible Gaussian's opacity (after
                                      the antialiasing compensation) exceeds 0.999, i.e. when alpha = min(0.999, o x vis) can clamp
                                      at all in this frame (A.5).  dnsplat_raster_args.saturation_flag takes it. */
+    int32_t phase;                /* 0: everything in one launch.  SH colours only (scene.sh_degree >= 0): 1 = all outputs except the three
+                                     colour channels of the records (left 0; no coefficient is read), 2 = those three channels for the
+                                     Gaussians with radii > 0 (reads radii and the records' location only).  A caller may run 2 on
+                                     another stream beside dnsplat_bin_*: binning reads nothing phase 2 writes. */
 } dnsplat_proj_out;
 
 int dnsplat_project_fwd(const dnsplat_scene *scene, const dnsplat_camera *cam,
@@ -215,7 +219,8 @@ typedef struct dnsplat_raster_args {
     int32_t ed_channel;                 /* channel normalised by max(alpha,1e-10) ("ED"), or -1 */
     float *render;                      /* [H,W,D] */
     float *alphas;                      /* [H,W] */
-    int32_t *last_ids;                  /* [H,W] sorted index of the last splat applied */
+    int32_t *last_ids;                  /* [H,W] where the backward starts its walk of the pixel's list: a sorted index >= that of the
+                                           last splat applied such that no entry in between applies to the pixel (undefined where alpha == 0) */
     /* backward only */
     const float *v_render;              /* [H,W,D] */
     const float *v_alphas;              /* [H,W] or NULL */
