@@ -162,15 +162,41 @@ def main():
     ap.add_argument("--losses", nargs="?", const="torch", default=None, choices=["torch", "fused"],
                     help="time dn-splatter's loss stack (L1+SSIM, EdgeAwareLogL1 depth, normal L1+TV, scale) instead of feeding "
                          "random cotangents (BASELINE config C5): 'torch' = as the reference does, 'fused' = dnsplat_dn_loss")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, count them with one all-reduce and print {n_gpus, ranks_seen} without rendering (works "
+                         "without a GPU over gloo: the CPU test of the --gpus N self-launch)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    # (one process per GPU over RCCL), so that the line printed is never a single-GPU run labelled as N
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
 
     import dn_splatter_amd as dns
     from dn_splatter_amd import _lib, dp, synthetic
 
-    rank, world, local, dev = dp.init_from_env("cuda")
+    rank, world, local, dev = dp.init_from_env(None if args.rendezvous_only else "cuda")
     if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if torch.distributed.is_initialized():
+        assert torch.distributed.get_world_size() == args.gpus
+    if args.rendezvous_only:
+        seen = int(dp.sum_over_ranks([1.0], dev)[0])
+        dp.barrier()
         if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+            print(json.dumps({"metric": "fwd+bwd frames/sec @1M Gaussians 1080p; HBM GB/s vs roofline", "value": None,
+                              "unit": "frames/s", "n_gpus": world, "multi_gpu": {"ranks_seen": seen},
+                              "note": "rendezvous only: the ranks were started and counted, nothing was rendered"}), flush=True)
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        return
     N, W, H, focal = WORKLOADS[args.workload]
     P = W * H
     T = ((W + 15) // 16) * ((H + 15) // 16)
@@ -211,6 +237,7 @@ def main():
             torch.autograd.backward([out[k] for k in OUT_KEYS], [cot[k] for k in OUT_KEYS])
         return dp.allreduce_gradients(gp, arena, exchange=exchange)
 
+    step_eager = step
     for _ in range(FIRST_TOUCH_STEPS):     # allocations, capacity guesses, code objects (the W warm-up steps come right before the timed region)
         step()
     # Stage breakdown: PROBE_STEPS fully instrumented steps OUTSIDE the timed region.  Bracketing all six stages with
@@ -339,8 +366,9 @@ def main():
     info = renderer.last_info
     I_sorted = int(info["n_isects"])               # what this build bins: the fused path's tight tile boxes
     Nv = int((renderer.radii > 0).sum())
-    # I of SURVEY.md 8(d) is the workload's intersection count under the reference's rule (gsplat's 3-sigma tile box, A.3): the
-    # algorithmic bytes are priced on THAT, whatever share of the pairs an implementation manages not to touch
+    # I of SURVEY.md 8(d) under the reference's rule (gsplat's 3-sigma tile box, A.3) is reported beside it: the bytes a stage is
+    # credited with ("alg_bytes", what `achieved` / `frac` are computed from) are priced on the pairs the launch PROCESSES
+    # (n_isects_sorted), the same formula on the reference-rule count is "alg_bytes_reference_rule"
     with torch.no_grad():
         xy_, r_ = renderer.xys.detach().reshape(-1, 2), renderer.radii.reshape(-1).float()
         tw_, th_ = (W + 15) // 16, (H + 15) // 16
@@ -352,7 +380,8 @@ def main():
     if gstep is not None:
         live_ms = [t * tick_ms for t in stamps.intervals_ticks()]     # one bracket per entry point of the dominant stage and step
     stages = {}
-    sb = stage_bytes(N, Nv, I, P, T)
+    sb = stage_bytes(N, Nv, I_sorted, P, T)
+    sb_ref = stage_bytes(N, Nv, I, P, T)
     for name, b in sb.items():
         if name == dominant and gstep is not None:
             ms = sum(live_ms) / max(args.steps, 1)
@@ -360,7 +389,8 @@ def main():
             ms = stage_ms(stats, name, args.steps) if name == dominant else probe_ms.get(name)
         if ms is None:
             continue
-        stages[name] = {"ms": round(ms, 4), "alg_bytes": b, "GBps": round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+        stages[name] = {"ms": round(ms, 4), "alg_bytes": b, "alg_bytes_reference_rule": sb_ref[name],
+                        "GBps": round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
                         "measured": "timed region" if name == dominant else f"{PROBE_STEPS} instrumented steps before it"}
     # HBM bytes per launch from the PMC passes (tools/pmc_traffic.sh -> profiles/pmc_traffic.json: separate FETCH_SIZE and
     # WRITE_SIZE runs of this very command, as MI355X_MICROARCH.md prescribes).  The file records the hash of the kernel
@@ -391,7 +421,10 @@ def main():
     ach = stages[dominant]["GBps"]
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic,
-                "alg_bytes_per_launch": sb[dominant], "ms_per_launch": stages[dominant]["ms"]}
+                "alg_bytes_per_launch": sb[dominant], "alg_bytes_reference_rule": sb_ref[dominant],
+                "ms_per_launch": stages[dominant]["ms"],
+                # the metric asks for the HBM figure; what BINDS this kernel is vector issue (roofline_valu)
+                "binding_roofline": "roofline_valu" if dominant in ("dnsplat_raster_bwd", "dnsplat_raster_fwd") else "hbm"}
     if traffic_note:
         roofline["traffic_note"] = traffic_note
     # VALU roofline of the two compositing kernels (what binds them: DESIGN.md §4)
@@ -412,10 +445,54 @@ def main():
                                        "useful_pair_fraction": round(useful / max(issued, 1), 4)}
     B = sum(sb.values())
     fps_total = world * args.steps / elapsed
-    frame_roofline = {"alg_bytes_per_frame": B, "achieved_GBps": round(B * (args.steps / elapsed) / 1e9, 1),
+    frame_roofline = {"alg_bytes_per_frame": B, "alg_bytes_reference_rule": sum(sb_ref.values()),
+                      "achieved_GBps": round(B * (args.steps / elapsed) / 1e9, 1),
                       "frac": round(B * (args.steps / elapsed) / 1e9 / HBM_PEAK_GBS, 4)}
     gpu_stage_ms = sum(v["ms"] for v in stages.values())
     i_all = dp.sum_over_ranks([float(I)], dev)[0]
+
+    # ---- the index-exact configuration, after the timed region ------------------------------------------------------------
+    # The fused path bins over tight tile boxes: its sorted lists are a sub-list of gsplat's (the pairs left out cannot reach
+    # alpha >= 1/255 anywhere in their tile; images and gradients are the same numbers).  With gsplat's own boxes
+    # (DNSPLAT_TIGHT_TILES=0) flatten_ids / isect_offsets are the reference's bit for bit — that configuration is timed here.
+    strict = None
+    from dn_splatter_amd import _ops as _ops_mod2
+    if world == 1 and exchange is None and not args.two_call and not args.torch_postops and _ops_mod2.TIGHT_TILES:
+        _ops_mod2.TIGHT_TILES = False
+        try:
+            renderer.forget()
+            K3 = max(5, min(20, args.steps))
+            dns.set_bin_policy("capacity")      # the first frame outgrows the capacity the tight lists needed: repaired in place
+            for _ in range(3):
+                step_eager()
+            torch.cuda.synchronize()
+            dns.set_bin_policy("deferred")
+            sprobe = _lib.StageTimer()
+            _lib.TIMER = sprobe
+            for _ in range(PROBE_STEPS):
+                step_eager()
+            torch.cuda.synchronize()
+            _lib.TIMER = None
+            sst = sprobe.summary()
+            for _ in range(PREROLL_STEPS):
+                step_eager()
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(K3):
+                step_eager()
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - ts
+            strict = {"what": "same step with gsplat's 3-sigma tile boxes (DNSPLAT_TIGHT_TILES=0): flatten_ids / isect_offsets / "
+                              "tiles_per_gauss are the reference's bit for bit (tests/test_gpu_parity.py)",
+                      "value": round(K3 / dts, 3), "unit": "frames/s", "ms_per_step": round(1e3 * dts / K3, 4), "steps": K3,
+                      "launch": "eager launches from Python", "n_isects_sorted": int(renderer.last_info["n_isects"]),
+                      "stages_ms": {name: round(stage_ms(sst, name, PROBE_STEPS), 4) for name in STAGE_NAMES
+                                    if stage_ms(sst, name, PROBE_STEPS) is not None}}
+        except Exception as e:
+            strict = {"value": None, "error": repr(e)}
+        finally:
+            _lib.TIMER = None
+            _ops_mod2.TIGHT_TILES = True
 
     # ---- multi-GPU accounting, all outside the timed region ----------------------------------------
     multi = None
@@ -454,8 +531,10 @@ def main():
         multi = {"step_ms": round(t_step, 4), "compute_only_ms": round(t_compute, 4), "exchange_alone_ms": round(t_comm, 4),
                  "exchange_exposed_ms": round(exposed, 4), "exchange_hidden_ms": round(max(0.0, t_comm - exposed), 4),
                  "bytes_exchanged_per_gpu_per_step": int(wire),
-                 "bytes_per_xgmi_link_per_step": int(wire / max(world - 1, 1)),
-                 "link_note": "per-GPU bytes spread evenly over the W-1 direct xGMI links of the fully connected node",
+                 "bytes_per_xgmi_link_per_step": int(wire / (world - 1)) if world > 1 else None,
+                 "link_note": ("per-GPU bytes spread evenly over the W-1 direct xGMI links of the fully connected node" if world > 1
+                               else "one rank: the collectives ran through RCCL but nothing crossed a link"),
+                 "ranks_seen": world,
                  "isects_per_rank": [int(x) for x in per_rank_I],
                  "isects_max_over_mean": round(max(per_rank_I) / (sum(per_rank_I) / len(per_rank_I)), 4)}
 
@@ -490,6 +569,7 @@ def main():
             "roofline": roofline,
             "roofline_valu": roofline_valu,
             "frame_roofline": frame_roofline,
+            "strict_index_parity": strict,
             "multi_gpu": multi,
             "stages": stages,
             "other_ms_torch_postops_autograd_host": round(1e3 * elapsed / args.steps - gpu_stage_ms, 4),

@@ -54,7 +54,7 @@ class ProjOut(ctypes.Structure):
         ("compensations", c_void_p), ("tiles_per_gauss", c_void_p), ("splats", c_void_p),
         ("normals_world", c_void_p),
         ("with_depth_channel", c_int32), ("with_normal_channels", c_int32), ("saturation_flag", c_void_p),
-        ("phase", c_int32),
+        ("tiles_bin", c_void_p), ("phase", c_int32),
     ]
 
 

@@ -82,7 +82,8 @@ class _Buffers:
         self.pinned: Dict[torch.device, Tensor] = {}
         self.ring: Dict[tuple, dict] = {}
         self.side: Dict[tuple, "torch.cuda.Stream"] = {}
-        self.n_max: Dict[tuple, Tensor] = {}     # "static" bin policy: running maximum of n_isects per (device, stream)
+        self.static_cap: Dict[tuple, int] = {}
+        self.n_max: Dict[tuple, Tensor] = {}     # "static" bin policy: running maximum of n_isects per (device, stream) + frame size key
         self.capacity_hint: Dict[tuple, int] = {}
 
     @staticmethod
@@ -220,15 +221,18 @@ class _PendingCount:
         return self.n
 
 
-def static_overflow(device, width: int, height: int, n_entries: int) -> Optional[int]:
-    """ "static" bin policy: the largest intersection count any frame of the current stream produced, if it exceeded the
-    capacity those frames ran with (their lists were then truncated), else None.  Synchronises."""
-    t = BUFFERS.n_max.get(_Buffers._key(device))
-    if t is None:
-        return None
-    n = int(t.item())
-    cap = BUFFERS.capacity_hint.get((device, n_entries, width, height), 0)
-    return n if n > cap else None
+def static_overflow(device, stream=None) -> Optional[int]:
+    """ "static" bin policy: the largest intersection count a frame binned on ``stream`` (default: the current one) produced, if
+    it exceeded the capacity the frames of that size ran with (their lists were then truncated), else None.  Synchronises."""
+    skey = (device, (torch.cuda.current_stream(device) if stream is None else stream).cuda_stream)
+    worst = None
+    for k, t in BUFFERS.n_max.items():
+        if k[:2] != skey:
+            continue
+        n = int(t.item())
+        if n > BUFFERS.static_cap.get(k, 0):
+            worst = n if worst is None else max(worst, n)
+    return worst
 
 
 def verify_pending_counts(device, block: bool = False) -> None:
@@ -317,6 +321,8 @@ class _ProjectFn(torch.autograd.Function):
             normal_frame = normal_frame.reshape(-1, 12)
         radii = torch.empty(C, N, dtype=torch.int32, device=dev)
         tiles = torch.empty(C, N, dtype=torch.int32, device=dev)
+        # tight tile boxes: gsplat's count for the caller (info["tiles_per_gauss"]), the tight one for the binning
+        tiles_bin = torch.empty(C, N, dtype=torch.int32, device=dev) if cfg.tight_tiles else None
         means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
         depths = torch.empty(C, N, dtype=torch.float32, device=dev)
         conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
@@ -335,6 +341,7 @@ class _ProjectFn(torch.autograd.Function):
             out.radii, out.means2d, out.depths, out.conics = _ptr(radii[c]), _ptr(means2d[c]), _ptr(depths[c]), _ptr(conics[c])
             out.compensations = _ptr(comp[c]) if comp is not None else None
             out.tiles_per_gauss, out.splats = _ptr(tiles[c]), _ptr(splats[c * N:])
+            out.tiles_bin = _ptr(tiles_bin[c]) if tiles_bin is not None else None
             out.normals_world = _ptr(nworld[c]) if nworld is not None else None
             out.with_depth_channel = int(cfg.with_depth)
             out.with_normal_channels = int(cfg.with_normals)
@@ -360,15 +367,17 @@ class _ProjectFn(torch.autograd.Function):
         ctx.layout = "cat" if coeffs is not None else ("split" if cfg.sh_degree >= 0 else "colors")
         ctx.save_for_backward(means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, radii, splats)
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(radii, tiles)
         empty = torch.empty(0, device=dev)
-        if nworld is not None:
-            ctx.mark_non_differentiable(nworld)
+        if tiles_bin is None:
+            tiles_bin = torch.empty(0, dtype=torch.int32, device=dev)
+        # ONE call: every call of mark_non_differentiable replaces the set of the previous one (normals_world with a grad_fn
+        # would keep the frame's autograd graph alive through gauss_params["normals"])
+        ctx.mark_non_differentiable(*([radii, tiles, tiles_bin] + ([nworld] if nworld is not None else [])))
         return (means2d, depths, conics, comp if comp is not None else empty, splats, radii, tiles,
-                nworld if nworld is not None else empty)
+                nworld if nworld is not None else empty, tiles_bin)
 
     @staticmethod
-    def backward(ctx, v_means2d, v_depths, v_conics, v_comp, v_splats, _r, _t, _n):
+    def backward(ctx, v_means2d, v_depths, v_conics, v_comp, v_splats, _r, _t, _n, _tb):
         means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, radii, splats_fwd = ctx.saved_tensors
         cfg: ProjCfg = ctx.cfg
         N = means.shape[0]
@@ -382,7 +391,14 @@ class _ProjectFn(torch.autograd.Function):
         # on info["means2d"] (or the legacy pass fed with non-detached xys): the kernel takes g.v_means2d INSTEAD of the
         # record's columns, so the two are added here.
         v_m2d = None
-        if v_means2d is not None:
+        via_autograd = v_splats.data_ptr() in _M2D_VIA_AUTOGRAD
+        _M2D_VIA_AUTOGRAD.discard(v_splats.data_ptr())
+        if v_means2d is not None and via_autograd:
+            # means2d was not retained: the compositing backward handed autograd the records' columns 0-1 themselves (a view), so
+            # what arrives is that view — nothing to do, the kernel reads the records — or its sum with the caller's extra terms
+            if not (v_means2d.data_ptr() == v_splats.data_ptr() and v_means2d.stride(-2) == RECORD_FLOATS):
+                v_m2d = v_means2d.reshape(C, N, 2).contiguous()
+        elif v_means2d is not None:
             v_m2d = (v_means2d.reshape(C * N, 2) + v_splats[:, 0:2]).reshape(C, N, 2).contiguous()
         v_dep = v_depths.reshape(C, N).contiguous() if v_depths is not None else None
         v_con = v_conics.reshape(C, N, 3).contiguous() if v_conics is not None else None
@@ -459,10 +475,13 @@ def project(means, quats, scales, opacities, *, coeffs=None, sh0=None, shN=None,
             normal_frame=None, cfg: ProjCfg, saturation_flag: Optional[Tensor] = None, side: Optional[dict] = None):
     """``viewmat`` [4,4] or [C,4,4] (``K``, ``normal_frame`` alike) -> dict(means2d[C,N,2], depths[C,N], conics[C,N,3],
     compensations[C,N] | None, splats[C*N,16], radii[C,N], tiles_per_gauss[C,N], normals_world[C,N,3] | None)"""
-    m2d, dep, con, comp, splats, radii, tiles, nworld = _ProjectFn.apply(
+    m2d, dep, con, comp, splats, radii, tiles, nworld, tiles_bin = _ProjectFn.apply(
         means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, cfg, saturation_flag, side)
+    # tiles_per_gauss: gsplat's count (A.3), always.  tiles_bin: what dnsplat_bin_* must be given — the same tensor, or the count
+    # over the tight boxes when cfg.tight_tiles (the flag travels WITH the counts: rasterize* take both from here)
     return dict(means2d=m2d, depths=dep, conics=con, compensations=comp if comp.numel() else None, splats=splats,
-                radii=radii, tiles_per_gauss=tiles, normals_world=nworld if nworld.numel() else None)
+                radii=radii, tiles_per_gauss=tiles, normals_world=nworld if nworld.numel() else None,
+                tiles_bin=tiles_bin if cfg.tight_tiles else tiles, tight_tiles=bool(cfg.tight_tiles))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -539,7 +558,7 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
         a.splats, a.tight_tiles = _ptr(tight_splats), int(tight_splats is not None)
         # the fused path keeps its lists to itself: [start, end) per tile instead of gsplat's offsets (no fill launch)
         a.tile_ends, a.skip_offsets_fill = _ptr(tile_ends), int(tile_ends is not None)
-        a.n_isects_max = _ptr(BUFFERS.n_max.get(_Buffers._key(dev)))
+        a.n_isects_max = _ptr(BUFFERS.n_max.get(_Buffers._key(dev) + key))
         return a, ws
 
     tile_offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
@@ -553,9 +572,11 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
     if mode == "static" and hint:
         # nothing on the host depends on the count (a frame captured into a HIP graph): the capacity is the hint, and the
         # device keeps a running maximum of n_isects that static_overflow() compares with it whenever the caller likes
-        if _Buffers._key(dev) not in BUFFERS.n_max:
-            BUFFERS.n_max[_Buffers._key(dev)] = torch.zeros(1, dtype=torch.int64, device=dev)
+        if _Buffers._key(dev) + key not in BUFFERS.n_max:
+            BUFFERS.n_max[_Buffers._key(dev) + key] = torch.zeros(1, dtype=torch.int64, device=dev)
         capacity = hint
+        sk = _Buffers._key(dev) + key
+        BUFFERS.static_cap[sk] = min(BUFFERS.static_cap.get(sk, capacity), capacity)      # the smallest buffers any such frame got
         flatten_ids = torch.empty(max(capacity, 1), dtype=torch.int32, device=dev)
         args, _ = make_args(capacity, flatten_ids, tile_offsets)
         args.n_isects_host = None
@@ -678,16 +699,31 @@ def isect_ids(b: Binning, depths: Tensor) -> Tensor:
 
 
 
+# data_ptr of the gradient records whose columns 0-1 were ALSO returned to autograd as means2d's gradient (see below)
+_M2D_VIA_AUTOGRAD = set()
+
+
 def _hand_over_means2d_grad(means2d: Tensor, v_splats: Tensor):
     """gsplat's contract (dn_model.py:517-519): after ``info["means2d"].retain_grad()`` the screen-space gradient is found in
     ``info["means2d"].grad``.  Returning columns 0-1 of the gradient records as means2d's autograd gradient would make the
     retain_grad hook CLONE that strided view (a 13 us copy kernel per frame at 1 M Gaussians) although the projection
-    backward reads the same numbers from the records anyway.  So autograd gets no separate gradient for means2d (None: the
-    records carry it) and the view itself is stored in ``.grad`` — added to whatever is already there, as the hook would."""
-    if not means2d.retains_grad:
-        return
+    backward reads the same numbers from the records anyway.  So with retain_grad() autograd gets no separate gradient for
+    means2d (None: the records carry it) and the view itself is stored in ``.grad`` — added to whatever is already there, as
+    the hook would.  WITHOUT retain_grad() the view is returned to autograd as usual, so that torch.autograd.grad(loss,
+    info["means2d"]) and hooks registered on the tensor see the rasterizer's term; the projection backward is told (through
+    _M2D_VIA_AUTOGRAD) that what it receives for means2d already contains the records' columns.
+    Returns the gradient to hand to autograd for ``means2d``."""
     view = v_splats[:, 0:2].view(means2d.shape)
+    # every projection backward is preceded by the compositing backward that produced ITS gradient records: the entry for this
+    # address is rewritten here each time, so a stale one (a backward that stopped at means2d) can never be mistaken for ours
+    _M2D_VIA_AUTOGRAD.discard(v_splats.data_ptr())
+    if not means2d.retains_grad:
+        if means2d.requires_grad:
+            _M2D_VIA_AUTOGRAD.add(v_splats.data_ptr())
+            return view
+        return None
     means2d.grad = view if means2d.grad is None else means2d.grad + view
+    return None
 
 
 class _RasterFn(torch.autograd.Function):
@@ -715,7 +751,7 @@ class _RasterFn(torch.autograd.Function):
             a.render, a.alphas, a.last_ids = _ptr(render), _ptr(alphas), _ptr(last_ids)
             _lib.run("dnsplat_raster_fwd", _lib.lib().dnsplat_raster_fwd, ctypes.byref(a), _stream())
 
-        tight = bool(holder is not None and holder.get("tight_tiles"))      # ``tiles`` were counted over the tight boxes
+        tight = bool(holder is not None and holder.get("tight"))      # ``tiles`` were counted over the tight boxes
         b = bin_tiles(means2d.detach().reshape(-1, 2), radii.reshape(-1), depths.detach().reshape(-1), tiles.reshape(-1), width,
                       height, tile_size, after_emit=composite, n_cameras=C, tight_splats=splats.detach() if tight else None)
         if holder is not None:
@@ -753,13 +789,17 @@ class _RasterFn(torch.autograd.Function):
         if absgrad:
             # gsplat contract (dn_model.py:512, consumed by nerfstudio after_train via self.xys.absgrad)
             means2d.absgrad = v_splats[:, 14:16].reshape(means2d.shape)
-        _hand_over_means2d_grad(means2d, v_splats)
-        return (None, v_splats) + (None,) * 12
+        return (_hand_over_means2d_grad(means2d, v_splats), v_splats) + (None,) * 12
 
 
 def rasterize(means2d, splats, depths, radii, tiles, *, background=None, width, height, tile_size=16, D,
-              ed_channel=-1, xy_split=None, absgrad=False, holder=None):
-    """-> render [C,H,W,D], alphas [C,H,W] for the C cameras of ``means2d`` [C,N,2] / ``splats`` [C*N,16]."""
+              ed_channel=-1, xy_split=None, absgrad=False, holder=None, tight=False):
+    """-> render [C,H,W,D], alphas [C,H,W] for the C cameras of ``means2d`` [C,N,2] / ``splats`` [C*N,16].
+    ``tiles`` / ``tight``: ``tiles_bin`` and ``tight_tiles`` of the project() result, always taken together (the binning walks the
+    boxes the counts were taken over)."""
+    if tight:
+        holder = {} if holder is None else holder
+        holder["tight"] = True
     if tile_size != 16:
         raise NotImplementedError("libdnsplat composites 16x16 tiles (dn_model.py:470-472 uses BLOCK_WIDTH = 16)")
     if xy_split is None:
@@ -808,7 +848,7 @@ class _RasterDnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, splats, depths, radii, tiles, bg_rgb, width, height, intr, absgrad, holder):
         dev = splats.device
-        tight = bool(holder is not None and holder.get("tight_tiles"))
+        tight = bool(holder is not None and holder.get("tight"))
         ctx.saturation_flag = holder.get("saturation_flag") if holder is not None else None
         C = means2d.shape[0]                     # cameras of the batch; intr = [(fx, fy, cx, cy)] * C
         f32 = dict(dtype=torch.float32, device=dev)
@@ -917,18 +957,20 @@ class _RasterDnFn(torch.autograd.Function):
         _lib.run("dnsplat_raster_bwd", _lib.lib().dnsplat_raster_bwd, ctypes.byref(a), _stream())
         if absgrad:
             means2d.absgrad = v_splats[:, 14:16].reshape(means2d.shape)
-        _hand_over_means2d_grad(means2d, v_splats)
-        return (None, v_splats) + none
+        return (_hand_over_means2d_grad(means2d, v_splats), v_splats) + none
 
 
 def rasterize_dn(means2d, splats, depths, radii, tiles, *, background_rgb, width, height, intrinsics, absgrad=True,
-                 holder=None):
+                 holder=None, tight=False):
     """``intrinsics``: one (fx, fy, cx, cy) per camera of ``means2d`` [C,N,2].
     -> rgb[C,H,W,3], depth[C,H,W,1], normal[C,H,W,3], accumulation[C,H,W,1], surface_normal[C,H,W,3].
     ``holder["pair_counters"]`` (optional uint64 [8] device tensor) switches both compositing kernels to their measurement
     instantiation (bench.py's VALU roofline)."""
     if isinstance(intrinsics[0], (int, float)):
         intrinsics = [tuple(intrinsics)]
+    if tight:          # ``tiles`` = tiles_bin of a projection with tight tile boxes (always taken together from the project() result)
+        holder = {} if holder is None else holder
+        holder["tight"] = True
     return _RasterDnFn.apply(means2d, splats, depths, radii, tiles, background_rgb, width, height, list(intrinsics), absgrad,
                              holder)
 

@@ -417,6 +417,7 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
         p.o.conics[3 * g] = 0.f; p.o.conics[3 * g + 1] = 0.f; p.o.conics[3 * g + 2] = 0.f;
         if (p.o.compensations) p.o.compensations[g] = 0.f;
         p.o.tiles_per_gauss[g] = 0;
+        if (p.c.tight_tiles) p.o.tiles_bin[g] = 0;
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         rec4[0] = z4; rec4[1] = z4; rec4[2] = z4; rec4[3] = z4;
         if (p.o.normals_world) {
@@ -438,18 +439,20 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
     // backward whether this frame holds one at all (dnsplat_proj_out.saturation_flag; many lanes may store the same 1)
     if (p.o.saturation_flag && opac > (float)DNS_ALPHA_MAX) *p.o.saturation_flag = 1u;
     int x0, y0, x1, y1;
-    if (p.c.tight_tiles)
+    dns_tile_bbox(st.mean2d[0], st.mean2d[1], st.radius, p.c.tile_size, tw, th, x0, y0, x1, y1);
+    const int tiles_ref = (y1 - y0) * (x1 - x0);          // gsplat's count (A.3): what info["tiles_per_gauss"] / num_tiles_hit report
+    if (p.c.tight_tiles) {
         dns_snug_tile_bbox(st.mean2d[0], st.mean2d[1], st.conic[0], st.conic[1], st.conic[2], opac, st.radius, p.c.tile_size, tw, th,
                            x0, y0, x1, y1);
-    else
-        dns_tile_bbox(st.mean2d[0], st.mean2d[1], st.radius, p.c.tile_size, tw, th, x0, y0, x1, y1);
+        p.o.tiles_bin[g] = (y1 - y0) * (x1 - x0);          // what the binning of the fused path walks
+    }
 
     p.o.radii[g] = (int32_t)st.radius;
     p.o.means2d[2 * g] = st.mean2d[0]; p.o.means2d[2 * g + 1] = st.mean2d[1];
     p.o.depths[g] = st.mean_c[2];
     p.o.conics[3 * g] = st.conic[0]; p.o.conics[3 * g + 1] = st.conic[1]; p.o.conics[3 * g + 2] = st.conic[2];
     if (p.o.compensations) p.o.compensations[g] = st.compensation;
-    p.o.tiles_per_gauss[g] = (y1 - y0) * (x1 - x0);
+    p.o.tiles_per_gauss[g] = tiles_ref;
 
     float r[DNS_REC];
 #pragma unroll
@@ -954,6 +957,7 @@ static int check_scene(const dnsplat_scene *s, const dnsplat_camera *c, const dn
     if (o->with_normal_channels && !c->normal_frame) return DNSPLAT_ERR_INVALID_ARG;
     if (!o->radii || !o->means2d || !o->depths || !o->conics || !o->tiles_per_gauss || !o->splats)
         return DNSPLAT_ERR_INVALID_ARG;
+    if (c->tight_tiles && !o->tiles_bin) return DNSPLAT_ERR_INVALID_ARG;
     return DNSPLAT_OK;
 }
 

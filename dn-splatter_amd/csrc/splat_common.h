@@ -67,6 +67,9 @@ __device__ __forceinline__ void dns_snug_tile_bbox(float mx, float my, float ca,
     dns_tile_bbox(mx, my, radius, tile_size, tw, th, x0, y0, x1, y1);
     const float tau = logf(255.f * opac);          // alpha = opacity exp(-sigma) >= 1/255  <=>  sigma <= tau
     if (!(tau > 0.f)) { x1 = x0; y1 = y0; return; }   // opacity <= 1/255: never composited
+    // opacity within 0.2 % of 1/255: the ellipse is a fraction of a pixel wide and the fp32 error of the compositing alpha test
+    // (relative ~1e-6 in opacity x vis) is no longer small against the margins below: keep gsplat's box
+    if (tau < 2e-3f) return;
     const float det = ca * cc - cb * cb;
     if (!(det > 0.f)) return;                       // degenerate conic: keep gsplat's box
     // half widths sqrt(2 tau Sigma_xx), sqrt(2 tau Sigma_yy) with Sigma = conic^-1; `rel` covers the cancellation in det

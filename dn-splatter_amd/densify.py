@@ -72,6 +72,13 @@ class DensifyStats:
             cur.copy_(old + inc)
         dist.all_reduce(self.max_2Dsize, op=dist.ReduceOp.MAX, group=group)
 
+    def reset(self, num_points: Optional[int] = None) -> None:
+        """Start over (dn_model.py:359-363 sets the three statistics to None after a refinement), for ``num_points`` Gaussians if
+        the set changed size."""
+        n = self.xys_grad_norm.shape[0] if num_points is None else num_points
+        dev = self.xys_grad_norm.device
+        self.__init__(n, dev)
+
     def clone(self) -> "DensifyStats":
         c = DensifyStats.__new__(DensifyStats)
         c.xys_grad_norm, c.vis_counts, c.max_2Dsize = (self.xys_grad_norm.clone(), self.vis_counts.clone(),
@@ -206,7 +213,10 @@ def refinement_after(gauss_params: Dict[str, Tensor], stats: Optional[DensifySta
                             new_adam[name][key] = rows
                         else:
                             new_adam[name][key] = t
-            report.update(n_split=int(split_par.numel()), n_dup=int(((flags & DUP) != 0).sum()),
+            # n_dup counts every Gaussian the reference duplicates (incl. duplicates its cull removes straight away, which also
+            # count in n_culled); n_dup_kept is what actually stays
+            report.update(n_split=int(split_par.numel()), n_dup=int(((flags & DUP) != 0).sum()), n_dup_kept=int(dup_src.numel()),
+                          n_children_kept=int(n_child),
                           n_culled=report["n_before"] + ns * int(split_par.numel()) + int(((flags & DUP) != 0).sum()) - int(src.numel()))
             params = new_params
         if step < cfg.stop_split_at and step % reset_interval == cfg.refine_every:
@@ -221,3 +231,21 @@ def refinement_after(gauss_params: Dict[str, Tensor], stats: Optional[DensifySta
             report["opacity_reset"] = True
     report["n_after"] = int(params["means"].shape[0])
     return params, new_adam, report
+
+
+def after_refinement(new_params: Dict[str, Tensor], stats=None, report: Optional[dict] = None):
+    """What the caller of ``refinement_after`` has to renew when the Gaussian set changed size, in one place: the statistics start
+    over (dn_model.py:359-363 sets xys_grad_norm / vis_counts / max_2Dsize to None), the flat gradient bucket and the SH factor
+    exchange are rebuilt for the new tensors (their slices and data pointers belong to the old ones), and the binning capacity
+    guesses of the old size are dropped.  Returns the new ``dp.GradArena`` (or None if none was installed)."""
+    from . import _ops, dp
+
+    if stats is not None:
+        stats.reset(int(new_params["means"].shape[0]))
+    arena = None
+    if _ops.GRAD_ARENA is not None:
+        arena = dp.GradArena({k: new_params[k] for k in dp.GRAD_KEYS})
+        _ops.set_grad_arena(arena)
+    if _ops.SH_EXCHANGE is not None:
+        _ops.set_sh_exchange(dp.ShFactorExchange())
+    return arena

@@ -76,14 +76,16 @@ def render_dn(
     bg = None
     if predict_normals:
         bg = torch.tensor([0.0, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0], device=means.device)
-    holder: Dict = {"tight_tiles": cfg.tight_tiles}      # the tile lists of this path are internal: tight tile boxes
-    out, alphas = _ops.rasterize(pr["means2d"], pr["splats"], pr["depths"], pr["radii"], pr["tiles_per_gauss"],
+    holder: Dict = {}
+    # the tile lists of this path are internal: tight tile boxes (counts and flag both from the projection result)
+    out, alphas = _ops.rasterize(pr["means2d"], pr["splats"], pr["depths"], pr["radii"], pr["tiles_bin"],
                                  background=bg, width=width, height=height, tile_size=16, D=D, ed_channel=3,
-                                 xy_split=4, absgrad=absgrad, holder=holder)
+                                 xy_split=4, absgrad=absgrad, holder=holder, tight=pr["tight_tiles"])
     b = holder["binning"]
     info = {
         "means2d": pr["means2d"], "radii": pr["radii"], "depths": pr["depths"], "conics": pr["conics"],
-        "tiles_per_gauss": pr["tiles_per_gauss"], "normals_world": None if pr["normals_world"] is None else pr["normals_world"][-1],
+        "tiles_per_gauss": pr["tiles_per_gauss"], "tiles_bin": pr["tiles_bin"],
+        "normals_world": None if pr["normals_world"] is None else pr["normals_world"][-1],
         "flatten_ids": b.flatten_ids[: b.n_isects], "isect_offsets": b.tile_offsets[:-1].reshape(1, b.tile_height, b.tile_width),
         "n_isects": b.n_isects, "tile_width": b.tile_width, "tile_height": b.tile_height,
         "width": width, "height": height, "tile_size": 16, "n_cameras": 1, "tight_tiles": cfg.tight_tiles,
@@ -140,16 +142,19 @@ def _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest
     pr = _ops.project(means, quats, scales, opacities.reshape(N), sh0=features_dc, shN=features_rest, viewmat=viewmats,
                       K=Ks, normal_frame=nfs, cfg=cfg, saturation_flag=saturation_flag, side=side)
     # the tile lists of this path are internal: tight tile boxes; the projection's "some visible opacity > 0.999" word
-    holder: Dict = {"tight_tiles": cfg.tight_tiles, "saturation_flag": saturation_flag, "colours_ready": side.get("colours_ready")}
+    holder: Dict = {"saturation_flag": saturation_flag, "colours_ready": side.get("colours_ready")}
     if pair_counters is not None:
         holder["pair_counters"] = pair_counters
     rgb, depth, normal, acc, surface_normal = _ops.rasterize_dn(
-        pr["means2d"], pr["splats"], pr["depths"], pr["radii"], pr["tiles_per_gauss"], background_rgb=background_rgb,
-        width=width, height=height, intrinsics=intr, absgrad=absgrad, holder=holder)
+        pr["means2d"], pr["splats"], pr["depths"], pr["radii"], pr["tiles_bin"], background_rgb=background_rgb,
+        width=width, height=height, intrinsics=intr, absgrad=absgrad, holder=holder, tight=pr["tight_tiles"])
     b = holder["binning"]
     info = _ops.LazyInfo({
         "means2d": pr["means2d"], "radii": pr["radii"], "depths": pr["depths"], "conics": pr["conics"],
-        "tiles_per_gauss": pr["tiles_per_gauss"], "normals_world": pr["normals_world"][-1],      # dn_model.py:558 keeps the last camera's
+        # tiles_per_gauss: gsplat's count (what dn_model.py:524 stores as num_tiles_hit); tiles_bin: the count this path's binning
+        # walked (tight tile boxes) — sum(tiles_bin) == n_isects
+        "tiles_per_gauss": pr["tiles_per_gauss"], "tiles_bin": pr["tiles_bin"],
+        "normals_world": pr["normals_world"][-1],      # dn_model.py:558 keeps the last camera's
         "tile_width": b.tile_width, "tile_height": b.tile_height,
         "width": width, "height": height, "tile_size": 16, "n_cameras": C, "_binning": b, "tight_tiles": cfg.tight_tiles,
         "_saturation_flag": saturation_flag,

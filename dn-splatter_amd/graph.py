@@ -88,13 +88,7 @@ class GraphedStep:
         torch.cuda.current_stream(self.device).wait_stream(s)
 
     def _overflow(self):
-        t = _ops.BUFFERS.n_max.get((self.device, self.stream.cuda_stream))
-        if t is None:
-            return None
-        n = int(t.item())
-        caps = [c for (d, *_), c in _ops.BUFFERS.capacity_hint.items() if d == self.device]
-        # every size binned on this stream shares the running maximum: it must fit the smallest capacity in use
-        return n if caps and n > min(caps) else None
+        return _ops.static_overflow(self.device, self.stream)
 
     def __call__(self, copy: Optional[int] = None):
         """Replays the captured step (copy ``replays % copies`` unless given) on the CURRENT stream.  With several copies the

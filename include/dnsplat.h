@@ -116,6 +116,9 @@ typedef struct dnsplat_proj_out {
     uint32_t *saturation_flag;    /* NULL, or a device word the caller zeroed: set to 1 when a visible Gaussian's opacity (after
                                      the antialiasing compensation) exceeds 0.999, i.e. when alpha = min(0.999, o x vis) can clamp
                                      at all in this frame (A.5).  dnsplat_raster_args.saturation_flag takes it. */
+    int32_t *tiles_bin;           /* required iff camera.tight_tiles: [N] tile count over the TIGHT box (what dnsplat_bin_args.tiles_per_gauss
+                                     must then be given); tiles_per_gauss itself always receives gsplat's count (A.3), which is what
+                                     info["tiles_per_gauss"] / DNSplatterModel.num_tiles_hit (dn_model.py:524) report */
     int32_t phase;                /* 0: everything in one launch.  SH colours only (scene.sh_degree >= 0): 1 = all outputs except the three
                                      colour channels of the records (left 0; no coefficient is read), 2 = those three channels for the
                                      Gaussians with radii > 0 (reads radii and the records' location only).  A caller may run 2 on

@@ -457,7 +457,7 @@ def tight_tile_boxes(means2d: Tensor, conics: Tensor, opacities: Tensor, radii: 
     ly0 = torch.floor(my / ts - r / ts).clamp(0, tile_height); ly1 = torch.ceil(my / ts + r / ts).clamp(0, tile_height)
     tau = torch.log(255.0 * o)
     det = ca * cc - cb * cb
-    ok = (tau > 0) & (det > 0)
+    ok = (tau >= 2e-3) & (det > 0)                      # opacity within 0.2 % of 1/255: gsplat's box (rounding of the alpha test)
     s = 2.0 * tau / det
     rel = 1e-4 + 2.4e-7 * ((ca * cc + cb * cb) / det)
     hx = torch.sqrt(s * cc) * (1.0 + rel) + 0.01

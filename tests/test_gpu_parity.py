@@ -198,7 +198,10 @@ def _check_mirror(hip, ora, keep, what="mirror", quat_atol=0.0, ints=True):
             kept = torch.isin(key_o, key_g)
             assert_equal_int(fid_o[kept], fid_g, what + " tight tile lists are an order-preserving sub-list of the reference's")
             assert_equal_int(tile_o[kept], tile_g, what + " tight tile lists: tiles")
-            assert (t_g[solid] <= t_o[solid]).all()
+            # what the caller sees (info["tiles_per_gauss"] / num_tiles_hit, dn_model.py:524) is gsplat's count, bit for bit;
+            # the count the binning walked is never larger
+            assert_equal_int(t_g[solid], t_o[solid], what + " num_tiles_hit (tight tile boxes are internal)")
+            assert (m_g.last_info["tiles_bin"].reshape(-1).cpu()[solid] <= t_o[solid]).all()
             gone_t, gone_g = tile_o[~kept], fid_o[~kept]
             info_o = m_o.last_info
             tw_ = int(info_o["tile_width"]) if "tile_width" in info_o else int(info_o["isect_offsets"].shape[-1])
@@ -525,10 +528,10 @@ def test_get_outputs_mirror_matches_reference_sequence(dns, orc, mode):
         assert int(m_g.last_info["_saturation_flag"].item()) == 0
     _check_mirror(hip, ora, keep, "mirror " + mode, ints=False)
     assert_equal_int(m_g.radii, m_o.radii, "radii")
-    if m_g.last_info.get("tight_tiles"):      # the fused path counts the tiles of its tight boxes (dnsplat_camera.tight_tiles)
-        assert bool((m_g.num_tiles_hit.reshape(-1).cpu() <= m_o.num_tiles_hit.reshape(-1)).all())
-    else:
-        assert_equal_int(m_g.num_tiles_hit.reshape(-1), m_o.num_tiles_hit.reshape(-1), "num_tiles_hit")
+    # the fused path bins over tight tile boxes internally (info["tiles_bin"]); what it reports is gsplat's count
+    assert_equal_int(m_g.num_tiles_hit.reshape(-1), m_o.num_tiles_hit.reshape(-1), "num_tiles_hit")
+    if m_g.last_info.get("tight_tiles"):
+        assert bool((m_g.last_info["tiles_bin"].reshape(-1).cpu() <= m_o.num_tiles_hit.reshape(-1)).all())
     # surface_normal is a finite-difference stencil of the depth image: depth noise is amplified by ~fx/d, so it
     # is compared on the 99.9 % quantile of the error; the border must be exactly the reference's 0.5
     d_sn = (out_g["surface_normal"].detach().cpu() - out_o["surface_normal"].detach()).abs().reshape(-1)
@@ -1138,8 +1141,8 @@ def test_full_size_binning_properties(dns, full_scene):
     info = m.last_info
     assert _ops.binning_status(info["_binning"], info["radii"].numel()) == 0, "a look-back wait of the tile sort timed out"
     n = info["n_isects"]
-    tiles = info["tiles_per_gauss"][0].long()
-    assert int(tiles.sum()) == n, "sum(tiles_per_gauss) != n_isects"
+    tiles = info["tiles_bin"][0].long()          # the count the binning walked (== tiles_per_gauss unless tight tile boxes)
+    assert int(tiles.sum()) == n, "sum(tiles_bin) != n_isects"
     if info.get("tight_tiles"):     # a visible Gaussian may reach alpha >= 1/255 at no pixel centre at all
         assert int(((tiles > 0) & ~(info["radii"][0] > 0)).sum()) == 0
     else:
@@ -1230,7 +1233,9 @@ def test_tight_tile_boxes_change_the_lists_not_the_images(dns):
                 cot = [torch.rand(out[k].shape, device=DEV, generator=gen) * 2 - 1 for k in keys]
             torch.autograd.backward([out[k] for k in keys], cot)
             res[tight] = ({k: out[k].detach().clone() for k in keys}, {k: v.grad.clone() for k, v in gp.items() if v.grad is not None},
-                          int(r.last_info["n_isects"]), r.last_info["tiles_per_gauss"].clone(), r.radii.clone())
+                          int(r.last_info["n_isects"]), r.last_info["tiles_bin"].clone(), r.radii.clone())
+            if tight:   # the reported count stays gsplat's
+                assert torch.equal(r.last_info["tiles_per_gauss"], res[False][3])
     finally:
         _ops.TIGHT_TILES = old
     (o0, g0, n0, t0, r0), (o1, g1, n1, t1, r1) = res[False], res[True]
@@ -1280,6 +1285,19 @@ def test_extra_terms_on_means2d_add_to_the_compositing_gradient(dns, orc):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         assert info2["means2d"].grad is None
+    # ... but the tensor still takes part in autograd like any other: torch.autograd.grad on it and a hook registered on it see
+    # the rasterizer's term (+ the extra one), and the parameters receive the same gradients as with retain_grad()
+    gk = to_leaf(inp, DEV)
+    r3, _, info3 = dns.rasterization(**gk, viewmats=viewmat.to(DEV), Ks=K.to(DEV), **kw)
+    seen = {}
+    info3["means2d"].register_hook(lambda g: seen.__setitem__("g", g.detach().clone()))
+    loss3 = (r3 * v_r.to(DEV)).sum() + (info3["means2d"] * w.to(DEV)).sum()
+    g_m2d, = torch.autograd.grad(loss3, info3["means2d"], retain_graph=True)
+    assert_close(g_m2d, info_o["means2d"].grad, "autograd.grad(loss, means2d) without retain_grad")
+    loss3.backward()
+    assert_close(seen["g"], info_o["means2d"].grad, "hook on means2d without retain_grad")
+    for k in ("means", "scales", "quats"):
+        assert_close(gk[k].grad, ci[k].grad, "grad " + k + " with an extra term on means2d, no retain_grad")
 
 
 def test_second_backward_through_the_same_frame_gets_fresh_gradient_records(dns):
@@ -1299,3 +1317,113 @@ def test_second_backward_through_the_same_frame_gets_fresh_gradient_records(dns)
     loss.backward()
     for k in g1:
         assert_close(gp[k].grad, g1[k], "second backward: grad " + k, tol=1e-5)
+
+
+def test_deferred_bin_policy_same_frames_and_a_loud_overflow(dns):
+    """'deferred' (bench.py's policy for eager launches): the host never waits for a frame's intersection count, it verifies it
+    once it has arrived.  Same images, gradients and lists as 'sync'; a capacity guess that turns out too small RAISES (at the
+    latest when the count is asked for) instead of leaving truncated lists behind, and enlarges the guess."""
+    from dn_splatter_amd import _lib, _ops, synthetic
+
+    gp = synthetic.make_gauss_params(20_000, sh_rest_std=0.1, seed=4, device=DEV)
+    cam = synthetic.orbit_camera(2, width=320, height=240, focal=200.0).to(DEV)
+    keys = ("rgb", "depth", "normal", "accumulation")
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    cot = None
+
+    def frame(policy):
+        nonlocal cot
+        dns.set_bin_policy(policy)
+        for v in gp.values():
+            v.grad = None
+        r = dns.DNSplatterRenderer(gp, fused=True)
+        out = r.get_outputs(cam)
+        if cot is None:
+            cot = [torch.rand(out[k].shape, device=DEV, generator=gen) * 2 - 1 for k in keys]
+        torch.autograd.backward([out[k] for k in keys], cot)
+        return ({k: out[k].detach().clone() for k in keys}, {k: v.grad.clone() for k, v in gp.items() if v.grad is not None}, r)
+
+    try:
+        o0, g0, r0 = frame("sync")
+        n0 = int(r0.last_info["n_isects"])
+        o1, g1, r1 = frame("deferred")
+        assert r1.last_info["_binning"].pending is not None or r1.last_info["_binning"]._n is not None
+        assert int(r1.last_info["n_isects"]) == n0                       # reading it is what waits
+        for k in keys:
+            assert torch.equal(o0[k], o1[k]), k
+        for k in g0:
+            assert_close(g1[k], g0[k], "deferred vs sync: grad " + k, tol=1e-5)
+        assert_equal_int(r1.last_info["flatten_ids"], r0.last_info["flatten_ids"], "flatten_ids deferred vs sync")
+        assert_equal_int(r1.last_info["isect_offsets"], r0.last_info["isect_offsets"], "isect_offsets deferred vs sync")
+        key = (torch.device(DEV), 20_000, 320, 240)
+        _ops.BUFFERS.capacity_hint[key] = 1000                           # far below the real count
+        with pytest.raises(_lib.DnsplatError, match="exceed the capacity"):
+            _, _, r2 = frame("deferred")
+            _ops.verify_pending_counts(torch.device(DEV), block=True)
+        assert _ops.BUFFERS.capacity_hint[key] >= n0                     # enlarged: the repeated step goes through
+        o3, g3, r3 = frame("deferred")
+        _ops.verify_pending_counts(torch.device(DEV), block=True)
+        for k in keys:
+            assert torch.equal(o0[k], o3[k]), k
+    finally:
+        dns.set_bin_policy("sync")
+
+
+def test_graphed_step_replays_equal_eager_frames(dns):
+    """graph.GraphedStep: get_outputs + backward captured into a HIP graph ('static' bin policy, no host code between the
+    kernels) and replayed — same outputs and gradients as eager frames, also after the camera pose was changed in place, and
+    check() notices a frame that outgrew the captured buffers."""
+    from dn_splatter_amd import _lib, _ops, dp, synthetic
+    from dn_splatter_amd.graph import GraphedStep
+
+    gp = synthetic.make_gauss_params(20_000, sh_rest_std=0.1, seed=6, device=DEV)
+    cams = [synthetic.orbit_camera(i, width=320, height=240, focal=200.0).to(DEV) for i in (1, 3)]
+    cam = synthetic.orbit_camera(1, width=320, height=240, focal=200.0).to(DEV)      # its pose tensor is what the graph reads
+    keys = ("rgb", "depth", "normal", "accumulation")
+    gen = torch.Generator(device=DEV).manual_seed(8)
+    shapes = {"rgb": (240, 320, 3), "depth": (240, 320, 1), "normal": (240, 320, 3), "accumulation": (240, 320, 1)}
+    cot = [torch.rand(shapes[k], device=DEV, generator=gen) * 2 - 1 for k in keys]
+    r = dns.DNSplatterRenderer(gp, fused=True)
+
+    def compute():
+        out = r.get_outputs(cam)
+        torch.autograd.backward([out[k] for k in keys], cot)
+        return out
+
+    def eager(c):
+        dns.set_bin_policy("sync")
+        for v in gp.values():
+            v.grad = None
+        r.forget()
+        out = r.get_outputs(c)
+        torch.autograd.backward([out[k] for k in keys], cot)
+        res = ({k: out[k].detach().clone() for k in keys}, {k: v.grad.clone() for k, v in gp.items() if v.grad is not None})
+        r.forget()
+        return res
+
+    try:
+        ref = [eager(c) for c in cams]
+        for v in gp.values():
+            v.grad = None
+        step = GraphedStep(compute, params={k: gp[k] for k in dp.GRAD_KEYS})
+        for i in (0, 1, 0):
+            cam.camera_to_worlds.copy_(cams[i].camera_to_worlds)          # a new pose, in place
+            out = step()
+            torch.cuda.synchronize()
+            for k in keys:
+                assert torch.equal(out[k], ref[i][0][k]), (i, k)
+            for k, g in ref[i][1].items():
+                assert_close(gp[k].grad, g, f"graph replay, camera {i}: grad {k}", tol=1e-5)
+        step.check()
+        # a frame that needs more intersections than the captured buffers hold is noticed (here: by shrinking what the check
+        # believes the capacity to be)
+        for kk in list(_ops.BUFFERS.static_cap):
+            if kk[3:] == (20_000, 320, 240):
+                _ops.BUFFERS.static_cap[kk] = 10
+        with pytest.raises(_lib.DnsplatError, match="more than the captured buffers hold"):
+            step.check()
+    finally:
+        dns.set_bin_policy("sync")
+        for kk in list(_ops.BUFFERS.static_cap):
+            if kk[3:] == (20_000, 320, 240):
+                del _ops.BUFFERS.static_cap[kk]

@@ -192,3 +192,26 @@ def test_refinement_step_equals_the_reference_sequence(step, kw):
     if step == 3100:
         assert report["opacity_reset"] and float(new["opacities"].max()) <= float(torch.logit(torch.tensor(0.2))) + 1e-6
         assert float(new_adam["opacities"]["exp_avg"].abs().max()) == 0.0
+
+
+def test_bench_gpus_n_starts_n_ranks():
+    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run with two ranks (gloo here:
+    no GPU) and refuses to print a line for fewer ranks than it was asked for (a single-GPU run must never be
+    labelled n_gpus: N)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c1", "--rendezvous-only"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["multi_gpu"]["ranks_seen"] == 2
+    # a launcher that started another number of ranks than --gpus says is an error, not a relabelled run
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                         capture_output=True, text=True, timeout=300, env=env2, cwd=root)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
