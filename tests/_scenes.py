@@ -70,6 +70,34 @@ def zero_borderline(v, keep):
     return v * k[..., None]
 
 
+# gradient entries per comparison that may need the fp64 envelope (beyond the plain tolerance): the suite's own scenes need none
+# (worst plain ratio 0.77, gpurun_out margins), unseen anisotropic scenes a handful (tools/parity_seed_sweep.py)
+ENVELOPE_MAX_ENTRIES = 8
+ENVELOPE_MAX_FRACTION = 2e-5
+
+
+def assert_close_groups(a, b, what, groups, dim=-1, **kw):
+    """assert_close on slices of ``dim`` taken separately, each against the scale of ITS slice of the reference: rgb and expected
+    depth of a render (depth ~ 3-13 would otherwise set the scale for the colours), the SH bands of a coefficient gradient
+    (band 0 is an order of magnitude above the rest).  ``groups``: [(name, lo, hi), ...]."""
+    env, keep = kw.pop("envelope", None), kw.get("keep")
+    for name, lo, hi in groups:
+        idx = [slice(None)] * a.dim()
+        idx[dim] = slice(lo, hi)
+        if lo >= a.shape[dim]:
+            continue
+        assert_close(a[tuple(idx)], b[tuple(idx)], f"{what}[{name}]", envelope=None if env is None else env[tuple(idx)], **kw)
+
+
+def sh_band_groups(K):
+    """bands of a [N, K, 3] coefficient tensor (K = 16: full, 15: features_rest)"""
+    if K == 16:
+        return [("band 0", 0, 1), ("band 1", 1, 4), ("band 2", 4, 9), ("band 3", 9, 16)]
+    if K == 15:
+        return [("band 1", 0, 3), ("band 2", 3, 8), ("band 3", 8, 15)]
+    return [("all", 0, K)]
+
+
 def assert_close(a, b, what, tol=REL_TOL, atol=0.0, keep=None, envelope=None):
     """|a-b| <= tol * max|b| + atol (+ envelope) at every entry (over the pixels selected by ``keep`` for images).
     ``atol`` is only for tensors that are mathematically zero (e.g. the quaternion gradient of isotropic
@@ -105,6 +133,15 @@ def assert_close(a, b, what, tol=REL_TOL, atol=0.0, keep=None, envelope=None):
         strict = (d.max().item() / (tol * scale + atol)) if d.numel() and tol * scale + atol > 0 else 0.0
         with open(log, "a") as f:
             f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]}\t{what}\t{worst:.3f}\t{strict:.3f}\n")
+    if envelope is not None and d.numel():
+        # how many entries the plain tolerance alone would have failed: printed, and bounded — the envelope is for a handful of
+        # ill-conditioned sums, not a second tolerance
+        need = int((d > tol * scale + atol).sum())
+        if need:
+            print(f"[parity] {what}: {need} of {d.numel()} entries needed the fp64 rounding envelope")
+        assert need <= max(ENVELOPE_MAX_ENTRIES, ENVELOPE_MAX_FRACTION * d.numel()), \
+            f"{what}: {need} of {d.numel()} entries are beyond the plain tolerance (allowed: the fp64 envelope for at most " \
+            f"{max(ENVELOPE_MAX_ENTRIES, int(ENVELOPE_MAX_FRACTION * d.numel()))})"
     if worst > 1.0:
         n_bad = int((ratio > 1.0).sum())
         raise AssertionError(f"{what}: max abs error {d.max().item():.3e} vs {tol:.1e} * scale {scale:.3e} + {atol:.1e}"
