@@ -79,27 +79,47 @@ def tv_loss(pred: Tensor) -> Tensor:
     return _dcol(pred).abs().mean() + _drow(pred).abs().mean()
 
 
+def rgb_term(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], ssim_lambda: float = 0.2) -> Tensor:
+    """nerfstudio splatfacto's main_loss, which DNSplatterModel.get_loss_dict takes over unchanged (dn_model.py:624-627, :663):
+    (1 - l) * L1 + l * (1 - SSIM).  Restated from nerfstudio / pytorch_msssim's published definitions (not vendored: unpinned)."""
+    pred_img = outputs["rgb"]
+    ll1 = torch.abs(batch["image"] - pred_img).mean()
+    simloss = 1 - ssim(pred_img, batch["image"])
+    return (1 - ssim_lambda) * ll1 + ssim_lambda * simloss
+
+
+def regularization_term(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], scales: Tensor, depth_lambda: float = 0.2,
+                        depth_tolerance: float = 0.1, use_depth_loss: bool = True, use_normal_loss: bool = True) -> Tensor:
+    """What dn-splatter itself adds in get_loss_dict (dn_model.py:629-727) for regularization_strategy == "dn-splatter" with mono
+    depth / mono normal supervision: ``DNRegularization.get_loss`` (regularization_strategy.py:146-199) on the ground truths the
+    method picks — the image clamped at 10/255 for the edge weights (:633), depth, both normals and their ground truths multiplied
+    by ``batch["mask"]`` if there is one (:646-659).  Pinned to the reference's own text: tests/golden/reference_regularization.npz."""
+    gt_img = batch["image"].clamp(min=10 / 255.0)                                   # dn_model.py:633
+    depth_out, pred_normal = outputs["depth"], outputs["normal"]
+    gt_depth, gt_normal = batch.get("mono_depth"), batch.get("normal")
+    if "mask" in batch:                                                             # dn_model.py:646-659
+        mask = batch["mask"]
+        depth_out = depth_out * mask
+        gt_depth = gt_depth * mask if gt_depth is not None else None
+        gt_normal = gt_normal * mask if gt_normal is not None else None
+        pred_normal = pred_normal * mask
+    loss = torch.min(torch.exp(scales), dim=1, keepdim=True)[0].mean()              # regularization_strategy.py:195-199
+    if use_depth_loss and gt_depth is not None:
+        valid = gt_depth > depth_tolerance                                          # :162
+        d = edge_aware_log_l1(depth_out, gt_depth.float(), gt_img, valid)
+        loss = loss + (d + depth_lambda * d)                                        # :184
+    if use_normal_loss and gt_normal is not None:
+        loss = loss + torch.abs(pred_normal - gt_normal).mean() + tv_loss(pred_normal)   # :188-193
+    return loss
+
+
 def dn_loss(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], scales: Tensor, ssim_lambda: float = 0.2,
             depth_lambda: float = 0.2, depth_tolerance: float = 0.1, use_depth_loss: bool = True,
             use_normal_loss: bool = True) -> Tensor:
     """main_loss of ``DNSplatterModel.get_loss_dict`` for regularization_strategy == "dn-splatter" with mono depth
-    and mono normal supervision (dn_model.py:614-729)."""
-    gt_img = batch["image"].clamp(min=10 / 255.0)                                   # dn_model.py:633
-    pred_img = outputs["rgb"]
-    ll1 = torch.abs(batch["image"] - pred_img).mean()
-    simloss = 1 - ssim(pred_img, batch["image"])
-    loss = (1 - ssim_lambda) * ll1 + ssim_lambda * simloss                          # nerfstudio splatfacto
-    if use_depth_loss and "mono_depth" in batch:
-        gt_depth = batch["mono_depth"]
-        valid = gt_depth > depth_tolerance                                          # regularization_strategy.py:162
-        d = edge_aware_log_l1(outputs["depth"], gt_depth.float(), gt_img, valid)
-        d = d + depth_lambda * d                                                    # :184
-        loss = loss + d
-    if use_normal_loss and "normal" in batch:
-        n = torch.abs(outputs["normal"] - batch["normal"]).mean() + tv_loss(outputs["normal"])   # :188-193
-        loss = loss + n
-    loss = loss + torch.min(torch.exp(scales), dim=1, keepdim=True)[0].mean()       # :195-199
-    return loss
+    and mono normal supervision (dn_model.py:614-729): rgb_loss + regularization_strategy_loss (:727)."""
+    return rgb_term(outputs, batch, ssim_lambda) + regularization_term(outputs, batch, scales, depth_lambda, depth_tolerance,
+                                                                       use_depth_loss, use_normal_loss)
 
 
 def synthetic_batch(width: int, height: int, device, seed: int = 0) -> Dict[str, Tensor]:

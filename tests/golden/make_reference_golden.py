@@ -270,8 +270,192 @@ def get_outputs_case(nrm, path, N=60, W=40, H=24, seed=11):
     print(path, os.path.getsize(path) // 1024, "KiB", "outputs", {k: tuple(v.shape) for k, v in out.items()})
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# DNRegularization.get_loss and DNSplatterModel.get_loss_dict (N2: how the per-pixel terms are COMBINED)
+
+
+def regularization_case(los, path, W=56, H=40, N=300, seed=17):
+    """regularization_strategy.py is loaded as it stands (its only import beside torch is dn_splatter.losses, the reference's
+    own file loaded above): DNRegularization() with its defaults, get_loss on seeded images -> value and gradients.  Then
+    DNSplatterModel.get_loss_dict (dn_model.py:614-729) executed from its source text inside a class whose parent's
+    get_loss_dict (nerfstudio's, absent) is a stand-in returning a recorded rgb term: what is pinned is everything dn-splatter
+    itself does — gt image clamp at 10/255, which depth / normal ground truth is chosen, the mask products, main_loss =
+    rgb_loss + regularization.  The SSIM + L1 rgb term stays nerfstudio's (unpinned)."""
+    import types as _t
+
+    reg_mod = _load("dn_splatter.regularization_strategy", "dn_splatter/regularization_strategy.py")
+    g = torch.Generator().manual_seed(seed)
+    rnd = lambda *shape: torch.rand(*shape, generator=g)       # noqa: E731
+    image = rnd(H, W, 3)
+    image[:6, :9] *= 0.02                                       # below the 10/255 clamp of dn_model.py:633
+    gt_depth = rnd(H, W, 1) * 6 + 0.2
+    gt_depth[10:16, 20:31] = 0.05                               # below depth_tolerance: masked out of the depth term
+    gt_normal = (torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1) + 1) / 2
+    pred_depth = (rnd(H, W, 1) * 6 + 0.2).requires_grad_(True)
+    pred_normal = ((torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1) + 1) / 2).requires_grad_(True)
+    pred_rgb = rnd(H, W, 3).requires_grad_(True)
+    scales = (torch.randn(N, 3, generator=g) * 0.7 - 3.0).requires_grad_(True)
+    save = dict(W=W, H=H, N=N, image=image.numpy(), gt_depth=gt_depth.numpy(), gt_normal=gt_normal.numpy(),
+                pred_depth=pred_depth.detach().numpy(), pred_normal=pred_normal.detach().numpy(),
+                pred_rgb=pred_rgb.detach().numpy(), scales=scales.detach().numpy())
+
+    # (1) the strategy object on its own, defaults of regularization_strategy.py:126-144
+    strat = reg_mod.DNRegularization()
+    save["defaults"] = np.array([strat.depth_tolerance, strat.depth_lambda, strat.normal_lambda], dtype=np.float64)
+    gt_img = image.clamp(min=10 / 255.0)
+    val = strat(pred_depth=pred_depth, gt_depth=gt_depth, pred_normal=pred_normal, gt_normal=gt_normal, scales=scales, gt_img=gt_img)
+    gd, gn, gs = torch.autograd.grad(val, [pred_depth, pred_normal, scales])
+    save.update(reg_value=np.float64(val.item()), reg_v_depth=gd.numpy(), reg_v_normal=gn.numpy(), reg_v_scales=gs.numpy())
+    # its three parts, for the record
+    save["reg_depth_term"] = np.float64(strat.get_depth_loss(pred_depth, gt_depth, gt_img=gt_img).item())
+    save["reg_normal_term"] = np.float64(strat.get_normal_loss(pred_normal, gt_normal).item())
+    save["reg_scale_term"] = np.float64(strat.get_scale_loss(scales=scales).item())
+
+    # (2) get_loss_dict from the reference's text
+    text = extract_method(os.path.join(REF, "dn_splatter/dn_model.py"), "DNSplatterModel", "get_loss_dict")
+    rgb_term = (pred_rgb - image).abs().mean() * 0.8 + 0.05                # stand-in for nerfstudio's main_loss (recorded)
+    src = ("class _Base:\n"
+           "    def get_loss_dict(self, outputs, batch, metrics_dict=None):\n"
+           "        return {'main_loss': _RGB_TERM, 'scale_reg': _SCALE_REG}\n"
+           "class _M(_Base):\n" + "\n".join("    " + ln for ln in text.splitlines()) + "\n")
+    from typing import Dict, List, Union
+    ns = dict(torch=torch, Dict=Dict, List=List, Union=Union, _RGB_TERM=rgb_term, _SCALE_REG=torch.tensor(0.0),
+              normal_from_depth_image=None, CONSOLE=_t.SimpleNamespace(log=lambda *a, **k: None))
+    exec(compile(src, "dn_model.py::DNSplatterModel.get_loss_dict", "exec"), ns)
+    me = ns["_M"]()
+    me.config = _t.SimpleNamespace(normal_supervision="mono", use_depth_loss=True, regularization_strategy="dn-splatter")
+    me.regularization_strategy = strat
+    me.get_gt_img = lambda im: im                                # num_downscales == 0: the image as it is
+    me.scales = scales
+    me.device = torch.device("cpu")
+    outputs = {"rgb": pred_rgb, "depth": pred_depth, "normal": pred_normal, "surface_normal": rnd(H, W, 3)}
+    batch = {"image": image, "mono_depth": gt_depth, "normal": gt_normal.clone()}
+    ld = me.get_loss_dict(outputs, batch)
+    main = ld["main_loss"]
+    gd2, gn2, gs2, gr2 = torch.autograd.grad(main, [pred_depth, pred_normal, scales, pred_rgb])
+    save.update(loss_dict_main=np.float64(main.item()), loss_dict_rgb_term=np.float64(rgb_term.item()),
+                loss_dict_v_depth=gd2.numpy(), loss_dict_v_normal=gn2.numpy(), loss_dict_v_scales=gs2.numpy())
+    # with a mask in the batch (dn_model.py:646-659): depth, both normals and the ground truths are multiplied by it
+    mask = (rnd(H, W, 1) > 0.3).float()
+    pd3 = pred_depth.detach().clone().requires_grad_(True)
+    pn3 = pred_normal.detach().clone().requires_grad_(True)
+    outputs3 = {"rgb": pred_rgb, "depth": pd3, "normal": pn3, "surface_normal": outputs["surface_normal"]}
+    batch3 = {"image": image, "mono_depth": gt_depth, "normal": gt_normal.clone(), "mask": mask}
+    main3 = me.get_loss_dict(outputs3, batch3)["main_loss"]
+    gd3, gn3 = torch.autograd.grad(main3, [pd3, pn3])
+    save.update(mask=mask.numpy(), masked_main=np.float64(main3.item()), masked_v_depth=gd3.numpy(), masked_v_normal=gn3.numpy())
+    np.savez_compressed(path, **save)
+    print(path, os.path.getsize(path) // 1024, "KiB", {k: float(save[k]) for k in ("reg_value", "loss_dict_main", "masked_main")})
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# DNSplatterModel.refinement_after (N3), executed from the reference's own text
+
+
+def refinement_case(path, N=200, seed=23):
+    """dn_model.py:271-386 is cut out and executed as a method.  The five helpers it inherits from nerfstudio's SplatfactoModel
+    (split_gaussians, dup_gaussians, cull_gaussians, dup_in_all_optim, remove_from_all_optim — not vendored) are RECORDING
+    stand-ins that delegate to oracle/densify_ref.py's restatement of them; what this pins is the reference's own text: which
+    masks it forms from which thresholds and statistics, in which order it calls the helpers with which arguments, how it
+    concatenates parameters / max_2Dsize, the splits_mask it hands to the cull, the opacity-reset branch, the statistics reset.
+    One scenario per branch."""
+    import types as _t
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import densify_ref as ref
+
+    text = extract_method(os.path.join(REF, "dn_splatter/dn_model.py"), "DNSplatterModel", "refinement_after")
+    ns = dict(torch=torch, Optimizers=object)
+    exec(compile(text, "dn_model.py::DNSplatterModel.refinement_after", "exec"), ns)
+    reference_refinement_after = ns["refinement_after"]
+
+    class RefModel(ref.Model):
+        def __init__(self, *a, noise_seed=0):
+            super().__init__(*a)
+            self.__dict__["log"] = []
+            self.__dict__["device"] = torch.device("cpu")
+            self.__dict__["_gen"] = torch.Generator().manual_seed(noise_seed)
+            self.__dict__["noise"] = None
+
+        def split_gaussians(self, split_mask, samps):
+            self.log.append(("split_gaussians", split_mask.clone(), int(samps)))
+            self.__dict__["noise"] = torch.randn(samps * int(split_mask.sum()), 3, generator=self._gen)
+            return super().split_gaussians(split_mask, samps, self.noise)
+
+        def dup_gaussians(self, dup_mask):
+            self.log.append(("dup_gaussians", dup_mask.clone()))
+            return super().dup_gaussians(dup_mask)
+
+        def cull_gaussians(self, extra_cull_mask=None):
+            self.log.append(("cull_gaussians", None if extra_cull_mask is None else extra_cull_mask.clone()))
+            deleted = super().cull_gaussians(extra_cull_mask)
+            self.log.append(("cull_result", deleted.clone()))
+            return deleted
+
+        def dup_in_all_optim(self, optimizers, idcs, n):
+            self.log.append(("dup_in_all_optim", idcs.clone(), int(n)))
+            return super().dup_in_all_optim(idcs, n)
+
+        def remove_from_all_optim(self, optimizers, deleted_mask):
+            self.log.append(("remove_from_all_optim", deleted_mask.clone()))
+            return super().remove_from_all_optim(deleted_mask)
+
+    g = torch.Generator().manual_seed(seed)
+    gp = {"means": (torch.rand(N, 3, generator=g) - 0.5) * 6, "scales": torch.randn(N, 3, generator=g) * 1.5 - 4.0,
+          "quats": torch.randn(N, 4, generator=g), "features_dc": torch.rand(N, 3, generator=g),
+          "features_rest": torch.randn(N, 15, 3, generator=g) * 0.1, "opacities": torch.randn(N, 1, generator=g) * 2 - 1,
+          "normals": torch.randn(N, 3, generator=g)}
+    xys_grad_norm = torch.rand(N, generator=g) * 0.01
+    vis_counts = torch.randint(1, 5, (N,), generator=g).float()
+    max_2Dsize = torch.rand(N, generator=g) * 0.1
+    adam = {k: {"exp_avg": torch.randn(v.shape, generator=g), "exp_avg_sq": torch.rand(v.shape, generator=g)} for k, v in gp.items() if k != "normals"}
+    base = dict(warmup_length=500, refine_every=100, reset_alpha_every=30, stop_split_at=15000, stop_screen_size_at=4000,
+                densify_grad_thresh=0.0008, densify_size_thresh=0.01, split_screen_size=0.05, n_split_samples=2,
+                cull_alpha_thresh=0.1, cull_scale_thresh=0.5, cull_screen_size=0.15, continue_cull_post_densification=True)
+    scenarios = [("densify_screen", 3500, {}), ("densify_early", 2500, {}), ("opacity_reset", 3100, {}), ("densify_no_screen", 6500, {}),
+                 ("cull_only", 16000, {}), ("no_cull", 16000, dict(continue_cull_post_densification=False)),
+                 ("big_thresholds", 3500, dict(cull_alpha_thresh=0.005)), ("warmup", 400, {})]
+    save = dict(N=N, num_train_data=100, last_size=np.array([480, 640]), scenario_names=np.array([s[0] for s in scenarios]),
+                xys_grad_norm=xys_grad_norm.numpy(), vis_counts=vis_counts.numpy(), max_2Dsize=max_2Dsize.numpy())
+    for k, v in gp.items():
+        save["param_" + k] = v.numpy()
+    for k, st in adam.items():
+        save["adam_avg_" + k] = st["exp_avg"].numpy(); save["adam_sq_" + k] = st["exp_avg_sq"].numpy()
+    save["config_keys"] = np.array(sorted(base))
+    for name, step, kw in scenarios:
+        cfg = _t.SimpleNamespace(**{**base, **kw})
+        m = RefModel(gp, cfg, step, 100, (480, 640), xys_grad_norm.clone(), vis_counts.clone(), max_2Dsize.clone(), adam, noise_seed=step)
+        opt_state = {} if m.adam is None else m.adam["opacities"]
+        p_key = torch.zeros(1)
+        optimizers = _t.SimpleNamespace(optimizers={"opacities": _t.SimpleNamespace(param_groups=[{"params": [p_key]}], state={p_key: opt_state})})
+        reference_refinement_after(m, optimizers, step)
+        save[name + "__step"] = step
+        save[name + "__config"] = np.array([float(getattr(cfg, k)) for k in sorted(base)])
+        save[name + "__calls"] = np.array([e[0] for e in m.log])
+        for i, e in enumerate(m.log):
+            for j, a in enumerate(e[1:]):
+                if a is None:
+                    save[f"{name}__call{i}_arg{j}_none"] = True
+                elif torch.is_tensor(a):
+                    save[f"{name}__call{i}_arg{j}"] = a.numpy()
+                else:
+                    save[f"{name}__call{i}_arg{j}"] = a
+        if m.noise is not None:
+            save[name + "__noise"] = m.noise.numpy()
+        for k, v in m.gauss_params.items():
+            save[f"{name}__out_{k}"] = v.detach().numpy()
+        for k, st in m.adam.items():
+            save[f"{name}__adam_avg_{k}"] = st["exp_avg"].numpy(); save[f"{name}__adam_sq_{k}"] = st["exp_avg_sq"].numpy()
+        save[name + "__stats_reset"] = np.array([m.xys_grad_norm is None, m.vis_counts is None, m.max_2Dsize is None])
+        print(f"  refinement {name:18s} step {step:6d}: calls {[e[0] for e in m.log]}, {N} -> {m.gauss_params['means'].shape[0]} Gaussians")
+    np.savez_compressed(path, **save)
+    print(path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     cam_mod, nrm_mod, los_mod = load_reference()
     depth_normal_case(nrm_mod, os.path.join(HERE, "reference_depth_normal.npz"))
     loss_case(los_mod, os.path.join(HERE, "reference_losses.npz"))
     get_outputs_case(nrm_mod, os.path.join(HERE, "reference_get_outputs.npz"))
+    regularization_case(los_mod, os.path.join(HERE, "reference_regularization.npz"))
+    refinement_case(os.path.join(HERE, "reference_refinement.npz"))

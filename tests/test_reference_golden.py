@@ -257,3 +257,192 @@ def test_hip_postops_equal_the_reference_pinned_torch_postops():
     for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities"):
         a, b = res[True][1][k].grad, res[False][1][k].grad
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()), k
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# N2: how the loss terms are combined — DNRegularization.get_loss and DNSplatterModel.get_loss_dict, executed from the
+# reference's own files (tests/golden/make_reference_golden.py: regularization_case)
+
+
+def _reg_case():
+    g = _load("reference_regularization.npz")
+    t = lambda k: torch.from_numpy(g[k])       # noqa: E731
+    return g, t
+
+
+def test_regularization_combination_equals_the_reference():
+    """torch_losses.regularization_term == DNRegularization() (regularization_strategy.py:146-199, its own defaults) as
+    DNSplatterModel.get_loss_dict (dn_model.py:614-729) calls it: gt image clamped at 10/255, the (1 + depth_lambda) factor, L1 +
+    TV on the normals, the min-scale term, and the mask products of dn_model.py:646-659.  Value and every gradient."""
+    from dn_splatter_amd import torch_losses as tl
+
+    g, t = _reg_case()
+    assert np.allclose(g["defaults"], [0.1, 0.2, 0.1])        # depth_tolerance, depth_lambda, normal_lambda (unused by get_loss)
+    pd, pn, sc = t("pred_depth").requires_grad_(True), t("pred_normal").requires_grad_(True), t("scales").requires_grad_(True)
+    out = {"rgb": t("pred_rgb"), "depth": pd, "normal": pn}
+    batch = {"image": t("image"), "mono_depth": t("gt_depth"), "normal": t("gt_normal")}
+    v = tl.regularization_term(out, batch, sc)
+    assert abs(float(v) - float(g["reg_value"])) < 2e-6
+    assert abs(float(v) - (float(g["loss_dict_main"]) - float(g["loss_dict_rgb_term"]))) < 2e-6     # main = rgb + regularization
+    assert abs(float(g["reg_depth_term"]) + float(g["reg_normal_term"]) + float(g["reg_scale_term"]) - float(g["reg_value"])) < 2e-6
+    gd, gn, gs = torch.autograd.grad(v, [pd, pn, sc])
+    for got, key in ((gd, "v_depth"), (gn, "v_normal"), (gs, "v_scales")):
+        for pre in ("reg_", "loss_dict_"):
+            ref = t(pre + key)
+            assert float((got - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max())), pre + key
+    # with a mask in the batch
+    pd3, pn3 = t("pred_depth").requires_grad_(True), t("pred_normal").requires_grad_(True)
+    v3 = tl.regularization_term({"rgb": t("pred_rgb"), "depth": pd3, "normal": pn3}, dict(batch, mask=t("mask")), sc)
+    assert abs(float(v3) - (float(g["masked_main"]) - float(g["loss_dict_rgb_term"]))) < 2e-6
+    gd3, gn3 = torch.autograd.grad(v3, [pd3, pn3])
+    assert float((gd3 - t("masked_v_depth")).abs().max()) < 2e-6 and float((gn3 - t("masked_v_normal")).abs().max()) < 2e-6
+    # dn_loss = rgb term + regularization (dn_model.py:727); the rgb term is nerfstudio's L1 + SSIM (unpinned: SSIM is restated)
+    full = tl.dn_loss(out, batch, sc)
+    assert abs(float(full) - float(tl.rgb_term(out, batch)) - float(v)) < 1e-6
+
+
+@pytest.mark.gpu
+def test_hip_fused_loss_equals_the_reference_combination():
+    """dnsplat_dn_loss (N2, fused_loss.dn_loss_fused): its depth / normal cotangents and its value minus the rgb term against the
+    reference-executed DNRegularization / get_loss_dict vectors."""
+    from dn_splatter_amd import fused_loss, torch_losses as tl
+
+    g, t = _reg_case()
+    dev = "cuda:0"
+    pd, pn = t("pred_depth").to(dev).requires_grad_(True), t("pred_normal").to(dev).requires_grad_(True)
+    rgb = t("pred_rgb").to(dev).requires_grad_(True)
+    sc = t("scales").to(dev).requires_grad_(True)
+    out = {"rgb": rgb, "depth": pd, "normal": pn}
+    batch = {"image": t("image").to(dev), "mono_depth": t("gt_depth").to(dev), "normal": t("gt_normal").to(dev)}
+    loss = fused_loss.dn_loss_fused(out, batch, sc)
+    reg = float(loss) - float(tl.rgb_term({k: v.detach() for k, v in out.items()}, batch))
+    assert abs(reg - float(g["reg_value"])) < 2e-5, (reg, float(g["reg_value"]))
+    gd, gn, gs = torch.autograd.grad(loss, [pd, pn, sc])
+    for got, key in ((gd, "loss_dict_v_depth"), (gn, "loss_dict_v_normal"), (gs, "loss_dict_v_scales")):
+        ref = t(key)
+        assert float((got.cpu() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), key
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# N3: DNSplatterModel.refinement_after executed from the reference's own text (refinement_case)
+
+
+def _refinement_scenarios():
+    g = _load("reference_refinement.npz")
+    names = [str(n) for n in g["scenario_names"]]
+    keys = [str(k) for k in g["config_keys"]]
+    return g, names, keys
+
+
+def _scenario_inputs(g, name, keys, device="cpu"):
+    from dn_splatter_amd import densify
+
+    t = lambda k: torch.from_numpy(g[k]).to(device)        # noqa: E731
+    gp = {k: t("param_" + k) for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities", "normals")}
+    adam = {k: {"exp_avg": t("adam_avg_" + k), "exp_avg_sq": t("adam_sq_" + k)} for k in gp if k != "normals"}
+    vals = dict(zip(keys, g[name + "__config"].tolist()))
+    ints = ("warmup_length", "refine_every", "reset_alpha_every", "stop_split_at", "stop_screen_size_at", "n_split_samples")
+    cfg = densify.RefineConfig(**{k: (int(v) if k in ints else (bool(v) if k == "continue_cull_post_densification" else float(v)))
+                                  for k, v in vals.items()})
+    stats = densify.DensifyStats(int(g["N"]), device)
+    stats.xys_grad_norm, stats.vis_counts, stats.max_2Dsize = t("xys_grad_norm"), t("vis_counts"), t("max_2Dsize")
+    return gp, adam, cfg, stats, int(g[name + "__step"])
+
+
+def _calls(g, name):
+    calls = [str(c) for c in g[name + "__calls"]]
+    arg = lambda i, j: (None if f"{name}__call{i}_arg{j}_none" in g else g[f"{name}__call{i}_arg{j}"])      # noqa: E731
+    return calls, arg
+
+
+def test_refinement_restatement_equals_the_reference_text():
+    """oracle/densify_ref.py's refinement_after (what the GPU kernels are tested against) == dn_model.py:271-386 executed from
+    its source with recording stand-ins for the five nerfstudio helpers: same call sequence per branch, same masks, same
+    parameters, Adam moments and statistics reset afterwards — all eight scenarios (densify with / without the screen rules,
+    opacity reset, cull only, no cull, dn-splatter-big's thresholds, warm-up)."""
+    from oracle import densify_ref as ref
+
+    g, names, keys = _refinement_scenarios()
+    expected_calls = {"densify": ["split_gaussians", "dup_gaussians", "dup_in_all_optim", "dup_in_all_optim", "cull_gaussians",
+                                  "cull_result", "remove_from_all_optim"],
+                      "cull": ["cull_gaussians", "cull_result", "remove_from_all_optim"], "none": []}
+    for name in names:
+        gp, adam, cfg, stats, step = _scenario_inputs(g, name, keys)
+        calls, arg = _calls(g, name)
+        kind = "densify" if "split_gaussians" in calls else ("cull" if calls else "none")
+        assert calls == expected_calls[kind], (name, calls)
+        noise = torch.from_numpy(g[name + "__noise"]) if name + "__noise" in g else torch.zeros(0, 3)
+        m = ref.Model(gp, cfg, step, int(g["num_train_data"]), tuple(int(v) for v in g["last_size"]), stats.xys_grad_norm.clone(),
+                      stats.vis_counts.clone(), stats.max_2Dsize.clone(), adam)
+        m.refinement_after(lambda n: noise)
+        for k in gp:
+            ref_out = torch.from_numpy(g[f"{name}__out_{k}"])
+            assert m.gauss_params[k].shape == ref_out.shape, (name, k)
+            assert torch.equal(m.gauss_params[k], ref_out), (name, k)
+        for k in adam:
+            assert torch.equal(m.adam[k]["exp_avg"], torch.from_numpy(g[f"{name}__adam_avg_{k}"])), (name, k)
+            assert torch.equal(m.adam[k]["exp_avg_sq"], torch.from_numpy(g[f"{name}__adam_sq_{k}"])), (name, k)
+        if step > cfg.warmup_length:
+            assert bool(g[name + "__stats_reset"].all()) and m.xys_grad_norm is None and m.max_2Dsize is None
+        if kind == "densify":
+            # the masks the reference formed (arguments it handed to the helpers) against the flag byte of the product's rule
+            flags = ref.classify_torch(gp, stats, cfg, step, tuple(int(v) for v in g["last_size"]), True)
+            splits, dups = torch.from_numpy(arg(0, 0)), torch.from_numpy(arg(1, 0))
+            assert torch.equal((flags & 1) != 0, splits), name + ": split mask"
+            assert torch.equal((flags & 2) != 0, dups), name + ": duplicate mask"
+            assert int(arg(0, 1)) == cfg.n_split_samples and int(arg(2, 1)) == cfg.n_split_samples and int(arg(3, 1)) == 1
+            assert torch.equal(torch.from_numpy(arg(2, 0)), torch.where(splits)[0]) and torch.equal(torch.from_numpy(arg(3, 0)), torch.where(dups)[0])
+            extra = torch.from_numpy(arg(4, 0))           # splits_mask: the parents, then zeros for children and duplicates
+            assert extra.shape[0] == splits.shape[0] + cfg.n_split_samples * int(splits.sum()) + int(dups.sum())
+            assert torch.equal(extra[: splits.shape[0]], splits) and not bool(extra[splits.shape[0]:].any())
+            deleted = torch.from_numpy(arg(5, 0))
+            n0 = splits.shape[0]
+            nch = cfg.n_split_samples * int(splits.sum())
+            assert torch.equal(deleted[:n0], (flags & 4) != 0), name + ": cull of the originals"
+            par = torch.where(splits)[0].repeat(cfg.n_split_samples)
+            assert torch.equal(deleted[n0:n0 + nch], (flags[par] & 8) != 0), name + ": cull of the split children"
+            assert torch.equal(deleted[n0 + nch:], (flags[torch.where(dups)[0]] & 16) != 0), name + ": cull of the duplicates"
+        elif kind == "cull":
+            assert arg(0, 0) is None
+            flags = ref.classify_torch(gp, stats, cfg, step, tuple(int(v) for v in g["last_size"]), False)
+            assert torch.equal(torch.from_numpy(arg(1, 0)), (flags & 4) != 0)
+
+
+def _product_refinement_matches(g, name, keys, device, classify_fn=None, split_fn=None):
+    from dn_splatter_amd import densify
+
+    gp, adam, cfg, stats, step = _scenario_inputs(g, name, keys, device)
+    noise = torch.from_numpy(g[name + "__noise"]).to(device) if name + "__noise" in g else None
+
+    def split_with_reference_noise(params, parents, _own_noise):
+        return (split_fn or densify.split_children)(params, parents, noise)
+
+    new, new_adam, report = densify.refinement_after(gp, stats, cfg, step, int(g["num_train_data"]), tuple(int(v) for v in g["last_size"]),
+                                                     adam_state=adam, seed=1, classify_fn=classify_fn,
+                                                     split_fn=split_with_reference_noise)
+    for k in gp:
+        ref_out = torch.from_numpy(g[f"{name}__out_{k}"])
+        assert new[k].shape == ref_out.shape, (name, k, new[k].shape, ref_out.shape)
+        assert torch.allclose(new[k].cpu(), ref_out, atol=2e-6, rtol=1e-6), (name, k)
+    for k in adam:
+        assert torch.equal(new_adam[k]["exp_avg"].cpu(), torch.from_numpy(g[f"{name}__adam_avg_{k}"])), (name, k)
+        assert torch.equal(new_adam[k]["exp_avg_sq"].cpu(), torch.from_numpy(g[f"{name}__adam_sq_{k}"])), (name, k)
+    return report
+
+
+def test_product_refinement_host_logic_equals_the_reference_text():
+    """densify.refinement_after (flag byte -> index gathers; torch stand-ins for the two kernels on the CPU) ends with the same
+    Gaussian set, in the same row order, and the same Adam moments as the reference's text in every scenario."""
+    from oracle import densify_ref as ref
+
+    g, names, keys = _refinement_scenarios()
+    for name in names:
+        _product_refinement_matches(g, name, keys, "cpu", classify_fn=ref.classify_torch, split_fn=ref.split_children_torch)
+
+
+@pytest.mark.gpu
+def test_hip_refinement_equals_the_reference_text():
+    """The same with dnsplat_densify_classify / dnsplat_densify_split on the GPU."""
+    g, names, keys = _refinement_scenarios()
+    for name in names:
+        _product_refinement_matches(g, name, keys, "cuda:0")
