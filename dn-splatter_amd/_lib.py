@@ -124,7 +124,6 @@ class ProjGrads(ctypes.Structure):
         ("v_sh0", c_void_p), ("v_sh0_stride", c_int32),
         ("v_shN", c_void_p), ("v_shN_stride", c_int32),
         ("v_colors", c_void_p),
-        ("sh_factors", c_void_p),
         ("sh_grads_skip", c_int32),
     ]
 
@@ -188,12 +187,12 @@ def lib() -> ctypes.CDLL:
         L.dnsplat_dn_depth_normals.argtypes = [c_int32, c_int32, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p]
         L.dnsplat_densify_stats.argtypes = [c_int32, c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]
-        L.dnsplat_sh_grads_from_factors.argtypes = [c_int32, c_int32, c_void_p, c_int32, c_int32, c_float, c_void_p, c_int32,
+        L.dnsplat_sh_grads_from_factors.argtypes = [c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p, c_int32,
                                                     c_void_p, c_int32, c_void_p]
         L.dnsplat_dn_loss.argtypes = [ctypes.POINTER(DnLossArgs), c_void_p]
         L.dnsplat_camera_prepare.argtypes = [c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_void_p]
-        L.dnsplat_sh_factors.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.dnsplat_sh_factors.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         for name in EXPORTS:
             if name not in ("dnsplat_strerror", "dnsplat_bin_workspace_bytes", "dnsplat_bin_status_offset"):
                 getattr(L, name).restype = ctypes.c_int

@@ -454,8 +454,8 @@ class _ProjectFn(torch.autograd.Function):
                 # The coefficient-gradient tensors are handed to autograd unwritten; dp.allreduce_gradients fills them.  The
                 # factors come from their own small kernel so that their all-gather is already under way while the geometry
                 # gradients are computed below.
-                fac = ex.begin(N, dev, cfg.sh_degree, sh_K)
-                _lib.run("dnsplat_sh_factors", _lib.lib().dnsplat_sh_factors, N, _ptr(means), _ptr(radii[c]), _ptr(viewmat[c]),
+                fac = ex.begin(N, dev, cfg.sh_degree, sh_K, means=means)
+                _lib.run("dnsplat_sh_factors", _lib.lib().dnsplat_sh_factors, N, _ptr(radii[c]), _ptr(viewmat[c]),
                          _ptr(splats_fwd), _ptr(vs_c), _ptr(fac), _stream())
                 ex.launch()
                 g.sh_grads_skip = 1

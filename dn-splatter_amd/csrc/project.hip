@@ -555,11 +555,9 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
     // place; the block then stores the whole span with coalesced 16-byte writes
     float *lrow = sh_lds + (L == SH_DIRECT ? 0 : threadIdx.x * ShRowTraits<L>::LDS_ROW);
     float *lN = L == SH_CAT ? lrow + 3 : lrow;
-    // factor mode (multi-view data parallelism): hand out (view direction, colour gradient) instead of their outer product
-    float *fact = p.g.sh_factors ? p.g.sh_factors + (size_t)g * 6 : nullptr;
-    // the coefficient gradients are produced elsewhere: from the factors written here, or (sh_grads_skip) from those
-    // dnsplat_sh_factors wrote ahead of this launch
-    const bool sh_elsewhere = p.g.sh_factors || p.g.sh_grads_skip;
+    // the coefficient gradients are produced elsewhere (multi-view data parallelism): from the colour gradients dnsplat_sh_factors
+    // took ahead of this launch, all-gathered and turned into rows by dnsplat_sh_grads_from_factors
+    const bool sh_elsewhere = p.g.sh_grads_skip;
     if (g < p.s.N) {
     const int nbK = (p.s.sh_degree >= 0) ? (p.s.sh_degree + 1) * (p.s.sh_degree + 1) : 0;
 
@@ -590,10 +588,6 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
                          p.c.radius_clip, st);
     }
 
-    if (!ok && fact) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) fact[k] = 0.f;
-    }
     if (!ok) {
         if (L == SH_CAT) { lrow[0] = 0.f; lrow[1] = 0.f; lrow[2] = 0.f; }
         else if (vsh0) { vsh0[0] = 0.f; vsh0[1] = 0.f; vsh0[2] = 0.f; }
@@ -702,7 +696,6 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
                     }
                 for (int k = 3 * (nbK - 1); k < 45; ++k) lN[k] = 0.f;
             }
-            if (fact) { fact[0] = dx; fact[1] = dy; fact[2] = dz; fact[3] = fcol[0]; fact[4] = fcol[1]; fact[5] = fcol[2]; }
             if (p.s.sh_degree >= 1) {
                 float dot = vdn[0] * dx + vdn[1] * dy + vdn[2] * dz;
                 v_mean[0] += (vdn[0] - dot * dx) * inorm;
@@ -836,7 +829,7 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
     p.g.v_scales[3 * g] = v_scale[0]; p.g.v_scales[3 * g + 1] = v_scale[1]; p.g.v_scales[3 * g + 2] = v_scale[2];
     p.g.v_opacities[g] = v_opac;
     }  // g < N
-    if (L != SH_DIRECT && !(p.g.sh_factors || p.g.sh_grads_skip)) {
+    if (L != SH_DIRECT && !p.g.sh_grads_skip) {
         __syncthreads();
         float *base = (L == SH_CAT ? p.g.v_sh0 : p.g.v_shN) + (size_t)g0 * ShRowTraits<L>::ROW;
         sh_stage_out<L>(base, nG * ShRowTraits<L>::ROW, sh_lds);
@@ -867,7 +860,8 @@ __global__ __launch_bounds__(256) void pack_splats_kernel(int N, const float *__
 
 // v_coeff = scale * sum over views of basis(dir_view) (x) v_colour_view  — see dnsplat_sh_grads_from_factors
 template <int L>
-__global__ __launch_bounds__(SH_STAGE_THREADS) void sh_from_factors_kernel(int N, int n_views, const float *__restrict__ factors, int degree,
+__global__ __launch_bounds__(SH_STAGE_THREADS) void sh_from_factors_kernel(int N, int n_views, const float *__restrict__ factors,
+                                                              const float *__restrict__ means, int degree,
                                                               float scale, float *__restrict__ v_sh0, int s0,
                                                               float *__restrict__ v_shN, int sN, int restK)
 {
@@ -880,13 +874,19 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void sh_from_factors_kernel(int N
 #pragma unroll
     for (int i = 0; i < 48; ++i) acc[i] = 0.f;
     if (g < N) {
+        const size_t slab = (size_t)3 * N + 4;             // one view: [N,3] colour gradients | camera position (3) | pad
+        const float mx = means[3 * g], my = means[3 * g + 1], mz = means[3 * g + 2];
         for (int v = 0; v < n_views; ++v) {
-            const float2 *f = reinterpret_cast<const float2 *>(factors + ((size_t)v * N + g) * 6);
-            const float2 f0 = f[0], f1 = f[1], f2 = f[2];   // dir.xy | dir.z col.r | col.g col.b
-            const float c0 = f1.y, c1 = f2.x, c2 = f2.y;
+            const float *f = factors + (size_t)v * slab;
+            const float c0 = f[3 * (size_t)g], c1 = f[3 * (size_t)g + 1], c2 = f[3 * (size_t)g + 2];
             if (c0 == 0.f && c1 == 0.f && c2 == 0.f) continue;
+            // the view direction of camera v, re-derived as the projection kernels of rank v derived it (same operations)
+            const float *pos = f + (size_t)3 * N;
+            float dx = mx - pos[0], dy = my - pos[1], dz = mz - pos[2];
+            const float inorm = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+            dx *= inorm; dy *= inorm; dz *= inorm;
             float bas[16];
-            sh_basis(degree, f0.x, f0.y, f1.x, bas);
+            sh_basis(degree, dx, dy, dz, bas);
 #pragma unroll
             for (int k = 0; k < 16; ++k)
                 if (k < nb) {
@@ -1018,57 +1018,60 @@ extern "C" int dnsplat_project_bwd(const dnsplat_scene *scene, const dnsplat_cam
 }
 
 namespace {
-// The two factors of the SH-coefficient gradient alone (what project_bwd_kernel writes to sh_factors), from the forward's
-// records: the clamp mask is "the clamped colour in the record is positive".
-__global__ __launch_bounds__(256) void sh_factors_kernel(int N, const float *__restrict__ means, const int32_t *__restrict__ radii,
-                                                         const float *__restrict__ viewmat, const float *__restrict__ splats,
-                                                         const float *__restrict__ v_splats, float *__restrict__ factors)
+// The part of a camera's SH-coefficient gradient that has to travel (dnsplat.h): the clamp-masked colour gradient of every
+// Gaussian, from the forward's records ("the clamped colour in the record is positive") and the gradient records, followed by
+// the camera position the receiving ranks re-derive the view directions from.
+__global__ __launch_bounds__(256) void sh_factors_kernel(int N, const int32_t *__restrict__ radii, const float *__restrict__ viewmat,
+                                                         const float *__restrict__ splats, const float *__restrict__ v_splats,
+                                                         float *__restrict__ factors)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= N) return;
-    float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (radii[g] > 0) {
-        float Rv[9], t[3], pos[3];
+    if (g == 0) {
+        // camera centre = -R^T t of the world->camera matrix: exactly what load_cam() hands the projection kernels
+        float Rv[9], t[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) Rv[3 * i + j] = viewmat[4 * i + j];
             t[i] = viewmat[4 * i + 3];
         }
+        float *tail = factors + (size_t)3 * N;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) pos[i] = -(Rv[0 + i] * t[0] + Rv[3 + i] * t[1] + Rv[6 + i] * t[2]);
-        float dx = means[3 * g] - pos[0], dy = means[3 * g + 1] - pos[1], dz = means[3 * g + 2] - pos[2];
-        const float inorm = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
-        f[0] = dx * inorm; f[1] = dy * inorm; f[2] = dz * inorm;
+        for (int i = 0; i < 3; ++i) tail[i] = -(Rv[0 + i] * t[0] + Rv[3 + i] * t[1] + Rv[6 + i] * t[2]);
+        tail[3] = 0.f;
+    }
+    if (g >= N) return;
+    float f[3] = {0.f, 0.f, 0.f};
+    if (radii[g] > 0) {
         const float *rec = splats + (size_t)g * DNS_REC + REC_CH0;
         const float *vr = v_splats + (size_t)g * DNS_REC + REC_CH0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) f[3 + i] = rec[i] > 0.f ? vr[i] : 0.f;
+        for (int i = 0; i < 3; ++i) f[i] = rec[i] > 0.f ? vr[i] : 0.f;
     }
-    float2 *out = reinterpret_cast<float2 *>(factors + (size_t)g * 6);
-    out[0] = make_float2(f[0], f[1]); out[1] = make_float2(f[2], f[3]); out[2] = make_float2(f[4], f[5]);
+    factors[3 * (size_t)g] = f[0]; factors[3 * (size_t)g + 1] = f[1]; factors[3 * (size_t)g + 2] = f[2];
 }
 }  // namespace
 
-extern "C" int dnsplat_sh_factors(int32_t N, const float *means, const int32_t *radii, const float *viewmat, const float *splats,
+extern "C" int dnsplat_sh_factors(int32_t N, const int32_t *radii, const float *viewmat, const float *splats,
                                   const float *v_splats, float *factors, dnsplat_stream_t stream)
 {
     if (N < 0) return DNSPLAT_ERR_INVALID_ARG;
-    if (N == 0) return DNSPLAT_OK;
-    if (!means || !radii || !viewmat || !splats || !v_splats || !factors) return DNSPLAT_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(sh_factors_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, means, radii, viewmat, splats,
+    if (!viewmat || !factors) return DNSPLAT_ERR_INVALID_ARG;
+    if (N > 0 && (!radii || !splats || !v_splats)) return DNSPLAT_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(sh_factors_kernel, dim3((N + 256) / 256), dim3(256), 0, (hipStream_t)stream, N, radii, viewmat, splats,
                        v_splats, factors);
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;
 }
 
-extern "C" int dnsplat_sh_grads_from_factors(int32_t N, int32_t n_views, const float *factors, int32_t sh_degree, int32_t sh_K,
+extern "C" int dnsplat_sh_grads_from_factors(int32_t N, int32_t n_views, const float *factors, const float *means,
+                                             int32_t sh_degree, int32_t sh_K,
                                              float scale, float *v_sh0, int32_t v_sh0_stride, float *v_shN,
                                              int32_t v_shN_stride, dnsplat_stream_t stream)
 {
     if (N < 0 || n_views < 1 || sh_degree < 0 || sh_degree > 3 || sh_K < (sh_degree + 1) * (sh_degree + 1)) return DNSPLAT_ERR_INVALID_ARG;
     if (N == 0) return DNSPLAT_OK;
-    if (!factors || !v_sh0 || (sh_K > 1 && !v_shN)) return DNSPLAT_ERR_INVALID_ARG;
+    if (!factors || !means || !v_sh0 || (sh_K > 1 && !v_shN)) return DNSPLAT_ERR_INVALID_ARG;
     dnsplat_scene fake{};
     fake.sh_degree = sh_degree; fake.sh_K = sh_K;
     const int layout = sh_layout(&fake, v_sh0, v_sh0_stride, v_shN, v_shN_stride);
@@ -1076,15 +1079,15 @@ extern "C" int dnsplat_sh_grads_from_factors(int32_t N, int32_t n_views, const f
     const int restK = sh_K - 1;
     switch (layout) {
         case SH_SPLIT:
-            hipLaunchKernelGGL(sh_from_factors_kernel<SH_SPLIT>, grid, block, 0, (hipStream_t)stream, N, n_views, factors, sh_degree,
+            hipLaunchKernelGGL(sh_from_factors_kernel<SH_SPLIT>, grid, block, 0, (hipStream_t)stream, N, n_views, factors, means, sh_degree,
                                scale, v_sh0, v_sh0_stride, v_shN, v_shN_stride, restK);
             break;
         case SH_CAT:
-            hipLaunchKernelGGL(sh_from_factors_kernel<SH_CAT>, grid, block, 0, (hipStream_t)stream, N, n_views, factors, sh_degree,
+            hipLaunchKernelGGL(sh_from_factors_kernel<SH_CAT>, grid, block, 0, (hipStream_t)stream, N, n_views, factors, means, sh_degree,
                                scale, v_sh0, v_sh0_stride, v_shN, v_shN_stride, restK);
             break;
         default:
-            hipLaunchKernelGGL(sh_from_factors_kernel<SH_DIRECT>, grid, block, 0, (hipStream_t)stream, N, n_views, factors, sh_degree,
+            hipLaunchKernelGGL(sh_from_factors_kernel<SH_DIRECT>, grid, block, 0, (hipStream_t)stream, N, n_views, factors, means, sh_degree,
                                scale, v_sh0, v_sh0_stride, v_shN, v_shN_stride, restK);
     }
     DNS_CHECK_LAUNCH();

@@ -89,45 +89,55 @@ class ShFactorExchange:
     """Compact exchange of the SH-coefficient gradients between the cameras of a data-parallel step.
 
     For one camera the gradient of a Gaussian's 16 x 3 SH coefficients is the outer product of the SH basis of its view
-    direction with the 3 colour gradients: 6 numbers define 48.  Summed over the ranks' cameras that is no longer rank
-    one, but every rank can rebuild the sum from the other ranks' factors.  So instead of all-reducing 192 B per
-    Gaussian (~2 x 7/8 x 192 = 336 B over xGMI per GPU at 8 ranks) the ranks ALL-GATHER 24 B per Gaussian
-    (7 x 24 = 168 B received) and run ``dnsplat_sh_grads_from_factors``; only the 44 B of geometry gradients are
-    all-reduced.  Per-GPU xGMI traffic per Gaussian: 413 B -> 245 B at 8 GPUs, 236 B -> 68 B at 2.  The sums are the
-    same up to fp32 summation order.  ``dnsplat_project_bwd`` also stops writing the 192 B rows itself.
+    direction with the 3 colour gradients, and the view direction is something every rank can work out itself for every
+    camera (replicated means, 12-byte camera position).  Summed over the ranks' cameras the gradient is no longer rank
+    one, but every rank can rebuild the sum from the other ranks' colour gradients.  So instead of all-reducing 192 B per
+    Gaussian (~2 x 7/8 x 192 = 336 B over xGMI per GPU at 8 ranks) the ranks ALL-GATHER 12 B per Gaussian (7 x 12 = 84 B
+    received) and run ``dnsplat_sh_grads_from_factors``; only the 44 B of geometry gradients are all-reduced.  Per-GPU
+    xGMI traffic per Gaussian: 413 B -> 161 B at 8 GPUs, 236 B -> 56 B at 2.  The sums are the same up to fp32 summation
+    order.  ``dnsplat_project_bwd`` also stops writing the 192 B rows itself.
+    One rank's slab: ``[N,3]`` colour gradients, then its camera position (3 floats) and a pad word: 3 N + 4 floats.
     """
 
     def __init__(self):
         self.mine: Optional[Tensor] = None
         self.gathered: Optional[Tensor] = None
         self.meta = None
+        self.means: Optional[Tensor] = None
         self.work = None      # the all-gather in flight (launch())
 
-    def begin(self, N, device, sh_degree, sh_K, v_coeffs=None, v_sh0=None, v_shN=None) -> Tensor:
-        """Called by the projection backward: returns the [N,6] buffer the factors go to and remembers the shape of the
-        gradients to rebuild."""
+    @staticmethod
+    def slab_floats(N: int) -> int:
+        return 3 * N + 4
+
+    def begin(self, N, device, sh_degree, sh_K, means: Optional[Tensor] = None) -> Tensor:
+        """Called by the projection backward: returns the slab (3 N + 4 floats) dnsplat_sh_factors fills and remembers the
+        shape of the gradients to rebuild and the means the view directions are re-derived from."""
         if self.meta is not None:
             raise RuntimeError("ShFactorExchange: the factors of the previous backward were never rebuilt — with set_sh_exchange() "
                                "active every backward must be followed by dp.allreduce_gradients(..., exchange=...) (or "
                                "exchange.finish()); until then features_dc.grad / features_rest.grad are unwritten")
-        if self.mine is None or self.mine.shape[0] != N or self.mine.device != device:
-            self.mine = torch.empty(N, 6, dtype=torch.float32, device=device)
-        # no tensor references are kept here: autograd only adopts the returned gradient tensors as .grad (instead of
+        n = self.slab_floats(N)
+        if self.mine is None or self.mine.shape[0] != n or self.mine.device != device:
+            self.mine = torch.empty(n, dtype=torch.float32, device=device)
+        # no gradient tensors are kept here: autograd only adopts the returned gradient tensors as .grad (instead of
         # cloning them) while nobody else holds them
         self.meta = (N, sh_degree, sh_K)
+        if means is not None:
+            self.means = means.detach()
         self.work = None
         return self.mine
 
     def _gather_buffer(self, w: int) -> Tensor:
-        N = self.meta[0]
-        if self.gathered is None or self.gathered.shape != (w, N, 6) or self.gathered.device != self.mine.device:
-            self.gathered = torch.empty(w, N, 6, dtype=torch.float32, device=self.mine.device)
+        n = self.slab_floats(self.meta[0])
+        if self.gathered is None or self.gathered.shape != (w, n) or self.gathered.device != self.mine.device:
+            self.gathered = torch.empty(w, n, dtype=torch.float32, device=self.mine.device)
         return self.gathered
 
     def launch(self, group=None) -> None:
-        """Start the all-gather of the factors (enqueued after whatever filled ``mine`` on the current stream) without
+        """Start the all-gather of the slabs (enqueued after whatever filled ``mine`` on the current stream) without
         waiting for it: the projection backward calls this right after ``dnsplat_sh_factors`` and BEFORE
-        ``dnsplat_project_bwd``, so the 24 B/Gaussian travel while the geometry gradients are computed."""
+        ``dnsplat_project_bwd``, so the 12 B/Gaussian travel while the geometry gradients are computed."""
         if self.meta is None or not _collectives_on(group):
             return
         buf = self._gather_buffer(world_size(group))
@@ -151,11 +161,11 @@ class ShFactorExchange:
         else:
             buf.copy_(self.mine[None])
         self.meta = None
-        self._rebuild(buf, N, w, sh_degree, sh_K, v_coeffs, v_sh0, v_shN)
-        return (w - 1) * N * 24
+        self._rebuild(buf, self.means, N, w, sh_degree, sh_K, v_coeffs, v_sh0, v_shN)
+        return (w - 1) * self.slab_floats(N) * 4
 
 
-def _rebuild_hip(gathered: Tensor, N: int, w: int, sh_degree: int, sh_K: int, v_coeffs, v_sh0, v_shN) -> None:
+def _rebuild_hip(gathered: Tensor, means: Tensor, N: int, w: int, sh_degree: int, sh_K: int, v_coeffs, v_sh0, v_shN) -> None:
     from . import _lib
     from ._ops import _ptr, _stream
 
@@ -163,8 +173,8 @@ def _rebuild_hip(gathered: Tensor, N: int, w: int, sh_degree: int, sh_K: int, v_
         p0, s0, pN, sN = v_coeffs, 3 * sh_K, v_coeffs.view(-1)[3:], 3 * sh_K
     else:
         p0, s0, pN, sN = v_sh0, 3, v_shN, 3 * (sh_K - 1)
-    _lib.run("dnsplat_sh_grads_from_factors", _lib.lib().dnsplat_sh_grads_from_factors, N, w, _ptr(gathered), sh_degree, sh_K,
-             1.0 / w, _ptr(p0), s0, _ptr(pN), sN, _stream())
+    _lib.run("dnsplat_sh_grads_from_factors", _lib.lib().dnsplat_sh_grads_from_factors, N, w, _ptr(gathered), _ptr(means.contiguous()),
+             sh_degree, sh_K, 1.0 / w, _ptr(p0), s0, _ptr(pN), sN, _stream())
 
 
 ShFactorExchange._rebuild = staticmethod(_rebuild_hip)   # the CPU gloo test swaps in a torch reference

@@ -276,22 +276,25 @@ int dnsplat_camera_prepare(const float *c2w, float fx, float fy, float cx, float
                            float *viewmat, float *K, float *normal_frame, uint32_t *zero_word, dnsplat_stream_t stream);
 
 /* Multi-view data parallelism, compact exchange of the SH gradients.  For one camera the gradient of Gaussian g's SH
- * coefficients is an outer product  v_coeff[g][k][c] = basis_k(dir_g) * v_colour[g][c]  (k < (degree+1)^2, c < 3): 6 numbers
- * determine 48.  With one camera per GPU the ranks therefore all-gather the 24-byte factors instead of all-reducing the
- * 192-byte coefficient gradients (7 x 24 B received per Gaussian instead of ~2 x 7/8 x 192 B over xGMI at 8 GPUs), and
- * every rank rebuilds   v_coeff = scale * sum_views basis(dir_view) (x) v_colour_view   with this kernel.
- * factors: [n_views, N, 6] as written by dnsplat_project_bwd (sh_factors).  Layouts as dnsplat_scene.sh0 / shN. */
-int dnsplat_sh_grads_from_factors(int32_t N, int32_t n_views, const float *factors, int32_t sh_degree, int32_t sh_K,
-                                  float scale, float *v_sh0, int32_t v_sh0_stride, float *v_shN, int32_t v_shN_stride,
-                                  dnsplat_stream_t stream);
+ * coefficients is an outer product  v_coeff[g][k][c] = basis_k(dir_g) * v_colour[g][c]  (k < (degree+1)^2, c < 3), and the
+ * direction dir_g = normalize(mean_g - camera position) is something every rank can work out for every camera: the means are
+ * replicated and a camera position is 12 bytes.  So what travels per (camera, Gaussian) is the clamp-masked colour gradient
+ * alone — 12 bytes instead of the 192 bytes of coefficient gradients: with one camera per GPU the ranks all-gather
+ * [N,3] slabs (7 x 12 B received per Gaussian at 8 GPUs instead of ~2 x 7/8 x 192 B of an all-reduce) and every rank rebuilds
+ *     v_coeff = scale * sum_views basis(normalize(mean - pos_view)) (x) v_colour_view
+ * with dnsplat_sh_grads_from_factors.
+ * factors: n_views slabs of 3 N + 4 floats: [N,3] colour gradients | camera position (3) | 0, as dnsplat_sh_factors writes one.
+ * means: the [N,3] means of the scene.  Layouts of v_sh0 / v_shN as dnsplat_scene.sh0 / shN. */
+int dnsplat_sh_grads_from_factors(int32_t N, int32_t n_views, const float *factors, const float *means, int32_t sh_degree,
+                                  int32_t sh_K, float scale, float *v_sh0, int32_t v_sh0_stride, float *v_shN,
+                                  int32_t v_shN_stride, dnsplat_stream_t stream);
 
-/* The same factors [N,6] without the rest of the projection backward, from the forward's outputs (means, radii, viewmat
- * of dnsplat_camera, splats = dnsplat_proj_out.splats) and the gradient records of dnsplat_raster_bwd.  Lets the host start
- * the all-gather of the factors BEFORE dnsplat_project_bwd (then called with sh_grads_skip = 1), so that the exchange runs
- * while the geometry gradients are still being computed.  Agrees with the sh_factors output of dnsplat_project_bwd except
- * for a colour that sits exactly on the clamp (c + 0.5 == 0), which this kernel masks. */
-int dnsplat_sh_factors(int32_t N, const float *means, const int32_t *radii, const float *viewmat, const float *splats,
-                       const float *v_splats, float *factors, dnsplat_stream_t stream);
+/* One camera's slab (3 N + 4 floats, see above) from the forward's outputs (radii, viewmat of dnsplat_camera, splats =
+ * dnsplat_proj_out.splats) and the gradient records of dnsplat_raster_bwd — without the rest of the projection backward, so
+ * that the host can start the all-gather BEFORE dnsplat_project_bwd (called with sh_grads_skip = 1) and the exchange runs while
+ * the geometry gradients are still being computed.  A colour that sits exactly on the clamp (c + 0.5 == 0) is masked. */
+int dnsplat_sh_factors(int32_t N, const int32_t *radii, const float *viewmat, const float *splats, const float *v_splats,
+                       float *factors, dnsplat_stream_t stream);
 
 /* Densification statistics: the per-step accumulation nerfstudio's SplatfactoModel.after_train
  * performs on the renderer's outputs (called at dn_model.py:938-942, consumed by refinement_after dn_model.py:286-296):
@@ -377,11 +380,9 @@ typedef struct dnsplat_proj_grads {
     float *v_sh0; int32_t v_sh0_stride;   /* like scene.sh0 / shN; NULL to skip */
     float *v_shN; int32_t v_shN_stride;
     float *v_colors;             /* [N,n_colors] when sh_degree < 0; NULL to skip */
-    float *sh_factors;           /* optional [N,6]: when non-NULL the SH coefficient gradients are NOT written; instead the
-                                    two factors of their outer product are: unit view direction (3) and the clamp-masked
-                                    colour gradient (3); zeros for culled Gaussians.  See dnsplat_sh_grads_from_factors. */
-    int32_t sh_grads_skip;       /* non-zero: neither the SH coefficient gradients nor the factors are written — the caller
-                                    took the factors from dnsplat_sh_factors before this launch (sh_factors must be NULL) */
+    int32_t sh_grads_skip;       /* non-zero: the SH coefficient gradients are not written — the caller took the colour gradients
+                                    with dnsplat_sh_factors before this launch and rebuilds the rows from the gathered slabs
+                                    (dnsplat_sh_grads_from_factors) */
 } dnsplat_proj_grads;
 
 int dnsplat_project_bwd(const dnsplat_scene *scene, const dnsplat_camera *cam,

@@ -72,15 +72,18 @@ def _worker(rank, world, port, ret):
     assert all(torch.allclose(fake[k].grad, torch.full_like(fake[k], (1 + world) / 2)) for k in KEYS)
     assert dp.max_over_ranks(float(rank), dev) == world - 1
     assert dp.sum_over_ranks([1.0, float(rank)], dev) == [float(world), float(sum(range(world)))]
-    # SH factor exchange: all-gather of the (direction, colour gradient) pairs + rebuild == mean of the outer products.
+    # SH factor exchange: all-gather of the colour gradients (+ each rank's camera position) + rebuild == mean of the outer
+    # products basis(normalize(mean - camera)) (x) colour gradient.
     # The HIP rebuild kernel is swapped for a torch reference here (autograd through the oracle's dense SH evaluation).
     from oracle import dense_ref
 
-    def rebuild_ref(gathered, n, w, deg, K, v_coeffs, v_sh0, v_shN):
+    def rebuild_ref(gathered, means_, n, w, deg, K, v_coeffs, v_sh0, v_shN):
         tot = torch.zeros(n, K, 3)
         for v in range(w):
             co = torch.zeros(n, K, 3, requires_grad=True)
-            (dense_ref.sh_colors(deg, gathered[v, :, :3], co) * gathered[v, :, 3:]).sum().backward()
+            cols_v, pos_v = gathered[v, :3 * n].reshape(n, 3), gathered[v, 3 * n:3 * n + 3]
+            dirs_v = torch.nn.functional.normalize(means_ - pos_v, dim=-1)
+            (dense_ref.sh_colors(deg, dirs_v, co) * cols_v).sum().backward()
             tot += co.grad
         tot /= w
         v_sh0.copy_(tot[:, 0])
@@ -97,12 +100,15 @@ def _worker(rank, world, port, ret):
     for k in KEYS:
         fpar[k].grad = far.take(fpar[k])
         fpar[k].grad.fill_(float(rank))
-    mine = ex.begin(n_g, torch.device("cpu"), 3, 16, None, None, None)
-    dirs = torch.nn.functional.normalize(torch.randn(n_g, 3, generator=gen), dim=-1)
+    means_g = torch.randn(n_g, 3, generator=torch.Generator().manual_seed(99)) * 2          # replicated on every rank
+    campos = torch.randn(3, generator=gen) * 6                                              # this rank's camera
+    dirs = torch.nn.functional.normalize(means_g - campos, dim=-1)
     cols = torch.randn(n_g, 3, generator=gen)
-    mine.copy_(torch.cat([dirs, cols], 1))
+    slab = torch.cat([cols.reshape(-1), campos, torch.zeros(1)])
+    mine = ex.begin(n_g, torch.device("cpu"), 3, 16, means=means_g)
+    mine.copy_(slab)
     got_bytes = dp.allreduce_gradients(fpar, far, exchange=ex)
-    assert got_bytes == 11 * n_g * 4 + (world - 1) * n_g * 24
+    assert got_bytes == 11 * n_g * 4 + (world - 1) * (3 * n_g + 4) * 4
     assert torch.allclose(fpar["quats"].grad, torch.full((n_g, 4), (world - 1) / 2))      # geometry part: plain mean
     # every rank must hold the same rebuilt SH gradient = mean over ranks of basis (x) colour
     chk = fpar["features_rest"].grad.clone()
@@ -126,8 +132,8 @@ def _worker(rank, world, port, ret):
 
         @staticmethod
         def backward(ctx, g):
-            mine = ex.begin(n_g, torch.device("cpu"), 3, 16)
-            mine.copy_(torch.cat([dirs, cols], 1))
+            mine = ex.begin(n_g, torch.device("cpu"), 3, 16, means=means_g)
+            mine.copy_(slab)
             ex.launch()
             return g
 

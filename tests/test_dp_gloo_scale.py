@@ -3,7 +3,7 @@ configs name — for the flat gradient bucket, the SH factor exchange and the da
 
   * bucket / exchange offsets: every rank fills its gradient bucket with a rank- and element-dependent pattern; after
     ``dp.allreduce_gradients(..., exchange=...)`` the 44 B geometry prefix must hold the mean over ranks element by element
-    and the SH rows the mean of the ranks' outer products (all-gathered 24-byte factors, rebuilt per rank);
+    and the SH rows the mean of the ranks' outer products (all-gathered 12-byte colour gradients, rebuilt per rank);
   * refinement: ranks accumulate DIFFERENT per-camera densification statistics, combine them (``DensifyStats.allreduce``) and
     run ``densify.refinement_after``: all ranks must end with bit-identical Gaussian sets and Adam moments, equal to a single
     process that saw all cameras.  (The two HIP kernels are swapped for their torch restatements, as the 2-rank test does for
@@ -73,11 +73,12 @@ def _worker(rank, world, port, ret):
     assert (r, w) == (rank, world)
 
     # ---- bucket + factor exchange at this world size ------------------------------------------------------------------
-    def rebuild_ref(gathered, n, w_, deg, K, v_coeffs, v_sh0, v_shN):
+    def rebuild_ref(gathered, means_, n, w_, deg, K, v_coeffs, v_sh0, v_shN):
         tot = torch.zeros(n, K, 3)
         for v in range(w_):
             co = torch.zeros(n, K, 3, requires_grad=True)
-            (dense_ref.sh_colors(deg, gathered[v, :, :3], co) * gathered[v, :, 3:]).sum().backward()
+            cols_v, pos_v = gathered[v, :3 * n].reshape(n, 3), gathered[v, 3 * n:3 * n + 3]
+            (dense_ref.sh_colors(deg, torch.nn.functional.normalize(means_ - pos_v, dim=-1), co) * cols_v).sum().backward()
             tot += co.grad
         tot /= w_
         v_sh0.copy_(tot[:, 0])
@@ -94,11 +95,13 @@ def _worker(rank, world, port, ret):
         pattern[k] = torch.arange(fpar[k].numel(), dtype=torch.float32).reshape(fpar[k].shape) * 0.001 + 10 * i
         fpar[k].grad.copy_(pattern[k] + rank)                     # element- and rank-dependent
     gen = torch.Generator().manual_seed(7 + rank)
-    dirs = torch.nn.functional.normalize(torch.randn(N_G, 3, generator=gen), dim=-1)
+    means_g = torch.randn(N_G, 3, generator=torch.Generator().manual_seed(99)) * 2      # replicated on every rank
+    campos = torch.randn(3, generator=gen) * 6                                          # this rank's camera
+    dirs = torch.nn.functional.normalize(means_g - campos, dim=-1)
     cols = torch.randn(N_G, 3, generator=gen)
-    ex.begin(N_G, torch.device("cpu"), 3, 16).copy_(torch.cat([dirs, cols], 1))
+    ex.begin(N_G, torch.device("cpu"), 3, 16, means=means_g).copy_(torch.cat([cols.reshape(-1), campos, torch.zeros(1)]))
     got = dp.allreduce_gradients(fpar, arena, exchange=ex)
-    assert got == 11 * N_G * 4 + (world - 1) * N_G * 24, got
+    assert got == 11 * N_G * 4 + (world - 1) * (3 * N_G + 4) * 4, got
     mean_rank = (world - 1) / 2
     for k in dp.GEOMETRY_KEYS:                                     # the contiguous 44-byte prefix: element-wise mean
         assert torch.allclose(fpar[k].grad, pattern[k] + mean_rank, atol=1e-5), k

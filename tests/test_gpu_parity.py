@@ -788,8 +788,8 @@ def test_multi_camera_rasterization_equals_sequential_calls_and_oracle(dns, orc,
 
 @pytest.mark.parametrize("layout", ["split", "cat"])
 def test_sh_factor_exchange_rebuilds_the_multi_camera_gradient(dns, layout):
-    """Data parallel: all-gathering the 6 SH-gradient factors per Gaussian and rebuilding the sum equals averaging the
-    192-byte coefficient gradients of the cameras (dp.ShFactorExchange, dnsplat_sh_grads_from_factors) — checked here
+    """Data parallel: all-gathering the 3 colour gradients per Gaussian (+ each camera's position) and rebuilding the sum equals
+    averaging the 192-byte coefficient gradients of the cameras (dp.ShFactorExchange, dnsplat_sh_grads_from_factors) — checked here
     with three cameras rendered one after the other on one GPU; the geometry gradients are untouched by the mode."""
     import ctypes
 
@@ -843,18 +843,20 @@ def test_sh_factor_exchange_rebuilds_the_multi_camera_gradient(dns, layout):
             ref = dense[len(factors) - 1][0][k].grad
             assert_close(gp_f[k].grad, ref, "factor mode grad " + k, 1e-4)    # two runs differ by atomic order only
     fac = torch.stack(factors).contiguous()
+    assert fac.shape == (3, 3 * N + 4)                 # one slab per camera: [N,3] colour gradients | camera position | pad
+    means_dev = gp0["means"].detach().to(DEV).contiguous()
     if layout == "split":
         v0 = torch.empty(N, 3, device=DEV)
         vN = torch.empty(N, 15, 3, device=DEV)
-        _lib.check(_lib.lib().dnsplat_sh_grads_from_factors(N, 3, _ops._ptr(fac), 3, 16, 1.0 / 3, _ops._ptr(v0), 3, _ops._ptr(vN), 45,
-                                                            _ops._stream()), "dnsplat_sh_grads_from_factors")
+        _lib.check(_lib.lib().dnsplat_sh_grads_from_factors(N, 3, _ops._ptr(fac), _ops._ptr(means_dev), 3, 16, 1.0 / 3, _ops._ptr(v0), 3,
+                                                            _ops._ptr(vN), 45, _ops._stream()), "dnsplat_sh_grads_from_factors")
         ref0 = sum(d[0]["features_dc"].grad for d in dense) / 3
         refN = sum(d[0]["features_rest"].grad for d in dense) / 3
         assert_close(v0, ref0, "rebuilt features_dc gradient", 1e-5)
         assert_close(vN, refN, "rebuilt features_rest gradient", 1e-5)
     else:
         vc = torch.empty(N, 16, 3, device=DEV)
-        _lib.check(_lib.lib().dnsplat_sh_grads_from_factors(N, 3, _ops._ptr(fac), 3, 16, 1.0 / 3, _ops._ptr(vc), 48,
+        _lib.check(_lib.lib().dnsplat_sh_grads_from_factors(N, 3, _ops._ptr(fac), _ops._ptr(means_dev), 3, 16, 1.0 / 3, _ops._ptr(vc), 48,
                                                             _ops._ptr(vc.view(-1)[3:]), 48, _ops._stream()),
                    "dnsplat_sh_grads_from_factors")
         ref = sum(d[1].grad for d in dense) / 3
@@ -883,9 +885,11 @@ def test_sh_rebuild_kernel_equals_torch_rebuild_at_node_scale(dns, n_views, sh_d
 
     N = 10_007
     g = torch.Generator().manual_seed(40 + n_views)
-    dirs = torch.nn.functional.normalize(torch.randn(n_views, N, 3, generator=g), dim=-1)      # unit view directions, as dnsplat_sh_factors writes them
+    means = torch.randn(N, 3, generator=g) * 3
+    campos = torch.randn(n_views, 3, generator=g) * 8
+    dirs = torch.nn.functional.normalize(means[None] - campos[:, None], dim=-1)      # what every rank re-derives per camera
     cols = torch.randn(n_views, N, 3, generator=g)
-    fac = torch.cat([dirs, cols], -1).contiguous()
+    fac = torch.cat([cols.reshape(n_views, -1), campos, torch.zeros(n_views, 1)], -1).contiguous()      # slabs as dnsplat_sh_factors writes them
     tot = torch.zeros(N, 16, 3)
     for v in range(n_views):
         co = torch.zeros(N, 16, 3, requires_grad=True)
@@ -894,7 +898,7 @@ def test_sh_rebuild_kernel_equals_torch_rebuild_at_node_scale(dns, n_views, sh_d
     tot /= n_views
     v0 = torch.full((N, 3), float("nan"), device=DEV)
     vN = torch.full((N, 15, 3), float("nan"), device=DEV)
-    dp._rebuild_hip(fac.to(DEV), N, n_views, sh_degree, 16, None, v0, vN)
+    dp._rebuild_hip(fac.to(DEV), means.to(DEV), N, n_views, sh_degree, 16, None, v0, vN)
     torch.cuda.synchronize()
     assert_close(v0, tot[:, 0], "rebuilt band 0", 1e-5)
     assert_close(vN, tot[:, 1:], "rebuilt bands 1..3 (inactive bands must be zero, not untouched)", 1e-5)
