@@ -162,10 +162,15 @@ def main():
     ap.add_argument("--losses", nargs="?", const="torch", default=None, choices=["torch", "fused"],
                     help="time dn-splatter's loss stack (L1+SSIM, EdgeAwareLogL1 depth, normal L1+TV, scale) instead of feeding "
                          "random cotangents (BASELINE config C5): 'torch' = as the reference does, 'fused' = dnsplat_dn_loss")
+    ap.add_argument("--lean", action="store_true",
+                    help="profiling runs (rocprofv3 --kernel-trace / --pmc serialise every launch): eager launches, no pre-roll, no "
+                         "counting step, no strict-index-parity section")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, count them with one all-reduce and print {n_gpus, ranks_seen} without rendering (works "
                          "without a GPU over gloo: the CPU test of the --gpus N self-launch)")
     args = ap.parse_args()
+    if args.lean:
+        args.graph = "off"
 
     # `python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`
     # (one process per GPU over RCCL), so that the line printed is never a single-GPU run labelled as N
@@ -260,7 +265,7 @@ def main():
     probe_ms = {name: stage_ms(pstats, name, PROBE_STEPS) for name in STAGE_NAMES}
     # one step through the COUNTING instantiation of the compositing kernels (outside the timed region)
     counts = None
-    if not args.two_call and not args.torch_postops:
+    if not args.two_call and not args.torch_postops and not args.lean:
         from dn_splatter_amd import _ops
         _ops.PAIR_COUNTERS = torch.zeros(8, dtype=torch.int64, device=dev)
         step()
@@ -326,7 +331,7 @@ def main():
         stamps.reset()
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         stamps.stamp(); c0.record()
-    for _ in range(PREROLL_STEPS):
+    for _ in range(0 if args.lean else PREROLL_STEPS):
         step()
     if gstep is not None:
         c1.record(); stamps.stamp()
@@ -457,7 +462,7 @@ def main():
     # (DNSPLAT_TIGHT_TILES=0) flatten_ids / isect_offsets are the reference's bit for bit — that configuration is timed here.
     strict = None
     from dn_splatter_amd import _ops as _ops_mod2
-    if world == 1 and exchange is None and not args.two_call and not args.torch_postops and _ops_mod2.TIGHT_TILES:
+    if world == 1 and exchange is None and not args.two_call and not args.torch_postops and _ops_mod2.TIGHT_TILES and not args.lean:
         _ops_mod2.TIGHT_TILES = False
         try:
             renderer.forget()

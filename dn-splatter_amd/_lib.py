@@ -191,7 +191,7 @@ def lib() -> ctypes.CDLL:
                                                     c_void_p, c_int32, c_void_p]
         L.dnsplat_dn_loss.argtypes = [ctypes.POINTER(DnLossArgs), c_void_p]
         L.dnsplat_camera_prepare.argtypes = [c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
-                                             c_void_p, c_void_p]
+                                             c_void_p, c_int32, c_void_p]
         L.dnsplat_sh_factors.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         for name in EXPORTS:
             if name not in ("dnsplat_strerror", "dnsplat_bin_workspace_bytes", "dnsplat_bin_status_offset"):

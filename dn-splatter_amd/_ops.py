@@ -858,7 +858,13 @@ class _RasterDnFn(torch.autograd.Function):
         rgb = torch.empty(C, height, width, 3, **f32)
         depth_raw = torch.empty(C, height, width, **f32)
         normal = torch.empty(C, height, width, 3, **f32)
-        depth_max = torch.empty(C, **f32)               # zeroed in composite() (again if the capacity guess forces a re-run)
+        # per-camera maximum of the expected depth: zeroed by the frame's camera_prepare launch when it came with the saturation
+        # flag, otherwise (and again if the capacity guess forces a re-run) by a fill in composite()
+        sat = holder.get("saturation_flag") if holder is not None else None
+        depth_max = DEPTH_MAX_OF.pop(sat.data_ptr(), None) if sat is not None else None
+        fresh = {"depth_max": depth_max is not None and depth_max.numel() == C}
+        if not fresh["depth_max"]:
+            depth_max = torch.empty(C, **f32)
         depth_out = torch.empty(C, height, width, 1, **f32)
         surface_normal = torch.empty(C, height, width, 3, **f32)
         bg_rgb = _f32c(bg_rgb, "background")
@@ -876,7 +882,9 @@ class _RasterDnFn(torch.autograd.Function):
                 if (FORWARD_ZERO_FILL and ctx.needs_input_grad[1] and counters is None) else None}
 
         def composite(b: Binning):
-            depth_max.zero_()
+            if not fresh["depth_max"]:
+                depth_max.zero_()
+            fresh["depth_max"] = False
             ready = holder.get("colours_ready") if holder is not None else None
             if ready is not None:          # the projection's colour phase runs on a side stream (ProjCfg.split_colours)
                 torch.cuda.current_stream(dev).wait_event(ready)
@@ -975,26 +983,36 @@ def rasterize_dn(means2d, splats, depths, radii, tiles, *, background_rgb, width
                              holder)
 
 
-def camera_prepare(c2w: Tensor, fx: float, fy: float, cx: float, cy: float, with_normal_frame: bool = True, with_flag: bool = False):
+def camera_prepare(c2w: Tensor, fx: float, fy: float, cx: float, cy: float, with_normal_frame: bool = True, with_flag: bool = False,
+                   n_depth_max: int = 0):
     """One-launch replacement of get_viewmat + intrinsics + normal frame (dn_model.py:475-479, 550-560).
     ``c2w`` [3,4] (or [1,3,4]) on the GPU -> viewmat[4,4], K[3,3], normal_frame[12] | None
-    (+ with_flag: a zeroed int32 [1] device word, the frame's opacity-saturation flag for project(..., saturation_flag=))."""
+    (+ with_flag: a zeroed int32 [1] device word, the frame's opacity-saturation flag for project(..., saturation_flag=);
+    n_depth_max > 0: the flag is followed by that many zeroed floats, the per-camera depth maxima of the fused epilogue —
+    ``flag.depth_max`` — so that the frame needs no fill launch for either)."""
     c2w = _f32c(c2w.reshape(-1)[:12], "camera_to_worlds")
     dev = c2w.device
-    out = torch.empty(16 + 9 + 12 + 1, dtype=torch.float32, device=dev)
+    out = torch.empty(16 + 9 + 12 + 1 + n_depth_max, dtype=torch.float32, device=dev)
     viewmat, K, nf = out[:16], out[16:25], out[25:37]
     flag = out[37:38].view(torch.int32) if with_flag else None
     _lib.run("dnsplat_camera_prepare", _lib.lib().dnsplat_camera_prepare, _ptr(c2w), fx, fy, cx, cy, _ptr(viewmat), _ptr(K),
-             _ptr(nf) if with_normal_frame else None, _ptr(flag), _stream())
+             _ptr(nf) if with_normal_frame else None, _ptr(flag), 1 + n_depth_max, _stream())
+    if with_flag and n_depth_max:
+        DEPTH_MAX_OF[flag.data_ptr()] = out[38:38 + n_depth_max]
     res = (viewmat.view(4, 4), K.view(3, 3), (nf if with_normal_frame else None))
     return res + (flag,) if with_flag else res
+
+
+# zeroed depth_max words that came with a saturation flag (keyed by the flag's address; taken once by _RasterDnFn.forward)
+DEPTH_MAX_OF: Dict[int, Tensor] = {}
 
 
 def camera_prepare_batch(cameras, with_normal_frame: bool = True, with_flag: bool = False):
     """camera_prepare for a list of camera records (``camera_to_worlds`` [1,3,4], fx, fy, cx, cy) ->
     viewmats[C,4,4], Ks[C,3,3], normal_frames[C,12] | None (+ with_flag: ONE zeroed flag word for the whole batch)."""
     parts = [camera_prepare(c.camera_to_worlds, float(c.fx), float(c.fy), float(c.cx), float(c.cy), with_normal_frame,
-                            with_flag=(with_flag and i == 0)) for i, c in enumerate(cameras)]
+                            with_flag=(with_flag and i == 0), n_depth_max=(len(cameras) if (with_flag and i == 0) else 0))
+             for i, c in enumerate(cameras)]
     vm = torch.stack([p[0] for p in parts])
     K = torch.stack([p[1] for p in parts])
     nf = torch.stack([p[2] for p in parts]) if with_normal_frame else None

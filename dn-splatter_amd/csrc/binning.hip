@@ -39,7 +39,15 @@ constexpr int RS_ITEMS_I = DNS_RS_ITEMS_I;       // keys per lane in the I-sized
 #endif
 constexpr int RS_ITEMS_N = DNS_RS_ITEMS_N;                    // ... in the N-sized depth passes: 1 M keys are only 245 chunks of 4096, less than
                                                  // one workgroup per CU and a 16-round ranking chain each; 2048-key chunks fill the chip (measured best of 2/4/8/16)
-constexpr int RS_WAVES = RS_THREADS / DNS_WAVE;
+// the I-sized tile passes: the same 4096-key chunk as RS_THREADS x RS_ITEMS_I, cut into TI_THREADS x TI_ITEMS.  With 512 threads
+// the ranking chain of a wave (one LDS counter round trip per 64 keys) is 8 rounds long instead of 16 and a CU holds 24 instead
+// of 16 waves of this latency-bound kernel
+#ifndef DNS_TI_THREADS
+#define DNS_TI_THREADS 512
+#endif
+constexpr int TI_THREADS = DNS_TI_THREADS;
+constexpr int TI_ITEMS = RS_THREADS * RS_ITEMS_I / TI_THREADS;
+static_assert(TI_THREADS * TI_ITEMS == RS_THREADS * RS_ITEMS_I && TI_THREADS % DNS_WAVE == 0 && TI_THREADS >= 256, "tile-pass chunk");
 constexpr int RS_DIGITS = 256;
 
 constexpr int SC_THREADS = 256;
@@ -60,22 +68,28 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
     return v;
 }
 
-// inclusive scan over a 256-thread block; returns inclusive value, total in `total`
-__device__ __forceinline__ uint32_t block_incl_scan_256(uint32_t v, uint32_t *lds_wave /*[4]*/, uint32_t &total)
+// inclusive scan over a workgroup of NW waves; returns inclusive value, total in `total`
+template <int NW = 4>
+__device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t *lds_wave /*[NW]*/, uint32_t &total)
 {
     const int w = threadIdx.x / DNS_WAVE;
     uint32_t inc = wave_incl_scan(v);
     if (lane_id() == DNS_WAVE - 1) lds_wave[w] = inc;
     __syncthreads();
-    uint32_t base = 0;
+    uint32_t base = 0, tot = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NW; ++i) {
         uint32_t s = lds_wave[i];
         if (i < w) base += s;
+        tot += s;
     }
-    total = lds_wave[0] + lds_wave[1] + lds_wave[2] + lds_wave[3];
+    total = tot;
     __syncthreads();
     return inc + base;
+}
+__device__ __forceinline__ uint32_t block_incl_scan_256(uint32_t v, uint32_t *lds_wave /*[4]*/, uint32_t &total)
+{
+    return block_incl_scan<4>(v, lds_wave, total);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -110,15 +124,15 @@ constexpr int gen_pad(int i) { return i + (i >> 5); }      // one pad word per 3
 
 // owner[gen_pad(i)], i < CHUNK := 1 + (depth rank - j0) of the Gaussian that emits pair q0 + i.  Every Gaussian marks the slot of
 // its first pair inside the chunk, a prefix maximum spreads the mark over its pairs.  Returns j0.
-template <int ITEMS>
-__device__ __forceinline__ uint32_t gen_owners(uint32_t *owner, uint32_t *lds_wave /*[4]*/, const GenArgs &g, uint32_t chunk,
+template <int ITEMS, int TH>
+__device__ __forceinline__ uint32_t gen_owners(uint32_t *owner, uint32_t *lds_wave /*[TH / 64]*/, const GenArgs &g, uint32_t chunk,
                                                uint32_t q0, uint32_t n_valid)
 {
-    constexpr int CHUNK = RS_THREADS * ITEMS;
-    for (int i = threadIdx.x; i < gen_pad(CHUNK); i += RS_THREADS) owner[i] = 0u;
+    constexpr int CHUNK = TH * ITEMS;
+    for (int i = threadIdx.x; i < gen_pad(CHUNK); i += TH) owner[i] = 0u;
     const uint32_t j0 = g.chunk_first[chunk];
     __syncthreads();
-    for (uint32_t jb = j0;; jb += RS_THREADS) {
+    for (uint32_t jb = j0;; jb += TH) {
         const uint32_t jj = jb + threadIdx.x;
         bool inside = false;       // this Gaussian starts before the end of the chunk (cum is non-decreasing: so do all before it)
         if (jj < (uint32_t)g.N) {
@@ -127,7 +141,7 @@ __device__ __forceinline__ uint32_t gen_owners(uint32_t *owner, uint32_t *lds_wa
             if (inside && e > s && e > q0) owner[gen_pad((int)(max(s, q0) - q0))] = jj - j0 + 1u;
         }
         // another round only if the last Gaussian of this one still started inside the chunk
-        if (!__syncthreads_or(inside && threadIdx.x == RS_THREADS - 1)) break;
+        if (!__syncthreads_or(inside && threadIdx.x == TH - 1)) break;
     }
     // prefix maximum: thread t owns slots [t * ITEMS, (t + 1) * ITEMS)
     uint32_t loc[ITEMS];
@@ -149,7 +163,7 @@ __device__ __forceinline__ uint32_t gen_owners(uint32_t *owner, uint32_t *lds_wa
     uint32_t before = __shfl_up(inc, 1, DNS_WAVE);
     if (lane_id() == 0) before = 0u;
 #pragma unroll
-    for (int i = 0; i < RS_WAVES; ++i)
+    for (int i = 0; i < TH / DNS_WAVE; ++i)
         if (i < w) before = max(before, lds_wave[i]);
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) owner[gen_pad(threadIdx.x * ITEMS + i)] = max(loc[i], before);
@@ -175,8 +189,9 @@ __device__ __forceinline__ void gen_pair(const uint32_t *owner, const GenArgs &g
 
 // FIRST = first pass of the depth sort (keys synthesised from radii / depths, n given by value: n_ptr may be NULL)
 // GEN = first pass of the tile sort: the keys are the tile ids of the pairs the workgroup re-creates (see GenArgs)
-template <typename K, int ITEMS, bool FIRST = false, bool GEN = false>
-__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const K *__restrict__ keys,
+// TH = threads per workgroup (chunk = TH x ITEMS keys): 256 x 8 for the N-sized depth passes, 512 x 8 for the tile passes
+template <typename K, int ITEMS, bool FIRST = false, bool GEN = false, int TH = RS_THREADS>
+__global__ __launch_bounds__(TH) void radix_hist_kernel(const K *__restrict__ keys,
                                                                 const uint32_t *__restrict__ n_ptr, uint32_t n_cap,
                                                                 int shift, uint32_t mask, uint32_t *__restrict__ table,
                                                                 int nb, const int32_t *__restrict__ radii = nullptr,
@@ -186,25 +201,25 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const K *__restr
                                                                 uint32_t *__restrict__ status = nullptr)
 {
     __shared__ uint32_t hist[RS_DIGITS];
-    __shared__ uint32_t owner[GEN ? gen_pad(RS_THREADS * ITEMS) : 1];
-    __shared__ uint32_t lds_wave[RS_WAVES];
+    __shared__ uint32_t owner[GEN ? gen_pad(TH * ITEMS) : 1];
+    __shared__ uint32_t lds_wave[TH / DNS_WAVE];
     const uint32_t n = n_ptr ? min(*n_ptr, n_cap) : n_cap;
     // first pass of the tile sort: also presets the tile offsets to n (the last scatter pass lowers the non-empty tiles'
     // entries with atomicMin, tile_offsets_fill gives the empty ones the offset of the next non-empty tile) and the tile ends to 0
     if (tile_first)
-        for (int i = blockIdx.x * RS_THREADS + threadIdx.x; i <= n_tiles; i += gridDim.x * RS_THREADS) tile_first[i] = (int32_t)n;
+        for (int i = blockIdx.x * TH + threadIdx.x; i <= n_tiles; i += gridDim.x * TH) tile_first[i] = (int32_t)n;
     if (tile_end)
-        for (int i = blockIdx.x * RS_THREADS + threadIdx.x; i < n_tiles; i += gridDim.x * RS_THREADS) tile_end[i] = 0;
+        for (int i = blockIdx.x * TH + threadIdx.x; i < n_tiles; i += gridDim.x * TH) tile_end[i] = 0;
     if (status && blockIdx.x == 0 && threadIdx.x == 0) *status = 0u;
-    hist[threadIdx.x] = 0;
+    if (threadIdx.x < RS_DIGITS) hist[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * (RS_THREADS * ITEMS);
+    const uint32_t base = blockIdx.x * (TH * ITEMS);
     if (base < n) {
         uint32_t j0 = 0;
-        if (GEN) j0 = gen_owners<ITEMS>(owner, lds_wave, gen, blockIdx.x, base, min((uint32_t)(RS_THREADS * ITEMS), n - base));
+        if (GEN) j0 = gen_owners<ITEMS, TH>(owner, lds_wave, gen, blockIdx.x, base, min((uint32_t)(TH * ITEMS), n - base));
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
-            uint32_t idx = base + i * RS_THREADS + threadIdx.x;
+            uint32_t idx = base + i * TH + threadIdx.x;
             if (idx < n) {
                 uint32_t k;
                 if (GEN) { uint32_t v; gen_pair(owner, gen, j0, base, idx - base, k, v); }
@@ -257,8 +272,8 @@ __global__ __launch_bounds__(SC_THREADS) void radix_scan_kernel(uint32_t *__rest
 // GEN: the first pass of the tile sort — keys / values are the pairs the workgroup re-creates (GenArgs), nothing is read.
 // tile_end (LAST, optional): one past the last entry of every non-empty tile, so that a consumer that takes both arrays needs
 // no suffix-minimum fill of the offsets of the empty tiles.
-template <typename K, bool LAST, int DBITS, int ITEMS, bool FIRST = false, bool GEN = false>
-__global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
+template <typename K, bool LAST, int DBITS, int ITEMS, bool FIRST = false, bool GEN = false, int TH = RS_THREADS>
+__global__ __launch_bounds__(TH) void radix_scatter_kernel(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ n_ptr, uint32_t n_cap, int shift,
     const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nb, int32_t *__restrict__ tile_first,
@@ -269,15 +284,16 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     // store to consecutive addresses of one digit's run, so the stores coalesce.  A direct scatter from the
     // ranking registers sends the 64 lanes of one store instruction to up to 64 different cache lines and
     // ran at a quarter of this version's rate on the 21 M-entry tile passes.
-    __shared__ uint32_t wave_cnt[RS_WAVES][RS_DIGITS];
-    __shared__ uint32_t wave_loc[RS_WAVES][RS_DIGITS];   // chunk-local position of a (wave, digit) run
+    constexpr int NW = TH / DNS_WAVE;
+    __shared__ uint32_t wave_cnt[NW][RS_DIGITS];
+    __shared__ uint32_t wave_loc[NW][RS_DIGITS];         // chunk-local position of a (wave, digit) run
     __shared__ uint32_t dstart[RS_DIGITS];               // chunk-local start of a digit's run
     __shared__ uint32_t gbase[RS_DIGITS];                // global start of this chunk's run of a digit
-    constexpr int CHUNK = RS_THREADS * ITEMS;
+    constexpr int CHUNK = TH * ITEMS;
     __shared__ K keys_s[CHUNK];
     // GEN: the owner table (dead once the pairs sit in registers) shares the memory of the value staging area
     __shared__ uint32_t vals_s[GEN ? gen_pad(CHUNK) : CHUNK];
-    __shared__ uint32_t lds_wave[4];
+    __shared__ uint32_t lds_wave[NW];
     constexpr uint32_t DMASK = (1u << DBITS) - 1u;
     const uint32_t n = n_ptr ? min(*n_ptr, n_cap) : n_cap;
     const uint32_t chunk = blockIdx.x;
@@ -293,10 +309,12 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint32_t pre_tot = is_digit ? totals[threadIdx.x] : 0u;
     const uint32_t pre_tab = is_digit ? table[(size_t)threadIdx.x * nb + blockIdx.x] : 0u;
 
+    if (threadIdx.x < RS_DIGITS) {
 #pragma unroll
-    for (int i = 0; i < RS_WAVES; ++i) wave_cnt[i][threadIdx.x] = 0;
+        for (int i = 0; i < NW; ++i) wave_cnt[i][threadIdx.x] = 0;
+    }
     uint32_t j0 = 0;
-    if (GEN) j0 = gen_owners<ITEMS>(vals_s, lds_wave, gen, chunk, base, n_valid);
+    if (GEN) j0 = gen_owners<ITEMS, TH>(vals_s, lds_wave, gen, chunk, base, n_valid);
     else __syncthreads();
 
     uint32_t key[ITEMS], val[ITEMS], rnk[ITEMS];
@@ -337,22 +355,31 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     }
     __syncthreads();
     {
-        // digit d = threadIdx.x
-        const uint32_t c0 = wave_cnt[0][threadIdx.x], c1 = wave_cnt[1][threadIdx.x], c2 = wave_cnt[2][threadIdx.x],
-                       c3 = wave_cnt[3][threadIdx.x];
-        const uint32_t cnt = c0 + c1 + c2 + c3;
+        // digit d = threadIdx.x (threads beyond the 256 digits only take part in the scans)
+        const bool has_digit = threadIdx.x < RS_DIGITS;
+        uint32_t cw[NW];
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            cw[i] = has_digit ? wave_cnt[i][threadIdx.x] : 0u;
+            cnt += cw[i];
+        }
         uint32_t t2;
-        const uint32_t linc = block_incl_scan_256(cnt, lds_wave, t2);     // chunk-local exclusive start
+        const uint32_t linc = block_incl_scan<NW>(cnt, lds_wave, t2);     // chunk-local exclusive start
         const uint32_t ls = linc - cnt;
-        dstart[threadIdx.x] = ls;
-        wave_loc[0][threadIdx.x] = ls;
-        wave_loc[1][threadIdx.x] = ls + c0;
-        wave_loc[2][threadIdx.x] = ls + c0 + c1;
-        wave_loc[3][threadIdx.x] = ls + c0 + c1 + c2;
+        if (has_digit) {
+            dstart[threadIdx.x] = ls;
+            uint32_t run = ls;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                wave_loc[i][threadIdx.x] = run;
+                run += cw[i];
+            }
+        }
         // global base = (#keys with smaller digit) + (#same digit in earlier chunks)
         const uint32_t tot = pre_tot;
-        const uint32_t ginc = block_incl_scan_256(tot, lds_wave, t2);
-        gbase[threadIdx.x] = is_digit ? (ginc - tot) + pre_tab : 0u;
+        const uint32_t ginc = block_incl_scan<NW>(tot, lds_wave, t2);
+        if (has_digit) gbase[threadIdx.x] = is_digit ? (ginc - tot) + pre_tab : 0u;
     }
     __syncthreads();
 #pragma unroll
@@ -368,7 +395,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
-        const uint32_t i = r * RS_THREADS + threadIdx.x;
+        const uint32_t i = r * TH + threadIdx.x;
         if (i < n_valid) {
             const uint32_t k = keys_s[i];
             const uint32_t d = (k >> shift) & DMASK;
@@ -587,7 +614,7 @@ int tile_bits(int n_tiles);
 
 // one LSD pass over `dbits` bits at `shift`; tile_first != nullptr marks the last pass of the tile sort;
 // gen != nullptr: the first pass of the tile sort, whose input is generated (no ka / va)
-template <typename K, int ITEMS>
+template <typename K, int ITEMS, int TH = RS_THREADS>
 void radix_pass(hipStream_t stream, const K *ka, const uint32_t *va, K *kb, uint32_t *vb, const uint32_t *n_ptr,
                 uint32_t n_cap, int shift, int dbits, uint32_t *table, uint32_t *totals, int nb, int32_t *tile_first = nullptr,
                 const int32_t *radii = nullptr, const float *depths = nullptr, int32_t *init_offsets = nullptr, int n_tiles = 0,
@@ -595,22 +622,22 @@ void radix_pass(hipStream_t stream, const K *ka, const uint32_t *va, K *kb, uint
 {
     const uint32_t mask = (1u << dbits) - 1u;
     if (radii) {   // first pass of the depth sort: 8-bit digit, keys synthesised from (radii, depths)
-        hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS, true>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb, radii, depths);
+        hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS, true, false, TH>), dim3(nb), dim3(TH), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb, radii, depths);
         hipLaunchKernelGGL(radix_scan_kernel, dim3(1 << dbits), dim3(SC_THREADS), 0, stream, table, nb, totals);
-        hipLaunchKernelGGL((radix_scatter_kernel<K, false, 8, ITEMS, true>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb,
+        hipLaunchKernelGGL((radix_scatter_kernel<K, false, 8, ITEMS, true, false, TH>), dim3(nb), dim3(TH), 0, stream, ka, va, kb, vb,
                            n_ptr, n_cap, shift, table, totals, nb, tile_first, radii, depths);
         return;
     }
     const GenArgs g = gen ? *gen : GenArgs{};
     if (gen)
-        hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS, false, true>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n_ptr, n_cap, shift, mask,
+        hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS, false, true, TH>), dim3(nb), dim3(TH), 0, stream, ka, n_ptr, n_cap, shift, mask,
                            table, nb, (const int32_t *)nullptr, (const float *)nullptr, init_offsets, n_tiles, init_offsets ? tile_end : nullptr, g, status);
     else
-        hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb,
+        hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS, false, false, TH>), dim3(nb), dim3(TH), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb,
                            (const int32_t *)nullptr, (const float *)nullptr, init_offsets, n_tiles, init_offsets ? tile_end : nullptr, g, status);
     hipLaunchKernelGGL(radix_scan_kernel, dim3(1 << dbits), dim3(SC_THREADS), 0, stream, table, nb, totals);
 #define DNS_SCATTER3(B, L, G)                                                                                               \
-    hipLaunchKernelGGL((radix_scatter_kernel<K, L, B, ITEMS, false, G>), dim3(nb), dim3(RS_THREADS), 0, stream, ka, va, kb, vb,    \
+    hipLaunchKernelGGL((radix_scatter_kernel<K, L, B, ITEMS, false, G, TH>), dim3(nb), dim3(TH), 0, stream, ka, va, kb, vb,    \
                        n_ptr, n_cap, shift, table, totals, nb, tile_first, (const int32_t *)nullptr, (const float *)nullptr, \
                        tile_end, g)
 #define DNS_SCATTER(B)                                                                                                      \
@@ -654,7 +681,7 @@ void emit_and_sort(hipStream_t stream, const dnsplat_bin_args *a, const BinWs &w
         const bool last = pass == passes - 1;
         K *kout = (pass & 1) ? kc : kb;
         uint32_t *vout = last ? (uint32_t *)a->flatten_ids : ((pass & 1) ? vc : vb);
-        radix_pass<K, RS_ITEMS_I>(stream, ka, va, kout, vout, w.total, cap, shift, dbits, w.tab_i, w.totals, w.nb_i,
+        radix_pass<K, TI_ITEMS, TI_THREADS>(stream, ka, va, kout, vout, w.total, cap, shift, dbits, w.tab_i, w.totals, w.nb_i,
                                   last ? a->tile_offsets : nullptr, nullptr, nullptr, pass == 0 ? a->tile_offsets : nullptr, n_tiles,
                                   a->tile_ends, pass == 0 ? &g : nullptr, pass == 0 ? w.status : nullptr);
         shift += dbits;

@@ -59,10 +59,11 @@ __global__ __launch_bounds__(256) void dn_depth_normals_kernel(int W, int H, flo
 
 __global__ void camera_prepare_kernel(const float *__restrict__ c2w, float fx, float fy, float cx, float cy,
                                       float *__restrict__ viewmat, float *__restrict__ K, float *__restrict__ nf,
-                                      uint32_t *__restrict__ zero_word)
+                                      uint32_t *__restrict__ zero_word, int n_zero_words)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (zero_word) *zero_word = 0u;
+    if (zero_word)
+        for (int i = 0; i < n_zero_words; ++i) zero_word[i] = 0u;
     // c2w [3,4] nerfstudio/OpenGL.  get_viewmat: flip the y and z camera axes, then invert analytically.
     float R[9], t[3];
     for (int r = 0; r < 3; ++r) {
@@ -233,11 +234,11 @@ extern "C" int dnsplat_dn_depth_normals(int32_t width, int32_t height, float fx,
 }
 
 extern "C" int dnsplat_camera_prepare(const float *c2w, float fx, float fy, float cx, float cy, float *viewmat, float *K,
-                                      float *normal_frame, uint32_t *zero_word, dnsplat_stream_t stream)
+                                      float *normal_frame, uint32_t *zero_word, int32_t n_zero_words, dnsplat_stream_t stream)
 {
     if (!c2w || !viewmat || !K) return DNSPLAT_ERR_INVALID_ARG;
     hipLaunchKernelGGL(camera_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c2w, fx, fy, cx, cy, viewmat, K,
-                       normal_frame, zero_word);
+                       normal_frame, zero_word, zero_word ? (n_zero_words > 0 ? n_zero_words : 1) : 0);
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;
 }

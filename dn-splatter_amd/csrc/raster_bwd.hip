@@ -8,33 +8,35 @@
 // per (warp, splat).  On a 64-wide wave that reduction (15 values x 6 DPP steps) costs more than
 // the gradient math itself.  This kernel turns the problem by 90 degrees — a wave64 SYSTOLIC pass:
 //
-//   * one wave owns one 16x16 tile; lane l owns TWO SPLATS of the current bucket of 128 (lane 0 =
-//     back-most), carried as packed fp32 pairs, and keeps their 2 x 16 partial gradients in VGPRs;
-//   * the 256 pixels stream through the lanes, back to front: one pixel per lane per step, lane l
-//     one step behind lane l-1.  What travels with a pixel is only its running state (T, S_a, S_b) —
-//     three v_mov_dpp wave_shr:1 per step — where S = sum_k buffer_k * v_k collapses the reference's
-//     per-channel `buffer` into one scalar per gradient group (v_alpha = T*(c.v) - S/(1-alpha));
-//   * per-pixel constants (upstream gradient, last contributing index) sit in a 12 KiB LDS table,
-//     read with conflict-free ds_read_b128 (48-byte stride over consecutive lanes), issued before and
-//     awaited after the row-independent arithmetic of the step;
-//   * state leaving lane 63 is parked back in the pixel's LDS row and picked up by lane 0 in the
-//     next (nearer) bucket — the arithmetic order per pixel is exactly the reference's
-//     back-to-front replay (T *= 1/(1-alpha); buffer += c*alpha*T);
-//   * the stream is CONTINUOUS over the buckets of a tile: 15 idle slots separate two buckets, which
-//     lets 16 neighbouring lanes change their splats at the same wave-uniform step (four staggered
-//     group switches per bucket) instead of draining and refilling the whole array — 271 steps per
-//     bucket instead of 256 + 63;
-//   * a splat's 16 partials are summed over all 256 pixels in registers: NO cross-lane reduction,
-//     and ONE atomic row per (tile, splat).  The flush is transposed through LDS so that each
-//     global_atomic_add_f32 instruction covers whole 64-byte gradient records (16 lanes per record).
+//   * the unit of work is a 16 x 8 HALF tile = one wave = one workgroup (DNS_BWD_ROWS; whole tiles made the units twice as
+//     long and the launch's drain with them); lane l owns TWO SPLATS of the current bucket of 128 (lane 0 = back-most),
+//     carried as packed fp32 pairs, and keeps their 2 x 16 partial gradients in VGPRs;
+//   * the 128 pixels stream through the lanes, back to front: one pixel per lane per step, lane l one step behind lane
+//     l-1.  What travels with a pixel is only its running state (T, S_a, S_b) — three v_mov_dpp row_shr:1 per step — where
+//     S = sum_k buffer_k * v_k collapses the reference's per-channel `buffer` into one scalar per gradient group
+//     (v_alpha = T*(c.v) - S/(1-alpha));
+//   * the 64 lanes are four DPP ROWS of 16 linked through LDS: the last lane of a row parks the state in the pixel's LDS
+//     row, the first lane of the next row picks it up one step later — free, every lane reads its pixel's row anyway;
+//   * per-pixel constants (upstream gradient, last contributing index) sit in a 6 KiB LDS table (128 rows of 48 bytes), read
+//     with conflict-free ds_read_b128 (48-byte stride over consecutive lanes), issued before and awaited after the
+//     row-independent arithmetic of the step;
+//   * state leaving lane 63 is parked back in the pixel's LDS row and picked up by lane 0 in the next (nearer) bucket — the
+//     arithmetic order per pixel is exactly the reference's back-to-front replay (T *= 1/(1-alpha); buffer += c*alpha*T);
+//   * the stream is CONTINUOUS over the buckets of a unit: 15 idle slots separate two buckets, which lets the 16 lanes of
+//     a row change their splats at the same wave-uniform step (four staggered group switches per bucket) instead of
+//     draining and refilling the whole array — 143 steps per bucket instead of 128 + 63;
+//   * the last, partly filled bucket of a unit is FOLDED (DNS_BWD_FOLD): with <= 64 (<= 32) splats the four rows are re-cut
+//     into two (four) arrays that each hold all of its splats and stream a share of the pixels: 111 (71) steps;
+//   * a splat's 16 partials are summed over all 128 pixels in registers: NO cross-lane reduction, and ONE atomic row per
+//     (half tile, splat).  The flush is transposed through LDS so that each global_atomic_add_f32 instruction covers whole
+//     64-byte gradient records (16 lanes per record).
 //
-// Bucket compaction.  A tile list holds every splat whose 3-sigma bounding box touches the tile; on
-// the benchmark scenes about half of those cannot reach alpha >= 1/255 at any pixel centre of the
-// tile.  Before a bucket is formed the wave tests 64 list entries at once against the tile rectangle
-// (dns_cull_rect: exact minimum of the quadratic over the rectangle, one lane per entry) and
-// ballot-compacts the survivors into an LDS queue, so lanes only ever hold splats that can
-// contribute.  Culled entries are exactly those the per-pixel test would skip for all 256 pixels:
-// results are unchanged, the systolic array just runs ~2x fewer steps.
+// Bucket compaction.  A tile list holds every splat whose tile box touches the tile; on the benchmark scenes a good part of
+// those cannot reach alpha >= 1/255 at any pixel centre of the half tile.  Only contributing splats enter a bucket: the
+// benchmark instantiation (MASKS) takes the forward's rectangle-test ballots (dnsplat_raster_args.keep_masks, one 64-bit word
+// per 64 list entries), the others test 64 list entries at once against the half tile's rectangle themselves (dns_cull_rect:
+// exact minimum of the quadratic over the rectangle, one lane per entry) and ballot-compact the survivors into an LDS queue.
+// Culled entries are exactly those the per-pixel test would skip for all 128 pixels: results are unchanged.
 //
 // Channel groups: channels >= SPLIT (the normal channels of the fused pass) are rendered by the
 // reference with xys.detach() (dn_model.py:562), so their share of d/d(alpha) must not reach

@@ -107,7 +107,7 @@ def render_dn_outputs(
     depth->normal stencil; backward = compositing backward (taking the image cotangents directly) + fused
     projection backward.  Returns ``(outputs, info)`` with the output keys of dn_model.py:605-612 minus
     ``background``."""
-    viewmat, K, nf, flag = _ops.camera_prepare(camera_to_world, fx, fy, cx, cy, with_flag=True)
+    viewmat, K, nf, flag = _ops.camera_prepare(camera_to_world, fx, fy, cx, cy, with_flag=True, n_depth_max=1)
     outs, info = _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest, viewmat[None], K[None], nf[None],
                                   [(fx, fy, cx, cy)], width, height, sh_degree, background_rgb, near_plane, far_plane, eps2d,
                                   absgrad, pair_counters, flag)

@@ -29,19 +29,13 @@ _MEAN_3NN_FACTOR = (0.8929795115692493 + 1.1906393487589990 + 1.3890792402188323
 
 
 def random_quat_tensor(N: int, generator=None) -> Tensor:
-    """dn_model.py:1497-1509."""
-    u = torch.rand(N, generator=generator)
-    v = torch.rand(N, generator=generator)
-    w = torch.rand(N, generator=generator)
-    return torch.stack(
-        [
-            torch.sqrt(1 - u) * torch.sin(2 * math.pi * v),
-            torch.sqrt(1 - u) * torch.cos(2 * math.pi * v),
-            torch.sqrt(u) * torch.sin(2 * math.pi * w),
-            torch.sqrt(u) * torch.cos(2 * math.pi * w),
-        ],
-        dim=-1,
-    )
+    """Uniformly distributed unit quaternions from three uniform variates per quaternion (Shoemake's subgroup algorithm) — the
+    distribution, and the order in which the variates are drawn and combined, of dn_model.py:1497-1509, so that a seed gives
+    the reference's initial rotations."""
+    u, v, w = (torch.rand(N, generator=generator) for _ in range(3))
+    r1, r2 = torch.sqrt(1.0 - u), torch.sqrt(u)
+    a, b = 2.0 * math.pi * v, 2.0 * math.pi * w
+    return torch.stack((r1 * torch.sin(a), r1 * torch.cos(a), r2 * torch.sin(b), r2 * torch.cos(b)), dim=-1)
 
 
 def mean_3nn_distance_closed_form(N: int, extent: float = 10.0) -> float:

@@ -270,10 +270,11 @@ int dnsplat_dn_depth_normals(int32_t width, int32_t height, float fx, float fy, 
 /* nerfstudio get_viewmat + intrinsics + normal frame in one launch: from the camera-to-world matrix
  * c2w [3,4] (OpenGL axes, device) writes viewmat[16] (world->camera, OpenCV), K[9] and
  * normal_frame[12] (see dnsplat_camera).  Replaces ~20 tiny torch kernels per frame (dn_model.py:475-479).
- * zero_word (optional): a device word set to 0 by the same launch — the frame's dnsplat_proj_out.saturation_flag starts
- * here without a fill launch of its own. */
+ * zero_word (optional): n_zero_words (>= 1) device words set to 0 by the same launch — the frame's
+ * dnsplat_proj_out.saturation_flag and dnsplat_dn_post.depth_max start here without fill launches of their own. */
 int dnsplat_camera_prepare(const float *c2w, float fx, float fy, float cx, float cy,
-                           float *viewmat, float *K, float *normal_frame, uint32_t *zero_word, dnsplat_stream_t stream);
+                           float *viewmat, float *K, float *normal_frame, uint32_t *zero_word, int32_t n_zero_words,
+                           dnsplat_stream_t stream);
 
 /* Multi-view data parallelism, compact exchange of the SH gradients.  For one camera the gradient of Gaussian g's SH
  * coefficients is an outer product  v_coeff[g][k][c] = basis_k(dir_g) * v_colour[g][c]  (k < (degree+1)^2, c < 3), and the

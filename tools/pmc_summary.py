@@ -2,7 +2,7 @@
 import collections, csv, glob, json, re, sys
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 names = ["raster_bwd_kernel", "raster_fwd_kernel", "project_bwd_kernel", "project_fwd_kernel", "radix_scatter_kernel",
-         "radix_hist_kernel", "emit_kernel", "radix_scan_kernel", "tile_offsets_fill_kernel", "tile_first_init_kernel",
+         "radix_hist_kernel", "emit_prep_kernel", "radix_scan_kernel", "tile_offsets_fill_kernel", "tile_first_init_kernel",
          "scan_sums_kernel", "scan_sums_excl_kernel", "scan_final_kernel", "depth_keys_kernel", "set_u32_kernel",
          "dn_depth_normals_kernel", "sh_factors_kernel", "densify"]
 out = {}

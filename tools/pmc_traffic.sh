@@ -6,6 +6,6 @@
 cd "${GRAFT_REPO_ROOT:-.}"; R=$(pwd); mkdir -p gpurun_out/pmc_traffic; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$R/gpurun_out/pmc_traffic/$c" -o p -- \
-     python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > "$R/gpurun_out/pmc_traffic/$c.json" 2> "$R/gpurun_out/pmc_traffic/$c.err"); echo "$c rc=$?"
+     python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --lean ${BENCH_ARGS:-} > "$R/gpurun_out/pmc_traffic/$c.json" 2> "$R/gpurun_out/pmc_traffic/$c.err"); echo "$c rc=$?"
 done
 python tools/pmc_summary.py gpurun_out/pmc_traffic > gpurun_out/pmc_traffic/summary.json; python tools/pmc_traffic.py gpurun_out/pmc_traffic/summary.json ${WORKLOAD:-c2}

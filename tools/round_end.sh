@@ -27,11 +27,11 @@ python bench.py --steps 20 --warmup 3 --workload c5 --no-cpu-baseline --losses f
 DNSPLAT_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_c2_single_rank_rccl.json 2>/dev/null; tail -1 $O/bench_c2_single_rank_rccl.json | cut -c1-200
 DNSPLAT_TIGHT_TILES=0 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_c2_gsplat_tile_boxes.json 2>/dev/null; tail -1 $O/bench_c2_gsplat_tile_boxes.json | cut -c1-200
 echo "== kernel stats"
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof" -o trace -- python "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$R/$O/prof_bench.json" 2> "$R/$O/prof.err"); echo "rocprof rc=$?"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof" -o trace -- python "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --lean > "$R/$O/prof_bench.json" 2> "$R/$O/prof.err"); echo "rocprof rc=$?"
 cp $(ls $O/prof/*/*kernel_stats.csv $O/prof/*kernel_stats.csv 2>/dev/null | head -1) $O/kernel_stats.csv 2>/dev/null; head -4 $O/kernel_stats.csv | cut -c1-160
 echo "== vector-busy counters"
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d "$R/$O/pmc_sq" -o p -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1); echo "sq rc=$?"
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d "$R/$O/pmc_grbm" -o p -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1); echo "grbm rc=$?"
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d "$R/$O/pmc_sq" -o p -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --lean > /dev/null 2>&1); echo "sq rc=$?"
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d "$R/$O/pmc_grbm" -o p -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --lean > /dev/null 2>&1); echo "grbm rc=$?"
 python tools/pmc_summary.py $O > $O/pmc_counters.json 2>/dev/null
 python - <<'PY'
 import json
