@@ -54,7 +54,7 @@ class ProjOut(ctypes.Structure):
         ("compensations", c_void_p), ("tiles_per_gauss", c_void_p), ("splats", c_void_p),
         ("normals_world", c_void_p),
         ("with_depth_channel", c_int32), ("with_normal_channels", c_int32), ("saturation_flag", c_void_p),
-        ("tiles_bin", c_void_p), ("phase", c_int32),
+        ("tiles_bin", c_void_p), ("tile_boxes", c_void_p), ("phase", c_int32),
     ]
 
 
@@ -67,7 +67,7 @@ class BinArgs(ctypes.Structure):
         ("n_isects", c_void_p), ("n_isects_host", c_void_p),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("splats", c_void_p), ("tight_tiles", c_int32),
-        ("tile_ends", c_void_p), ("skip_offsets_fill", c_int32), ("n_isects_max", c_void_p),
+        ("tile_ends", c_void_p), ("skip_offsets_fill", c_int32), ("tile_boxes", c_void_p), ("n_isects_max", c_void_p),
     ]
 
 

@@ -323,6 +323,7 @@ class _ProjectFn(torch.autograd.Function):
         tiles = torch.empty(C, N, dtype=torch.int32, device=dev)
         # tight tile boxes: gsplat's count for the caller (info["tiles_per_gauss"]), the tight one for the binning
         tiles_bin = torch.empty(C, N, dtype=torch.int32, device=dev) if cfg.tight_tiles else None
+        tile_boxes = torch.empty(C, N, 2, dtype=torch.int32, device=dev)      # (first tile, width) of the box the binning walks
         means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
         depths = torch.empty(C, N, dtype=torch.float32, device=dev)
         conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
@@ -342,6 +343,7 @@ class _ProjectFn(torch.autograd.Function):
             out.compensations = _ptr(comp[c]) if comp is not None else None
             out.tiles_per_gauss, out.splats = _ptr(tiles[c]), _ptr(splats[c * N:])
             out.tiles_bin = _ptr(tiles_bin[c]) if tiles_bin is not None else None
+            out.tile_boxes = _ptr(tile_boxes[c])
             out.normals_world = _ptr(nworld[c]) if nworld is not None else None
             out.with_depth_channel = int(cfg.with_depth)
             out.with_normal_channels = int(cfg.with_normals)
@@ -372,12 +374,12 @@ class _ProjectFn(torch.autograd.Function):
             tiles_bin = torch.empty(0, dtype=torch.int32, device=dev)
         # ONE call: every call of mark_non_differentiable replaces the set of the previous one (normals_world with a grad_fn
         # would keep the frame's autograd graph alive through gauss_params["normals"])
-        ctx.mark_non_differentiable(*([radii, tiles, tiles_bin] + ([nworld] if nworld is not None else [])))
+        ctx.mark_non_differentiable(*([radii, tiles, tiles_bin, tile_boxes] + ([nworld] if nworld is not None else [])))
         return (means2d, depths, conics, comp if comp is not None else empty, splats, radii, tiles,
-                nworld if nworld is not None else empty, tiles_bin)
+                nworld if nworld is not None else empty, tiles_bin, tile_boxes)
 
     @staticmethod
-    def backward(ctx, v_means2d, v_depths, v_conics, v_comp, v_splats, _r, _t, _n, _tb):
+    def backward(ctx, v_means2d, v_depths, v_conics, v_comp, v_splats, _r, _t, _n, _tb, _bx):
         means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, radii, splats_fwd = ctx.saved_tensors
         cfg: ProjCfg = ctx.cfg
         N = means.shape[0]
@@ -475,13 +477,13 @@ def project(means, quats, scales, opacities, *, coeffs=None, sh0=None, shN=None,
             normal_frame=None, cfg: ProjCfg, saturation_flag: Optional[Tensor] = None, side: Optional[dict] = None):
     """``viewmat`` [4,4] or [C,4,4] (``K``, ``normal_frame`` alike) -> dict(means2d[C,N,2], depths[C,N], conics[C,N,3],
     compensations[C,N] | None, splats[C*N,16], radii[C,N], tiles_per_gauss[C,N], normals_world[C,N,3] | None)"""
-    m2d, dep, con, comp, splats, radii, tiles, nworld, tiles_bin = _ProjectFn.apply(
+    m2d, dep, con, comp, splats, radii, tiles, nworld, tiles_bin, tile_boxes = _ProjectFn.apply(
         means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, cfg, saturation_flag, side)
     # tiles_per_gauss: gsplat's count (A.3), always.  tiles_bin: what dnsplat_bin_* must be given — the same tensor, or the count
     # over the tight boxes when cfg.tight_tiles (the flag travels WITH the counts: rasterize* take both from here)
     return dict(means2d=m2d, depths=dep, conics=con, compensations=comp if comp.numel() else None, splats=splats,
                 radii=radii, tiles_per_gauss=tiles, normals_world=nworld if nworld.numel() else None,
-                tiles_bin=tiles_bin if cfg.tight_tiles else tiles, tight_tiles=bool(cfg.tight_tiles))
+                tiles_bin=tiles_bin if cfg.tight_tiles else tiles, tight_tiles=bool(cfg.tight_tiles), tile_boxes=tile_boxes)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -531,7 +533,7 @@ class Binning:
 
 def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, width: int, height: int,
               tile_size: int, after_emit=None, n_cameras: int = 1, tight_splats: Optional[Tensor] = None,
-              defer_ok: bool = False, want_ends: bool = False) -> Binning:
+              defer_ok: bool = False, want_ends: bool = False, tile_boxes: Optional[Tensor] = None) -> Binning:
     """Stage 2 over ``n_cameras`` stacked projections (inputs flattened to [C*N, ...]).  ``after_emit(binning)`` (optional)
     is called right after the emit/sort kernels are enqueued and BEFORE any host wait, so the caller can queue the
     compositing kernel behind them; in "capacity" mode it is called again if the capacity guess turned out too small."""
@@ -558,6 +560,7 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
         a.splats, a.tight_tiles = _ptr(tight_splats), int(tight_splats is not None)
         # the fused path keeps its lists to itself: [start, end) per tile instead of gsplat's offsets (no fill launch)
         a.tile_ends, a.skip_offsets_fill = _ptr(tile_ends), int(tile_ends is not None)
+        a.tile_boxes = _ptr(tile_boxes)          # the boxes ``tiles`` were counted over, from the same projection
         a.n_isects_max = _ptr(BUFFERS.n_max.get(_Buffers._key(dev) + key))
         return a, ws
 
@@ -753,7 +756,8 @@ class _RasterFn(torch.autograd.Function):
 
         tight = bool(holder is not None and holder.get("tight"))      # ``tiles`` were counted over the tight boxes
         b = bin_tiles(means2d.detach().reshape(-1, 2), radii.reshape(-1), depths.detach().reshape(-1), tiles.reshape(-1), width,
-                      height, tile_size, after_emit=composite, n_cameras=C, tight_splats=splats.detach() if tight else None)
+                      height, tile_size, after_emit=composite, n_cameras=C, tight_splats=splats.detach() if tight else None,
+                      tile_boxes=holder.get("tile_boxes") if holder is not None else None)
         if holder is not None:
             holder["binning"] = b
         ctx.save_for_backward(means2d, splats, b.flatten_ids, b.tile_offsets, render, alphas, last_ids)
@@ -793,13 +797,14 @@ class _RasterFn(torch.autograd.Function):
 
 
 def rasterize(means2d, splats, depths, radii, tiles, *, background=None, width, height, tile_size=16, D,
-              ed_channel=-1, xy_split=None, absgrad=False, holder=None, tight=False):
+              ed_channel=-1, xy_split=None, absgrad=False, holder=None, tight=False, tile_boxes=None):
     """-> render [C,H,W,D], alphas [C,H,W] for the C cameras of ``means2d`` [C,N,2] / ``splats`` [C*N,16].
     ``tiles`` / ``tight``: ``tiles_bin`` and ``tight_tiles`` of the project() result, always taken together (the binning walks the
     boxes the counts were taken over)."""
-    if tight:
+    if tight or tile_boxes is not None:
         holder = {} if holder is None else holder
-        holder["tight"] = True
+        holder["tight"] = bool(tight)
+        holder["tile_boxes"] = tile_boxes          # (first tile, width) per entry, of the same projection as ``tiles``
     if tile_size != 16:
         raise NotImplementedError("libdnsplat composites 16x16 tiles (dn_model.py:470-472 uses BLOCK_WIDTH = 16)")
     if xy_split is None:
@@ -910,7 +915,7 @@ class _RasterDnFn(torch.autograd.Function):
 
         b = bin_tiles(means2d.detach().reshape(-1, 2), radii.reshape(-1), depths.detach().reshape(-1), tiles.reshape(-1), width,
                       height, 16, after_emit=composite, n_cameras=C, tight_splats=splats.detach() if tight else None,
-                      defer_ok=True, want_ends=True)
+                      defer_ok=True, want_ends=True, tile_boxes=holder.get("tile_boxes") if holder is not None else None)
         for c in range(C):
             fx, fy, cx, cy = intr[c]
             _lib.run("dnsplat_dn_depth_normals", _lib.lib().dnsplat_dn_depth_normals, width, height, fx, fy, cx, cy,
@@ -969,16 +974,17 @@ class _RasterDnFn(torch.autograd.Function):
 
 
 def rasterize_dn(means2d, splats, depths, radii, tiles, *, background_rgb, width, height, intrinsics, absgrad=True,
-                 holder=None, tight=False):
+                 holder=None, tight=False, tile_boxes=None):
     """``intrinsics``: one (fx, fy, cx, cy) per camera of ``means2d`` [C,N,2].
     -> rgb[C,H,W,3], depth[C,H,W,1], normal[C,H,W,3], accumulation[C,H,W,1], surface_normal[C,H,W,3].
     ``holder["pair_counters"]`` (optional uint64 [8] device tensor) switches both compositing kernels to their measurement
     instantiation (bench.py's VALU roofline)."""
     if isinstance(intrinsics[0], (int, float)):
         intrinsics = [tuple(intrinsics)]
-    if tight:          # ``tiles`` = tiles_bin of a projection with tight tile boxes (always taken together from the project() result)
+    if tight or tile_boxes is not None:    # ``tiles`` = tiles_bin (+ flag, + boxes): always taken together from the project() result
         holder = {} if holder is None else holder
-        holder["tight"] = True
+        holder["tight"] = bool(tight)
+        holder["tile_boxes"] = tile_boxes
     return _RasterDnFn.apply(means2d, splats, depths, radii, tiles, background_rgb, width, height, list(intrinsics), absgrad,
                              holder)
 
@@ -992,13 +998,16 @@ def camera_prepare(c2w: Tensor, fx: float, fy: float, cx: float, cy: float, with
     ``flag.depth_max`` — so that the frame needs no fill launch for either)."""
     c2w = _f32c(c2w.reshape(-1)[:12], "camera_to_worlds")
     dev = c2w.device
-    out = torch.empty(16 + 9 + 12 + 1 + n_depth_max, dtype=torch.float32, device=dev)
+    out = torch.empty(16 + 9 + 12, dtype=torch.float32, device=dev)
     viewmat, K, nf = out[:16], out[16:25], out[25:37]
-    flag = out[37:38].view(torch.int32) if with_flag else None
+    # the words the launch zeroes live in their own buffer: autograd saves viewmat / K, and a later in-place fill of depth_max
+    # (a re-run after a capacity overflow) must not touch their version counter
+    zeros = torch.empty(1 + n_depth_max, dtype=torch.float32, device=dev) if with_flag else None
+    flag = zeros[0:1].view(torch.int32) if with_flag else None
     _lib.run("dnsplat_camera_prepare", _lib.lib().dnsplat_camera_prepare, _ptr(c2w), fx, fy, cx, cy, _ptr(viewmat), _ptr(K),
              _ptr(nf) if with_normal_frame else None, _ptr(flag), 1 + n_depth_max, _stream())
     if with_flag and n_depth_max:
-        DEPTH_MAX_OF[flag.data_ptr()] = out[38:38 + n_depth_max]
+        DEPTH_MAX_OF[flag.data_ptr()] = zeros[1:1 + n_depth_max]
     res = (viewmat.view(4, 4), K.view(3, 3), (nf if with_normal_frame else None))
     return res + (flag,) if with_flag else res
 

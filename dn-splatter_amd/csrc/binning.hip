@@ -437,6 +437,7 @@ struct EmitPrep {
     const float *__restrict__ means2d;
     const int32_t *__restrict__ radii;
     const float4 *__restrict__ splats;   // tight tile boxes (dnsplat_bin_args.tight_tiles): the box the projection kernel counted
+    const int2 *__restrict__ boxes;      // or NULL: (first tile id within the camera's grid, width) straight from the projection
 };
 
 __global__ __launch_bounds__(SC_THREADS) void scan_final_kernel(int N, const uint32_t *__restrict__ order,
@@ -489,6 +490,16 @@ __global__ __launch_bounds__(256) void emit_prep_kernel(int N, const uint32_t *_
     const uint32_t end = cum[j], start = j ? cum[j - 1] : 0u;
     if (end <= start) return;
     const uint32_t gid = order[j];
+    if (ep.boxes) {
+        const int2 b = ep.boxes[gid];
+        EmitRec r;
+        r.gid = gid; r.start = start; r.bw = (uint32_t)b.y;
+        r.base_tile = (uint32_t)b.x + ((ep.n_per_cam < N) ? (gid / (uint32_t)ep.n_per_cam) * (uint32_t)(ep.tw * ep.th) : 0u);
+        ep.jrec[j] = r;
+        const uint32_t c_lo = (start + (uint32_t)ep.chunk - 1u) / (uint32_t)ep.chunk, c_hi = (end - 1u) / (uint32_t)ep.chunk;
+        for (uint32_t c = c_lo; c <= c_hi && c < (uint32_t)ep.nb_chunks; ++c) ep.chunk_first[c] = (uint32_t)j;
+        return;
+    }
     int x0, y0, x1, y1;
     if (ep.splats) {
         const float4 r0 = ep.splats[(size_t)gid * 4], r1 = ep.splats[(size_t)gid * 4 + 1];
@@ -734,7 +745,7 @@ extern "C" int dnsplat_bin_prepare(const dnsplat_bin_args *a, dnsplat_stream_t s
     hipStream_t stream = (hipStream_t)stream_;
     BinWs w = carve(a->workspace, a->N, a->isect_capacity);
     const int N = a->N;
-    if (a->tight_tiles && !a->splats && N > 0) return DNSPLAT_ERR_INVALID_ARG;
+    if (a->tight_tiles && !a->splats && !a->tile_boxes && N > 0) return DNSPLAT_ERR_INVALID_ARG;
     if (N == 0) {
         if (hipMemsetAsync(a->n_isects, 0, sizeof(int64_t), stream) != hipSuccess) return DNSPLAT_ERR_LAUNCH;
         if (hipMemsetAsync(w.total, 0, sizeof(uint32_t), stream) != hipSuccess) return DNSPLAT_ERR_LAUNCH;
@@ -759,6 +770,7 @@ extern "C" int dnsplat_bin_prepare(const dnsplat_bin_args *a, dnsplat_stream_t s
         ep.tw = dns_tiles_w(a->width, a->tile_size); ep.th = dns_tiles_h(a->height, a->tile_size);
         ep.means2d = a->means2d; ep.radii = a->radii;
         ep.splats = a->tight_tiles ? reinterpret_cast<const float4 *>(a->splats) : nullptr;
+        ep.boxes = reinterpret_cast<const int2 *>(a->tile_boxes);
         hipLaunchKernelGGL(scan_final_kernel, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.val_a,
                            a->tiles_per_gauss, w.sums, w.cum, w.total, a->n_isects, a->n_isects_max);
         hipLaunchKernelGGL(emit_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, w.val_a, w.cum, ep);
@@ -776,7 +788,7 @@ extern "C" int dnsplat_bin_emit_sort(const dnsplat_bin_args *a, dnsplat_stream_t
     int rc = check_bin(a);
     if (rc != DNSPLAT_OK) return rc;
     if (!a->tile_offsets || (a->isect_capacity > 0 && !a->flatten_ids)) return DNSPLAT_ERR_INVALID_ARG;
-    if (a->tight_tiles && !a->splats && a->N > 0) return DNSPLAT_ERR_INVALID_ARG;
+    if (a->tight_tiles && !a->splats && !a->tile_boxes && a->N > 0) return DNSPLAT_ERR_INVALID_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     BinWs w = carve(a->workspace, a->N, a->isect_capacity);
     const int tw = dns_tiles_w(a->width, a->tile_size), th = dns_tiles_h(a->height, a->tile_size);

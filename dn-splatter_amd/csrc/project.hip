@@ -418,6 +418,7 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
         if (p.o.compensations) p.o.compensations[g] = 0.f;
         p.o.tiles_per_gauss[g] = 0;
         if (p.c.tight_tiles) p.o.tiles_bin[g] = 0;
+        if (p.o.tile_boxes) reinterpret_cast<int2 *>(p.o.tile_boxes)[g] = make_int2(0, 0);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         rec4[0] = z4; rec4[1] = z4; rec4[2] = z4; rec4[3] = z4;
         if (p.o.normals_world) {
@@ -446,6 +447,8 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
                            x0, y0, x1, y1);
         p.o.tiles_bin[g] = (y1 - y0) * (x1 - x0);          // what the binning of the fused path walks
     }
+    // the box the binning will walk, ready-made (dnsplat_bin_args.tile_boxes): first tile id and width
+    if (p.o.tile_boxes) reinterpret_cast<int2 *>(p.o.tile_boxes)[g] = make_int2(y0 * tw + x0, x1 - x0);
 
     p.o.radii[g] = (int32_t)st.radius;
     p.o.means2d[2 * g] = st.mean2d[0]; p.o.means2d[2 * g + 1] = st.mean2d[1];

@@ -80,7 +80,7 @@ def render_dn(
     # the tile lists of this path are internal: tight tile boxes (counts and flag both from the projection result)
     out, alphas = _ops.rasterize(pr["means2d"], pr["splats"], pr["depths"], pr["radii"], pr["tiles_bin"],
                                  background=bg, width=width, height=height, tile_size=16, D=D, ed_channel=3,
-                                 xy_split=4, absgrad=absgrad, holder=holder, tight=pr["tight_tiles"])
+                                 xy_split=4, absgrad=absgrad, holder=holder, tight=pr["tight_tiles"], tile_boxes=pr["tile_boxes"])
     b = holder["binning"]
     info = {
         "means2d": pr["means2d"], "radii": pr["radii"], "depths": pr["depths"], "conics": pr["conics"],
@@ -147,7 +147,7 @@ def _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest
         holder["pair_counters"] = pair_counters
     rgb, depth, normal, acc, surface_normal = _ops.rasterize_dn(
         pr["means2d"], pr["splats"], pr["depths"], pr["radii"], pr["tiles_bin"], background_rgb=background_rgb,
-        width=width, height=height, intrinsics=intr, absgrad=absgrad, holder=holder, tight=pr["tight_tiles"])
+        width=width, height=height, intrinsics=intr, absgrad=absgrad, holder=holder, tight=pr["tight_tiles"], tile_boxes=pr["tile_boxes"])
     b = holder["binning"]
     info = _ops.LazyInfo({
         "means2d": pr["means2d"], "radii": pr["radii"], "depths": pr["depths"], "conics": pr["conics"],

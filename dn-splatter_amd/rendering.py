@@ -98,7 +98,7 @@ def rasterization(
     bg = _background_row(backgrounds, n_feat, with_depth, D)
     render, alphas = _ops.rasterize(pr["means2d"], pr["splats"], pr["depths"], pr["radii"], pr["tiles_per_gauss"],
                                     background=bg, width=width, height=height, tile_size=tile_size, D=D,
-                                    ed_channel=ed_channel, absgrad=absgrad, holder=holder)
+                                    ed_channel=ed_channel, absgrad=absgrad, holder=holder, tile_boxes=pr["tile_boxes"])
     b: _ops.Binning = holder["binning"]
     tw, th = b.tile_width, b.tile_height
     meta = {
