@@ -40,16 +40,18 @@ __global__ __launch_bounds__(256) void dn_depth_normals_kernel(int W, int H, flo
         // back-projection with pixel centres at +0.5 (camera_utils.py:92-144), c2w = identity
         const float dl = filled_depth(depth, alphas, dmax, idx - 1), dr = filled_depth(depth, alphas, dmax, idx + 1);
         const float dt = filled_depth(depth, alphas, dmax, idx - W), db = filled_depth(depth, alphas, dmax, idx + W);
-        const float x = (float)j + 0.5f, y = (float)i + 0.5f;
-        const float lx = (x - 1.f - cx) * dl / fx, ly = (y - cy) * dl / fy, lz = dl;
-        const float rx = (x + 1.f - cx) * dr / fx, ry = (y - cy) * dr / fy, rz = dr;
-        const float tx = (x - cx) * dt / fx, ty = (y - 1.f - cy) * dt / fy, tz = dt;
-        const float bx = (x - cx) * db / fx, by = (y + 1.f - cy) * db / fy, bz = db;
+        // two reciprocals instead of eight divisions (the kernel is bound by them, not by its 49 MB): within 1-2 ulp of the
+        // reference's (x - cx) * d / fx, against a test tolerance of 5e-6 on the [0, 1] normal image
+        const float x = (float)j + 0.5f, y = (float)i + 0.5f, ifx = 1.f / fx, ify = 1.f / fy;
+        const float lx = (x - 1.f - cx) * dl * ifx, ly = (y - cy) * dl * ify, lz = dl;
+        const float rx = (x + 1.f - cx) * dr * ifx, ry = (y - cy) * dr * ify, rz = dr;
+        const float tx = (x - cx) * dt * ifx, ty = (y - 1.f - cy) * dt * ify, tz = dt;
+        const float bx = (x - cx) * db * ifx, by = (y + 1.f - cy) * db * ify, bz = db;
         const float ax = rx - lx, ay = ry - ly, az = rz - lz;     // left_to_right
         const float ux = tx - bx, uy = ty - by, uz = tz - bz;     // bottom_to_top
         float c0 = ay * uz - az * uy, c1 = az * ux - ax * uz, c2 = ax * uy - ay * ux;
-        const float nrm = fmaxf(sqrtf(c0 * c0 + c1 * c1 + c2 * c2), 1e-12f);   // F.normalize eps
-        n0 = c0 / nrm; n1 = c1 / nrm; n2 = c2 / nrm;
+        const float inrm = 1.f / fmaxf(sqrtf(c0 * c0 + c1 * c1 + c2 * c2), 1e-12f);   // F.normalize eps
+        n0 = c0 * inrm; n1 = c1 * inrm; n2 = c2 * inrm;
     }
     // dn_model.py:599-603: @ diag(1,-1,-1), then (1 + n) / 2; the zero-padded border becomes 0.5
     surface_normal[3 * idx + 0] = (1.f + n0) / 2.f;
