@@ -248,6 +248,8 @@ def main():
     # Stage breakdown: PROBE_STEPS fully instrumented steps OUTSIDE the timed region.  Bracketing all six stages with
     # HIP events costs ~80 us of stream time per frame (a ~6 us bubble per event pair, seen in the rocprofv3 timeline),
     # so the timed region below only brackets the dominant stage, whose live duration the roofline figure needs.
+    for _ in range(0 if args.lean else PREROLL_STEPS):      # the probes, too, are taken at operating clocks (see PREROLL_STEPS)
+        step()
     torch.cuda.synchronize()
     probe = _lib.StageTimer()
     _lib.TIMER = probe
