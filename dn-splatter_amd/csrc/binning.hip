@@ -6,7 +6,8 @@
 //
 // Same result, different route.  The reference sorts I = n_isects 12-byte pairs on ~45 key bits
 // (6 radix passes over I).  Here:
-//   1. the N Gaussians are stably radix-sorted once by their 32 depth bits (4 passes over N, N << I);
+//   1. the N Gaussians are stably radix-sorted once by their 32 depth bits (4 passes over N, N << I); the first pass
+//      drops the culled ones (they emit nothing), the other three and the scans run over the visible Gaussians only;
 //   2. the (tile, gaussian) pairs of that depth order are never written out as such: the FIRST pass of the tile
 //      sort generates them on the fly — once to count its digits, once to place them (each workgroup owns 4096
 //      consecutive pairs of the emission order and finds the Gaussians they belong to through a 16-byte record
@@ -118,6 +119,7 @@ struct GenArgs {
     const uint32_t *__restrict__ chunk_first;   // [nb] depth rank of the Gaussian that holds pair chunk * CHUNK
     int N, tw;
     int exact;                               // floor((t + 0.5) / bw) through an fp32 reciprocal is exact (see gen_pair)
+    const uint32_t *__restrict__ n_ranked;   // device word: how many depth ranks exist (the visible Gaussians); jrec / cum end there
 };
 
 constexpr int gen_pad(int i) { return i + (i >> 5); }      // one pad word per 32: a thread's 16 consecutive slots stay conflict-free
@@ -131,11 +133,12 @@ __device__ __forceinline__ uint32_t gen_owners(uint32_t *owner, uint32_t *lds_wa
     constexpr int CHUNK = TH * ITEMS;
     for (int i = threadIdx.x; i < gen_pad(CHUNK); i += TH) owner[i] = 0u;
     const uint32_t j0 = g.chunk_first[chunk];
+    const uint32_t n_ranked = min(*g.n_ranked, (uint32_t)g.N);
     __syncthreads();
     for (uint32_t jb = j0;; jb += TH) {
         const uint32_t jj = jb + threadIdx.x;
         bool inside = false;       // this Gaussian starts before the end of the chunk (cum is non-decreasing: so do all before it)
-        if (jj < (uint32_t)g.N) {
+        if (jj < n_ranked) {
             const uint32_t e = g.cum[jj], s = jj ? g.cum[jj - 1] : 0u;
             inside = s < q0 + n_valid;
             if (inside && e > s && e > q0) owner[gen_pad((int)(max(s, q0) - q0))] = jj - j0 + 1u;
@@ -224,7 +227,8 @@ __global__ __launch_bounds__(TH) void radix_hist_kernel(const K *__restrict__ ke
                 uint32_t k;
                 if (GEN) { uint32_t v; gen_pair(owner, gen, j0, base, idx - base, k, v); }
                 else k = FIRST ? depth_key(radii, depths, idx) : (uint32_t)keys[idx];
-                atomicAdd(&hist[(k >> shift) & mask], 1u);
+                // the first depth pass drops the culled Gaussians: they emit nothing, so nothing downstream needs their rank
+                if (!FIRST || radii[idx] > 0) atomicAdd(&hist[(k >> shift) & mask], 1u);
             }
         }
     }
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(TH) void radix_scatter_kernel(
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ n_ptr, uint32_t n_cap, int shift,
     const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nb, int32_t *__restrict__ tile_first,
     const int32_t *__restrict__ radii = nullptr, const float *__restrict__ depths = nullptr,
-    int32_t *__restrict__ tile_end = nullptr, GenArgs gen = GenArgs{})
+    int32_t *__restrict__ tile_end = nullptr, GenArgs gen = GenArgs{}, uint32_t *__restrict__ count_out = nullptr)
 {
     // The chunk is first sorted by digit INSIDE LDS (stable), then written out run by run: consecutive lanes
     // store to consecutive addresses of one digit's run, so the stores coalesce.  A direct scatter from the
@@ -318,6 +322,7 @@ __global__ __launch_bounds__(TH) void radix_scatter_kernel(
     else __syncthreads();
 
     uint32_t key[ITEMS], val[ITEMS], rnk[ITEMS];
+    uint32_t live = 0u;                                   // FIRST: bit r = item r is a visible Gaussian (the others are dropped here)
     const uint32_t wave_start = base + w * (DNS_WAVE * ITEMS);
     if (GEN) {
         // all pairs first: the owner table is overwritten by the staging stores below
@@ -331,10 +336,12 @@ __global__ __launch_bounds__(TH) void radix_scatter_kernel(
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const uint32_t idx = wave_start + r * DNS_WAVE + lane;
-        const bool valid = idx < n;
+        bool valid = idx < n;
         if (FIRST) {
-            key[r] = valid ? depth_key(radii, depths, idx) : 0u;
+            valid = valid && radii[idx] > 0;
+            key[r] = valid ? __float_as_uint(depths[idx]) : 0u;
             val[r] = idx;
+            live |= (valid ? 1u : 0u) << r;
         } else if (!GEN) {
             key[r] = valid ? (uint32_t)keys_in[idx] : 0u;
             val[r] = valid ? vals_in[idx] : 0u;
@@ -354,6 +361,7 @@ __global__ __launch_bounds__(TH) void radix_scatter_kernel(
         if (valid && below == 0) wave_cnt[w][d] = prior + __popcll(m);  // set leader bumps the counter
     }
     __syncthreads();
+    uint32_t n_out = n_valid;
     {
         // digit d = threadIdx.x (threads beyond the 256 digits only take part in the scans)
         const bool has_digit = threadIdx.x < RS_DIGITS;
@@ -367,6 +375,7 @@ __global__ __launch_bounds__(TH) void radix_scatter_kernel(
         uint32_t t2;
         const uint32_t linc = block_incl_scan<NW>(cnt, lds_wave, t2);     // chunk-local exclusive start
         const uint32_t ls = linc - cnt;
+        if (FIRST) n_out = t2;                                            // keys this chunk keeps (the same number in every thread)
         if (has_digit) {
             dstart[threadIdx.x] = ls;
             uint32_t run = ls;
@@ -380,12 +389,14 @@ __global__ __launch_bounds__(TH) void radix_scatter_kernel(
         const uint32_t tot = pre_tot;
         const uint32_t ginc = block_incl_scan<NW>(tot, lds_wave, t2);
         if (has_digit) gbase[threadIdx.x] = is_digit ? (ginc - tot) + pre_tab : 0u;
+        // FIRST: the number of keys the sort goes on with (every later pass and the scans read it)
+        if (FIRST && count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = t2;
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const uint32_t idx = wave_start + r * DNS_WAVE + lane;
-        if (idx < n) {
+        if (FIRST ? ((live >> r) & 1u) != 0u : idx < n) {
             const uint32_t d = (key[r] >> shift) & DMASK;
             const uint32_t lpos = wave_loc[w][d] + rnk[r];
             keys_s[lpos] = (K)key[r];
@@ -396,7 +407,7 @@ __global__ __launch_bounds__(TH) void radix_scatter_kernel(
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const uint32_t i = r * TH + threadIdx.x;
-        if (i < n_valid) {
+        if (i < n_out) {
             const uint32_t k = keys_s[i];
             const uint32_t d = (k >> shift) & DMASK;
             const uint32_t dst = gbase[d] + (i - dstart[d]);
@@ -409,18 +420,23 @@ __global__ __launch_bounds__(TH) void radix_scatter_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3. inclusive scan of tiles_per_gauss gathered in depth order  -> cum[N], total
-__global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(int N, const uint32_t *__restrict__ order,
+// 3. inclusive scan of tiles_per_gauss gathered in depth order  -> cum[n], total; n = the number of depth ranks (visible Gaussians),
+// a device word the first depth pass leaves behind
+__global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(int N, const uint32_t *__restrict__ n_ptr,
+                                                               const uint32_t *__restrict__ order,
                                                                const int32_t *__restrict__ tiles,
                                                                uint32_t *__restrict__ sums)
 {
     __shared__ uint32_t lds_wave[4];
+    const int n = (int)min(*n_ptr, (uint32_t)N);
     const int base = blockIdx.x * SC_CHUNK + threadIdx.x * SC_ITEMS;
     uint32_t s = 0;
+    if (blockIdx.x * SC_CHUNK < n) {
 #pragma unroll
-    for (int i = 0; i < SC_ITEMS; ++i) {
-        int j = base + i;
-        if (j < N) s += (uint32_t)tiles[order[j]];
+        for (int i = 0; i < SC_ITEMS; ++i) {
+            int j = base + i;
+            if (j < n) s += (uint32_t)tiles[order[j]];
+        }
     }
     uint32_t tot;
     block_incl_scan_256(s, lds_wave, tot);
@@ -428,7 +444,7 @@ __global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(int N, const uint
 }
 
 // What the pair generators of the tile sort's first pass need per Gaussian (EmitRec, by depth rank) and per 4096-pair chunk
-// (the depth rank of the Gaussian that holds the chunk's first pair) is written by the same kernel.
+// (the depth rank of the Gaussian that holds the chunk's first pair).
 struct EmitPrep {
     EmitRec *__restrict__ jrec;
     uint32_t *__restrict__ chunk_first;
@@ -440,20 +456,51 @@ struct EmitPrep {
     const int2 *__restrict__ boxes;      // or NULL: (first tile id within the camera's grid, width) straight from the projection
 };
 
-__global__ __launch_bounds__(SC_THREADS) void scan_final_kernel(int N, const uint32_t *__restrict__ order,
+// depth rank j = entry gid owns the pairs [start, end) of the emission order, end > start
+__device__ __forceinline__ void emit_record(const EmitPrep &ep, int N, uint32_t j, uint32_t gid, uint32_t start, uint32_t end)
+{
+    EmitRec r;
+    r.gid = gid; r.start = start;
+    // batch of cameras: entry gid belongs to camera gid / n_per_cam, whose tile grid is stacked below the previous
+    // cameras' (tile id = camera * tw * th + row * tw + column)
+    const uint32_t cam_tiles = (ep.n_per_cam < N) ? (gid / (uint32_t)ep.n_per_cam) * (uint32_t)(ep.tw * ep.th) : 0u;
+    if (ep.boxes) {
+        const int2 b = ep.boxes[gid];
+        r.bw = (uint32_t)b.y;
+        r.base_tile = (uint32_t)b.x + cam_tiles;
+    } else {
+        int x0, y0, x1, y1;
+        if (ep.splats) {
+            const float4 r0 = ep.splats[(size_t)gid * 4], r1 = ep.splats[(size_t)gid * 4 + 1];
+            dns_snug_tile_bbox(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, (float)ep.radii[gid], ep.tile_size, ep.tw, ep.th, x0, y0, x1, y1);
+        } else
+            dns_tile_bbox(ep.means2d[2 * gid], ep.means2d[2 * gid + 1], (float)ep.radii[gid], ep.tile_size, ep.tw, ep.th, x0, y0, x1, y1);
+        r.base_tile = (uint32_t)(y0 * ep.tw + x0) + cam_tiles;
+        r.bw = (uint32_t)(x1 - x0);
+    }
+    ep.jrec[j] = r;
+    const uint32_t c_lo = (start + (uint32_t)ep.chunk - 1u) / (uint32_t)ep.chunk, c_hi = (end - 1u) / (uint32_t)ep.chunk;
+    for (uint32_t c = c_lo; c <= c_hi && c < (uint32_t)ep.nb_chunks; ++c) ep.chunk_first[c] = j;
+}
+
+__global__ __launch_bounds__(SC_THREADS) void scan_final_kernel(int N, const uint32_t *__restrict__ n_ptr,
+                                                                const uint32_t *__restrict__ order,
                                                                 const int32_t *__restrict__ tiles,
                                                                 const uint32_t *__restrict__ sums,
                                                                 uint32_t *__restrict__ cum, uint32_t *__restrict__ total_u32,
                                                                 int64_t *__restrict__ total_i64, int64_t *__restrict__ total_max)
 {
     __shared__ uint32_t lds_wave[4];
+    const int n = (int)min(*n_ptr, (uint32_t)N);
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) { *total_u32 = 0u; *total_i64 = 0; }
+    if (blockIdx.x * SC_CHUNK >= n) return;
     const int base = blockIdx.x * SC_CHUNK + threadIdx.x * SC_ITEMS;
     uint32_t v[SC_ITEMS];
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < SC_ITEMS; ++i) {
         int j = base + i;
-        v[i] = (j < N) ? (uint32_t)tiles[order[j]] : 0u;
+        v[i] = (j < n) ? (uint32_t)tiles[order[j]] : 0u;
         s += v[i];
     }
     // exclusive prefix of the chunk sums: every workgroup adds up the (few hundred) sums of the chunks before it itself,
@@ -469,9 +516,9 @@ __global__ __launch_bounds__(SC_THREADS) void scan_final_kernel(int N, const uin
     for (int i = 0; i < SC_ITEMS; ++i) {
         int j = base + i;
         run += v[i];
-        if (j < N) {
+        if (j < n) {
             cum[j] = run;
-            if (j == N - 1) {
+            if (j == n - 1) {
                 *total_u32 = run; *total_i64 = (int64_t)run;
                 // sticky maximum over the frames since the caller last cleared it: lets a host that never waits for a single
                 // frame's count (captured HIP graphs) still find out, later, whether any frame exceeded its capacity
@@ -481,39 +528,16 @@ __global__ __launch_bounds__(SC_THREADS) void scan_final_kernel(int N, const uin
     }
 }
 
-// one thread per depth rank j: the Gaussian's EmitRec and the heads of the pair chunks that start inside its pairs
-__global__ __launch_bounds__(256) void emit_prep_kernel(int N, const uint32_t *__restrict__ order, const uint32_t *__restrict__ cum,
-                                                        EmitPrep ep)
+// one thread per depth rank j: the Gaussian's EmitRec and the heads of the pair chunks that start inside its pairs.  A kernel of its
+// own: folded into scan_final_kernel (eight consecutive ranks per thread) it cost more than the launch it saved (paired: +2.5 % on
+// dnsplat_bin_prepare at C2, +11 % at C5)
+__global__ __launch_bounds__(256) void emit_prep_kernel(int N, const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ order,
+                                                        const uint32_t *__restrict__ cum, EmitPrep ep)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N) return;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= min(*n_ptr, (uint32_t)N)) return;
     const uint32_t end = cum[j], start = j ? cum[j - 1] : 0u;
-    if (end <= start) return;
-    const uint32_t gid = order[j];
-    if (ep.boxes) {
-        const int2 b = ep.boxes[gid];
-        EmitRec r;
-        r.gid = gid; r.start = start; r.bw = (uint32_t)b.y;
-        r.base_tile = (uint32_t)b.x + ((ep.n_per_cam < N) ? (gid / (uint32_t)ep.n_per_cam) * (uint32_t)(ep.tw * ep.th) : 0u);
-        ep.jrec[j] = r;
-        const uint32_t c_lo = (start + (uint32_t)ep.chunk - 1u) / (uint32_t)ep.chunk, c_hi = (end - 1u) / (uint32_t)ep.chunk;
-        for (uint32_t c = c_lo; c <= c_hi && c < (uint32_t)ep.nb_chunks; ++c) ep.chunk_first[c] = (uint32_t)j;
-        return;
-    }
-    int x0, y0, x1, y1;
-    if (ep.splats) {
-        const float4 r0 = ep.splats[(size_t)gid * 4], r1 = ep.splats[(size_t)gid * 4 + 1];
-        dns_snug_tile_bbox(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, (float)ep.radii[gid], ep.tile_size, ep.tw, ep.th, x0, y0, x1, y1);
-    } else
-        dns_tile_bbox(ep.means2d[2 * gid], ep.means2d[2 * gid + 1], (float)ep.radii[gid], ep.tile_size, ep.tw, ep.th, x0, y0, x1, y1);
-    // batch of cameras: entry gid belongs to camera gid / n_per_cam, whose tile grid is stacked below the previous
-    // cameras' (tile id = camera * tw * th + row * tw + column) — folded into the first tile row of the box
-    if (ep.n_per_cam < N) y0 += (int)(gid / (uint32_t)ep.n_per_cam) * ep.th;
-    EmitRec r;
-    r.gid = gid; r.start = start; r.base_tile = (uint32_t)(y0 * ep.tw + x0); r.bw = (uint32_t)(x1 - x0);
-    ep.jrec[j] = r;
-    const uint32_t c_lo = (start + (uint32_t)ep.chunk - 1u) / (uint32_t)ep.chunk, c_hi = (end - 1u) / (uint32_t)ep.chunk;
-    for (uint32_t c = c_lo; c <= c_hi && c < (uint32_t)ep.nb_chunks; ++c) ep.chunk_first[c] = (uint32_t)j;
+    if (end > start) emit_record(ep, N, j, order[j], start, end);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -577,6 +601,7 @@ struct BinWs {
     uint32_t *sums;                           // [nb_scan]
     uint32_t *total;                          // [1] n_isects as u32
     uint32_t *status;                         // [1] reserved status word (dnsplat_bin_status_offset): 0
+    uint32_t *n_ranked;                       // [1] Gaussians the depth sort kept (radii > 0) = number of depth ranks
     uint32_t *tkey_b, *tval_b;                // [cap] pairs between the two tile passes
     uint32_t *tkey_c, *tval_c;                // [cap] only with three tile passes (> 65536 tiles)
     uint32_t *tab_i;                          // [256 * nb_i]
@@ -613,6 +638,7 @@ BinWs carve(void *ws, int N, int64_t cap)
     b.sums = take(b.nb_scan);
     b.total = take(1);
     b.status = take(1);
+    b.n_ranked = take(1);
     // capacity-sized part
     b.tkey_b = take(c); b.tval_b = take(c);
     b.tkey_c = take(c); b.tval_c = take(c);
@@ -629,14 +655,14 @@ template <typename K, int ITEMS, int TH = RS_THREADS>
 void radix_pass(hipStream_t stream, const K *ka, const uint32_t *va, K *kb, uint32_t *vb, const uint32_t *n_ptr,
                 uint32_t n_cap, int shift, int dbits, uint32_t *table, uint32_t *totals, int nb, int32_t *tile_first = nullptr,
                 const int32_t *radii = nullptr, const float *depths = nullptr, int32_t *init_offsets = nullptr, int n_tiles = 0,
-                int32_t *tile_end = nullptr, const GenArgs *gen = nullptr, uint32_t *status = nullptr)
+                int32_t *tile_end = nullptr, const GenArgs *gen = nullptr, uint32_t *status = nullptr, uint32_t *count_out = nullptr)
 {
     const uint32_t mask = (1u << dbits) - 1u;
     if (radii) {   // first pass of the depth sort: 8-bit digit, keys synthesised from (radii, depths)
         hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS, true, false, TH>), dim3(nb), dim3(TH), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb, radii, depths);
         hipLaunchKernelGGL(radix_scan_kernel, dim3(1 << dbits), dim3(SC_THREADS), 0, stream, table, nb, totals);
         hipLaunchKernelGGL((radix_scatter_kernel<K, false, 8, ITEMS, true, false, TH>), dim3(nb), dim3(TH), 0, stream, ka, va, kb, vb,
-                           n_ptr, n_cap, shift, table, totals, nb, tile_first, radii, depths);
+                           n_ptr, n_cap, shift, table, totals, nb, tile_first, radii, depths, (int32_t *)nullptr, GenArgs{}, count_out);
         return;
     }
     const GenArgs g = gen ? *gen : GenArgs{};
@@ -682,7 +708,7 @@ void emit_and_sort(hipStream_t stream, const dnsplat_bin_args *a, const BinWs &w
     const int passes = (bits + 7) / 8;
     GenArgs g;
     g.jrec = w.jrec; g.cum = w.cum; g.chunk_first = w.chunk_first;
-    g.N = a->N; g.tw = tw;
+    g.N = a->N; g.tw = tw; g.n_ranked = w.n_ranked;
     g.exact = (tw <= 256 && (int64_t)n_cam * tw * th <= 65536) ? 1 : 0;
     const K *ka = nullptr;
     const uint32_t *va = nullptr;
@@ -754,14 +780,16 @@ extern "C" int dnsplat_bin_prepare(const dnsplat_bin_args *a, dnsplat_stream_t s
         uint32_t *ka = w.key_a, *kb = w.key_b, *va = w.val_a, *vb = w.val_b;
         for (int pass = 0; pass < 4; ++pass) {
             const int shift = 8 * pass;
-            // the element count is known on the host here (n_ptr = NULL); pass 0 reads (radii, depths) instead of a key / value pair
-            radix_pass<uint32_t, RS_ITEMS_N>(stream, ka, va, kb, vb, nullptr, n_u32, shift, 8, w.tab_n, w.totals, w.nb_n, nullptr,
-                                             pass == 0 ? a->radii : nullptr, pass == 0 ? a->depths : nullptr);
+            // pass 0 knows its element count on the host (n_ptr = NULL), reads (radii, depths) instead of a key / value pair and drops
+            // the culled Gaussians; it leaves the number it kept in w.n_ranked, which bounds every later pass and the scans
+            radix_pass<uint32_t, RS_ITEMS_N>(stream, ka, va, kb, vb, pass == 0 ? nullptr : w.n_ranked, n_u32, shift, 8, w.tab_n, w.totals,
+                                             w.nb_n, nullptr, pass == 0 ? a->radii : nullptr, pass == 0 ? a->depths : nullptr, nullptr, 0,
+                                             nullptr, nullptr, nullptr, pass == 0 ? w.n_ranked : nullptr);
             uint32_t *t = ka; ka = kb; kb = t;
             t = va; va = vb; vb = t;
         }
         // after 4 passes the sorted order is back in val_a
-        hipLaunchKernelGGL(scan_sums_kernel, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.val_a, a->tiles_per_gauss,
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.n_ranked, w.val_a, a->tiles_per_gauss,
                            w.sums);
         EmitPrep ep;
         ep.jrec = w.jrec; ep.chunk_first = w.chunk_first; ep.nb_chunks = MAX_CHUNKS; ep.chunk = RS_THREADS * RS_ITEMS_I;
@@ -771,9 +799,9 @@ extern "C" int dnsplat_bin_prepare(const dnsplat_bin_args *a, dnsplat_stream_t s
         ep.means2d = a->means2d; ep.radii = a->radii;
         ep.splats = a->tight_tiles ? reinterpret_cast<const float4 *>(a->splats) : nullptr;
         ep.boxes = reinterpret_cast<const int2 *>(a->tile_boxes);
-        hipLaunchKernelGGL(scan_final_kernel, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.val_a,
+        hipLaunchKernelGGL(scan_final_kernel, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.n_ranked, w.val_a,
                            a->tiles_per_gauss, w.sums, w.cum, w.total, a->n_isects, a->n_isects_max);
-        hipLaunchKernelGGL(emit_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, w.val_a, w.cum, ep);
+        hipLaunchKernelGGL(emit_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, w.n_ranked, w.val_a, w.cum, ep);
         DNS_CHECK_LAUNCH();
     }
     if (a->n_isects_host) {

@@ -108,6 +108,13 @@ constexpr int TILE = 16;
 // 64 on average: with <= 64 (<= 32) splats the four rows are re-cut into two (four) independent arrays that each hold
 // ALL of the bucket's splats and stream a share of the pixels — 80 + 48 (56 + 40 + 24 + 8) of the 128, unequal because a
 // later row is still busy with the previous bucket for 16 more steps per row — and the bucket ends after 111 (71) steps.
+// State slots of a pixel row ordered (S_a, T, S_b, bin_final) instead of (T, S_a, S_b, bin_final): S_a and S_b arrive in the
+// LOW halves of the two aligned register pairs of the row's third ds_read_b128, the value the step computes next for each chain
+// (S after splat A) goes into the high half once T / bin_final are consumed, and the packed operand (S before A, S before B) is
+// that pair as it stands — no v_mov to build it.  The park store writes 12 bytes and leaves bin_final where it is.
+#ifndef DNS_BWD_PAIR_STATE
+#define DNS_BWD_PAIR_STATE 1
+#endif
 #ifndef DNS_BWD_FOLD
 #define DNS_BWD_FOLD 1
 #endif
@@ -209,6 +216,15 @@ __device__ __forceinline__ void pk_fma_bcast(f2 &acc, f2 a, f2 b, int hi)
     else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(b));
 }
 
+// a * (b.x or b.y broadcast to both halves): the first term of such a sum
+__device__ __forceinline__ f2 pk_mul_bcast(f2 a, f2 b, int hi)
+{
+    f2 r;
+    if (hi) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ float dpp_wave_shr1(float from_prev, float lane0_value)
 {
 #if DNS_BWD_FOLD
@@ -237,7 +253,7 @@ template <int D, int SPLIT, bool DN, bool COUNT = false, bool MASKS = false, boo
 __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) void raster_bwd_kernel(BwdArgs a)
 {
     if (a.sat_flag && (*a.sat_flag != 0u) != CLAMP_LOOP) return;
-    __shared__ float4 pix[NPIX][3];            // [p][0..1] = v_k, [p][2] = (T, S_a, S_b, bin_final)
+    __shared__ float4 pix[NPIX][3];            // [p][0..1] = v_k, [p][2] = (S_a, T, S_b, bin_final) (DNS_BWD_PAIR_STATE) or (T, S_a, S_b, bin_final)
     // compacted list indices waiting for a bucket (never more than 127 + 64) + the 1 KiB staging area of the transposed flush, which
     // ALIASES queue entries >= 64: while a pass is flushed only the < 64 left-over entries at the front of the queue are
     // live.  13.5 KiB per wave = 12 tiles in flight per CU (3 waves per SIMD, the VGPR limit) instead of 11.
@@ -355,7 +371,11 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
 #endif
         pix[p][0] = make_float4(v[0], v[1], v[2], v[3]);
         pix[p][1] = make_float4(v[4], v[5], v[6], v[7]);
+#if DNS_BWD_PAIR_STATE
+        pix[p][2] = make_float4(sa, T_final, sb, __int_as_float(bin_final));
+#else
         pix[p][2] = make_float4(T_final, sa, sb, __int_as_float(bin_final));
+#endif
         hi = max(hi, bin_final);
     }
 #pragma unroll
@@ -624,9 +644,16 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
                 const float al_a = CLAMP ? fminf((float)DNS_ALPHA_MAX, ov.x) : ov.x;
                 const float al_b = CLAMP ? fminf((float)DNS_ALPHA_MAX, ov.y) : ov.y;
                 // state arrives from the previous lane; lane 0 takes it from the pixel's LDS row
+#if DNS_BWD_PAIR_STATE
+                float T = dpp_wave_shr1(T_out, cst.y);
+                cst.x = dpp_wave_shr1(SA_out, cst.x);
+                cst.z = dpp_wave_shr1(SB_out, cst.z);
+                float SA = cst.x, SB = cst.z;
+#else
                 float T = dpp_wave_shr1(T_out, cst.x);
                 float SA = dpp_wave_shr1(SA_out, cst.y);
                 float SB = dpp_wave_shr1(SB_out, cst.z);
+#endif
                 const int bin_final = __float_as_int(cst.w);
                 const bool valid_a = active && cmp_a <= bin_final && e.x <= 0.f && al_a >= (float)DNS_ALPHA_MIN;
                 const bool valid_b = active && cmp_b <= bin_final && e.y <= 0.f && al_b >= (float)DNS_ALPHA_MIN;
@@ -659,17 +686,39 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
                         // one packed FMA with the cotangent broadcast by operand selection (hipcc would copy the
                         // broadcast pair into registers first, hence the inline instruction)
                         pk_fma_bcast(g_ch[k], fac, pp[k >> 1], k & 1);
+#if DNS_BWD_PAIR_STATE
+                        // the same broadcast for the two chains of channel sums: left to the compiler, one of the seven becomes a
+                        // v_mov of the channel into the low half of a fresh pair
+                        if (k < split) {
+                            if (k == 0) cva = pk_mul_bcast(ch[k], pp[0], 0);
+                            else pk_fma_bcast(cva, ch[k], pp[k >> 1], k & 1);
+                        } else {
+                            if (k == split) cvb = pk_mul_bcast(ch[k], pp[k >> 1], k & 1);
+                            else pk_fma_bcast(cvb, ch[k], pp[k >> 1], k & 1);
+                        }
+#else
                         if (k < split) cva = __builtin_elementwise_fma(ch[k], vk, cva);
                         else cvb = __builtin_elementwise_fma(ch[k], vk, cvb);
+#endif
                     }
                     const float SA1 = __builtin_fmaf(fac.x, cva.x, SA);
+#if DNS_BWD_PAIR_STATE
+                    cst.y = SA1;                                         // T has been consumed: (S_a, S_a after A) is a register pair
+                    const f2 SAv = __builtin_shufflevector(cst, cst, 0, 1);
+#else
                     const f2 SAv = {SA, SA1};
+#endif
                     const f2 va_a = Tv * cva - ra * SAv;
                     SA = __builtin_fmaf(fac.y, cva.y, SA1);
                     f2 va = va_a;
                     if (SPLIT != D) {
                         const float SB1 = __builtin_fmaf(fac.x, cvb.x, SB);
+#if DNS_BWD_PAIR_STATE
+                        cst.w = SB1;                                     // bin_final has been consumed
+                        const f2 SBv = __builtin_shufflevector(cst, cst, 2, 3);
+#else
                         const f2 SBv = {SB, SB1};
+#endif
                         va += Tv * cvb - ra * SBv;
                         SB = __builtin_fmaf(fac.y, cvb.y, SB1);
                     }
@@ -693,7 +742,13 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
                 }
                 T_out = T; SA_out = SA; SB_out = SB;
                 // park the state of the pixel leaving the array for the next (nearer) bucket
-#if DNS_BWD_FOLD
+#if DNS_BWD_FOLD && DNS_BWD_PAIR_STATE
+                if ((lane & 15) == 15 && active) {                        // to the next row / bucket; bin_final stays where it is
+                    float *st = reinterpret_cast<float *>(&pix[pcur][2]);
+                    typedef float v3f __attribute__((ext_vector_type(3)));
+                    *reinterpret_cast<v3f *>(st) = v3f{SA, T, SB};
+                }
+#elif DNS_BWD_FOLD
                 if ((lane & 15) == 15 && active) pix[pcur][2] = make_float4(T, SA, SB, cst.w);   // to the next row / bucket
 #else
                 if (lane == DNS_WAVE - 1 && active) pix[pcur][2] = make_float4(T, SA, SB, cst.w);

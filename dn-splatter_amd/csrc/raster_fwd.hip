@@ -22,6 +22,10 @@
 
 #include "splat_common.h"
 
+#ifndef DNS_FWD_PAIR_OPSEL
+#define DNS_FWD_PAIR_OPSEL 1
+#endif
+
 namespace {
 
 constexpr int TILE = 16;
@@ -212,8 +216,20 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
 #if DNS_EXP_SYM
             // dns_exponent() for both pixels of the lane, with the two products that only depend on dx formed once
             const float adx = q.na * dx, bdx = q.nb * dx;
+#if DNS_FWD_PAIR_OPSEL
+            // nb * dy + adx for both pixels as ONE packed FMA on the register pair (adx, nb) the record's (na, nb) turns into:
+            // nb is the pair's high half broadcast as the multiplier, adx its low half broadcast as the addend.  hipcc only finds
+            // low-half broadcasts and copies nb into a fresh pair first.
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 an = {adx, q.nb}, dyv = {dy0, dy1};
+            f2 hu;
+            asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(hu) : "v"(an), "v"(dyv));
+            const float e0 = __builtin_fmaf(dx, hu.x, dy0 * __builtin_fmaf(q.nc, dy0, bdx));
+            const float e1 = __builtin_fmaf(dx, hu.y, dy1 * __builtin_fmaf(q.nc, dy1, bdx));
+#else
             const float e0 = __builtin_fmaf(dx, __builtin_fmaf(q.nb, dy0, adx), dy0 * __builtin_fmaf(q.nc, dy0, bdx));
             const float e1 = __builtin_fmaf(dx, __builtin_fmaf(q.nb, dy1, adx), dy1 * __builtin_fmaf(q.nc, dy1, bdx));
+#endif
 #else
             const float e0 = dns_exponent(q, dx, dy0);
             const float e1 = dns_exponent(q, dx, dy1);
