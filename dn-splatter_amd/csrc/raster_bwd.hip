@@ -115,6 +115,9 @@ constexpr int TILE = 16;
 #ifndef DNS_BWD_PAIR_STATE
 #define DNS_BWD_PAIR_STATE 1
 #endif
+#ifndef DNS_BWD_FLUSH_ALL
+#define DNS_BWD_FLUSH_ALL 1
+#endif
 #ifndef DNS_BWD_FOLD
 #define DNS_BWD_FOLD 1
 #endif
@@ -380,6 +383,9 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) hi = max(hi, __shfl_xor(hi, off, DNS_WAVE));
+    // the same number in every lane: say so, or everything derived from it (the batch counter, the forward's keep masks, the number
+    // of queued entries, the bucket's size and fold) is computed by vector instructions on 64 copies
+    hi = __builtin_amdgcn_readfirstlane(hi);
     hi = min(hi, range_end - 1);
     if (hi < range_start) return;
     __builtin_amdgcn_wave_barrier();
@@ -490,7 +496,11 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
             //    atomic instruction covering 4 complete 64-byte records.
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-#if DNS_BWD_TOUCH_FLAGS
+#if DNS_BWD_FLUSH_ALL
+                // every splat the group holds is flushed: with the forward's keep masks 99 % of them met a pixel, and finding the others
+                // (an OR over the 16 partial sums per splat) cost more than their rows of zeros
+                const uint64_t tmask = dns_ballot((half ? cmp_b : cmp_a) != 0x7fffffff) & gmask;
+#elif DNS_BWD_TOUCH_FLAGS
                 const uint64_t tmask = dns_ballot(half ? touched_b : touched_a) & gmask;
 #else
                 uint32_t any_bits = 0;      // OR of the 16 partial sums' bit patterns; << 1 drops the sign of a -0.0
