@@ -193,6 +193,8 @@ __device__ __forceinline__ float dns_exp2(float e) { return __builtin_amdgcn_exp
 // the mean when the mean is outside) is compared with ln(255 o) plus a safety margin that dominates the
 // fp32 rounding of the per-pixel evaluation, so a culled splat is one the per-pixel test would have
 // skipped for every pixel: skipping it changes no result bit.  NaNs compare false => keep.
+// The minimiser along an edge is located with v_rcp_f32 (1 ulp) instead of an IEEE division: an error of the location enters the
+// value at second order (~1e-13 relative), eleven orders below the margin, and saves ~16 instructions per test.
 __device__ __forceinline__ bool dns_cull_rect(float sx, float sy, float ca, float cb, float cc, float opac,
                                               float xl, float xh, float yl, float yh)
 {
@@ -203,12 +205,12 @@ __device__ __forceinline__ bool dns_cull_rect(float sx, float sy, float ca, floa
     if (X != 0.f || Y != 0.f) {
         float sxe = 3.0e38f, sye = 3.0e38f, pxe = 0.f, pye = 0.f;
         if (X != 0.f) {
-            const float dy = fminf(fmaxf(-cb * X / cc, dyl), dyh);
+            const float dy = fminf(fmaxf(-cb * X * __builtin_amdgcn_rcpf(cc), dyl), dyh);
             pxe = 0.5f * (ca * X * X + cc * dy * dy);
             sxe = pxe + cb * X * dy;
         }
         if (Y != 0.f) {
-            const float dx = fminf(fmaxf(-cb * Y / ca, dxl), dxh);
+            const float dx = fminf(fmaxf(-cb * Y * __builtin_amdgcn_rcpf(ca), dxl), dxh);
             pye = 0.5f * (ca * dx * dx + cc * Y * Y);
             sye = pye + cb * dx * Y;
         }
