@@ -189,16 +189,19 @@ def init_from_env(device_type: Optional[str] = None):
     if device_type is None:
         device_type = "cuda" if torch.cuda.is_available() else "cpu"
     if device_type == "cuda":
-        torch.cuda.set_device(local)
-        device = torch.device("cuda", local)
+        # DNSPLAT_SHARE_GPU=1: several ranks on one GPU (functional tests on a single-GPU box; RCCL refuses that, so the
+        # backend must be gloo, which stages device tensors through the host)
+        dev_index = local % torch.cuda.device_count() if os.environ.get("DNSPLAT_SHARE_GPU", "0") == "1" else local
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
     else:
         device = torch.device("cpu")
     force = os.environ.get("DNSPLAT_FORCE_DIST", "0") == "1"   # exercise the collective path with a single rank
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        backend = "nccl" if device_type == "cuda" else "gloo"
-        kw = {"device_id": device} if device_type == "cuda" else {}
+        backend = os.environ.get("DNSPLAT_DIST_BACKEND") or ("nccl" if device_type == "cuda" else "gloo")
+        kw = {"device_id": device} if backend == "nccl" else {}
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local, device
 
