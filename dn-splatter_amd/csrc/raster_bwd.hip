@@ -520,7 +520,8 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
                     if (mine && (lane % GROUP) / FLUSH_REC == sub) {
                         const int r = lane % FLUSH_REC;
                         flush[r][0] = make_float4(XY_SCALE * SEL(g_x), XY_SCALE * SEL(g_y), 0.5f * SEL(g_ca), SEL(g_cb));
-                        flush[r][1] = make_float4(0.5f * SEL(g_cc), SEL(g_o) / SEL(opac), SEL(g_ch[0]), SEL(g_ch[1]));
+                        // g_o / opacity through v_rcp_f32: 1 ulp on a sum whose order the atomics do not fix anyway, ten instructions less than an IEEE division
+                        flush[r][1] = make_float4(0.5f * SEL(g_cc), SEL(g_o) * __builtin_amdgcn_rcpf(SEL(opac)), SEL(g_ch[0]), SEL(g_ch[1]));
                         flush[r][2] = make_float4(SEL(g_ch[2]), SEL(g_ch[3]), SEL(g_ch[4]), SEL(g_ch[5]));
                         flush[r][3] = make_float4(SEL(g_ch[6]), SEL(g_ch[7]), -XY_SCALE * SEL(g_ax), -XY_SCALE * SEL(g_ay));
                     }
