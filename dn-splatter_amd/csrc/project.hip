@@ -291,8 +291,8 @@ __device__ __forceinline__ int sh_lds_index(int e)
 }
 
 // DNS_PROJ_NT: the coefficient rows are read once and their gradients written once per frame, as one coalesced stream per
-// workgroup: 1 = non-temporal loads (they skip the CU's vector L1), 2 = non-temporal stores, 3 = both.  Paired at C2:
-// project_fwd -7.7 % with the loads; project_bwd -4.9 % (loads), -0.6 % (stores), -10.5 % (both); C5 project_bwd -3.5 %.
+// workgroup: 1 = non-temporal loads (they skip the CU's vector L1), 2 = non-temporal stores, 3 = both.  Inside the C2 frame
+// (library variants interleaved in whole bench runs): project_fwd -10 % with 3, -6 % with 1; project_bwd +-0 with 3, -3 % with 1.
 #ifndef DNS_PROJ_NT
 #define DNS_PROJ_NT 3
 #endif
