@@ -69,17 +69,31 @@ SH_K = 16
 D_CH = 7
 
 
-def kernel_source_sha16():
-    """Hash of everything that determines the device code (csrc/*.hip, *.h, include/*.h, the build script)."""
+def _strip_comments(src: str) -> str:
+    """C / C++ source without comments and without blank space at line ends: what the compiler sees."""
+    import re
+
+    def keep_strings(m):
+        t = m.group(0)
+        return t if t[0] in "\"'" else " "
+    src = re.sub(r'//[^\n]*|/\*.*?\*/|"(?:\\.|[^"\\])*"|\'(?:\\.|[^\'\\])*\'', keep_strings, src, flags=re.S)
+    return "\n".join(l.rstrip() for l in src.splitlines() if l.strip())
+
+
+def kernel_source_sha16(root=None):
+    """Hash of everything that determines the device code (csrc/*.hip, *.h, include/*.h, the build script), comments and blank
+    lines left out: rewording a comment does not un-stamp the PMC traffic file."""
     import hashlib
 
+    root = root or ROOT
     h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "dn-splatter_amd", "csrc")
+    csrc = os.path.join(root, "dn-splatter_amd", "csrc")
     files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".sh")))
-    files += sorted(os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")))
+    files += sorted(os.path.join(root, "include", f) for f in os.listdir(os.path.join(root, "include")))
     for f in files:
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        text = open(f, "r", encoding="utf-8").read()
+        h.update((text if f.endswith(".sh") else _strip_comments(text)).encode())
     return h.hexdigest()[:16]
 
 

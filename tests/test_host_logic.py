@@ -215,3 +215,25 @@ def test_bench_gpus_n_starts_n_ranks():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"],
                          capture_output=True, text=True, timeout=300, env=env2, cwd=root)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
+
+
+def test_kernel_source_hash_ignores_comments_but_not_code(tmp_path):
+    """profiles/pmc_traffic.json is stamped with a hash of the kernel sources; rewording a comment must not un-stamp it, touching
+    code (or a string literal that only looks like a comment) must."""
+    import shutil
+    import bench
+
+    root = tmp_path / "tree"
+    shutil.copytree(os.path.join(ROOT, "dn-splatter_amd", "csrc"), root / "dn-splatter_amd" / "csrc",
+                    ignore=shutil.ignore_patterns("*.o", "*.so"))
+    shutil.copytree(os.path.join(ROOT, "include"), root / "include")
+    base = bench.kernel_source_sha16(str(root))
+    assert base == bench.kernel_source_sha16()
+    f = root / "dn-splatter_amd" / "csrc" / "postops.hip"
+    src = f.read_text()
+    f.write_text("// a new remark\n" + src.replace("\n", "   \n", 3) + "\n/* and a block\n one */\n")
+    assert bench.kernel_source_sha16(str(root)) == base
+    f.write_text(src + "\nstatic const char *dns_probe = \"// not a comment\";\n")
+    assert bench.kernel_source_sha16(str(root)) != base
+    f.write_text(src.replace("0.5f", "0.25f", 1))
+    assert bench.kernel_source_sha16(str(root)) != base
