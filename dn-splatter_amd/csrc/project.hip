@@ -296,6 +296,9 @@ __device__ __forceinline__ int sh_lds_index(int e)
 #ifndef DNS_PROJ_NT
 #define DNS_PROJ_NT 3
 #endif
+#ifndef DNS_PROJ_STAGED_REC
+#define DNS_PROJ_STAGED_REC 1
+#endif
 typedef float dns_v4f __attribute__((ext_vector_type(4)));
 
 template <int L>
@@ -379,7 +382,16 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
         __syncthreads();
     }
     if (PHASE == 2 && (g >= p.s.N || p.o.radii[g] <= 0)) continue;
-    if (g >= p.s.N) return;
+    // STAGED: the 64-byte records of the workgroup's Gaussians leave through LDS as one coalesced stream (the coefficient rows are
+    // dead by then) instead of four 16-byte pieces per lane at a 64-byte stride, which is 4x the write requests for the same lines.
+    // Every lane has to reach that store, so the per-Gaussian work sits in a do { } while (false) whose `break`s replace the early returns.
+    constexpr bool STAGED = DNS_PROJ_STAGED_REC && PHASE == 0 && L != SH_DIRECT && SH_STAGE_THREADS == DNS_WAVE;
+    float r[DNS_REC];
+#pragma unroll
+    for (int i = 0; i < DNS_REC; ++i) r[i] = 0.f;
+    bool phase2_done = false;
+    do {                                       // `break` = this Gaussian is finished (beyond N, culled, or its record is in r[])
+    if (g >= p.s.N) break;
     const Cam cam = load_cam(p.c.viewmat, p.c.K);
 
     float mean[3], quat[4], sc_raw[3], sc[3];
@@ -409,7 +421,8 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
         rec[REC_CH0 + 0] = fmaxf(col[0] + 0.5f, 0.f);
         rec[REC_CH0 + 1] = fmaxf(col[1] + 0.5f, 0.f);
         rec[REC_CH0 + 2] = fmaxf(col[2] + 0.5f, 0.f);
-        continue;
+        phase2_done = true;
+        break;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) quat[i] = p.s.quats[4 * g + i];
@@ -437,7 +450,7 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
         if (p.c.tight_tiles) p.o.tiles_bin[g] = 0;
         if (p.o.tile_boxes) reinterpret_cast<int2 *>(p.o.tile_boxes)[g] = make_int2(0, 0);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        rec4[0] = z4; rec4[1] = z4; rec4[2] = z4; rec4[3] = z4;
+        if (!STAGED) { rec4[0] = z4; rec4[1] = z4; rec4[2] = z4; rec4[3] = z4; }
         if (p.o.normals_world) {
             // the reference computes the normal for every Gaussian, visible or not (dn_model.py:544-558)
             float Rq[9], qn[4], inv, n[3], nrm, sgn; int k;
@@ -447,7 +460,7 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
             gaussian_normal(Rq, sc_raw, mean, campos, n, k, nrm, sgn);
             p.o.normals_world[3 * g] = n[0]; p.o.normals_world[3 * g + 1] = n[1]; p.o.normals_world[3 * g + 2] = n[2];
         }
-        return;
+        break;
     }
 
     const int tw = (p.c.width + p.c.tile_size - 1) / p.c.tile_size;
@@ -474,9 +487,6 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
     if (p.o.compensations) p.o.compensations[g] = st.compensation;
     p.o.tiles_per_gauss[g] = tiles_ref;
 
-    float r[DNS_REC];
-#pragma unroll
-    for (int i = 0; i < DNS_REC; ++i) r[i] = 0.f;
     r[REC_X] = st.mean2d[0]; r[REC_Y] = st.mean2d[1];
     r[REC_CA] = st.conic[0]; r[REC_CB] = st.conic[1]; r[REC_CC] = st.conic[2];
     r[REC_OPAC] = opac;
@@ -545,10 +555,41 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
                 rec_set_ch(r, ch + i, Mn[3 * i + 0] * n[0] + Mn[3 * i + 1] * n[1] + Mn[3 * i + 2] * n[2]);
         }
     }
-    rec4[0] = make_float4(r[0], r[1], r[2], r[3]);
-    rec4[1] = make_float4(r[4], r[5], r[6], r[7]);
-    rec4[2] = make_float4(r[8], r[9], r[10], r[11]);
-    rec4[3] = make_float4(r[12], r[13], r[14], r[15]);
+    if (!STAGED) {
+        rec4[0] = make_float4(r[0], r[1], r[2], r[3]);
+        rec4[1] = make_float4(r[4], r[5], r[6], r[7]);
+        rec4[2] = make_float4(r[8], r[9], r[10], r[11]);
+        rec4[3] = make_float4(r[12], r[13], r[14], r[15]);
+    }
+    } while (false);
+    if (PHASE == 2 && phase2_done) continue;
+    if constexpr (STAGED) {
+        // One wave per workgroup: LDS operations complete in program order, so every lane's coefficient reads are behind us.
+        // Lane l parks its record at a 20-float stride (conflict-free ds_write_b128), then the wave writes the block's records
+        // as 16-byte pieces in address order: piece q = 64 k + lane belongs to the record of lane q / 4.
+        __builtin_amdgcn_wave_barrier();
+        dns_v4f *park = reinterpret_cast<dns_v4f *>(sh_lds) + threadIdx.x * 5;
+        park[0] = dns_v4f{r[0], r[1], r[2], r[3]};
+        park[1] = dns_v4f{r[4], r[5], r[6], r[7]};
+        park[2] = dns_v4f{r[8], r[9], r[10], r[11]};
+        park[3] = dns_v4f{r[12], r[13], r[14], r[15]};
+        __builtin_amdgcn_wave_barrier();
+        const int g0 = vb * SH_STAGE_THREADS;
+        const int pieces = 4 * min(SH_STAGE_THREADS, p.s.N - g0);
+        dns_v4f *out = reinterpret_cast<dns_v4f *>(p.o.splats + (size_t)g0 * DNS_REC);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = k * SH_STAGE_THREADS + (int)threadIdx.x;
+            const dns_v4f v = reinterpret_cast<const dns_v4f *>(sh_lds)[(q >> 2) * 5 + (q & 3)];
+            if (q < pieces) {
+#if DNS_PROJ_NT & 2
+                __builtin_nontemporal_store(v, out + q);
+#else
+                out[q] = v;
+#endif
+            }
+        }
+    }
     }
 }
 
