@@ -115,6 +115,13 @@ constexpr int TILE = 16;
 #ifndef DNS_BWD_PAIR_STATE
 #define DNS_BWD_PAIR_STATE 1
 #endif
+// The per-pixel running state (T, S_a, S_b) moves from lane to lane THROUGH the pixel's LDS row instead of three v_mov_dpp: every
+// lane reads its pixel's whole row at the start of a step anyway (the state slots came along unused except in the first lane of
+// a DPP row), so the lane before only has to have written them — one ds_write_b96 per step, LDS operations of a wave are in order.
+// Needs the (S_a, T, S_b, bin_final) slot order and the folded layout's rule that every lane may park.
+#ifndef DNS_BWD_LDS_STATE
+#define DNS_BWD_LDS_STATE 1
+#endif
 #ifndef DNS_BWD_FLUSH_ALL
 #define DNS_BWD_FLUSH_ALL 1
 #endif
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
     // DNS_BWD_FOLD: the lane's array streams pixels [p_first, p_first + p_count) of the half tile (all of them unless folded)
     [[maybe_unused]] int p_first = 0, p_count = NPIX;
     [[maybe_unused]] bool folded = false;          // the bucket in the lanes is a folded (hence the last) one (wave-uniform)
-    float T_out = 0.f, SA_out = 0.f, SB_out = 0.f;
+    [[maybe_unused]] float T_out = 0.f, SA_out = 0.f, SB_out = 0.f;
 
     const int col = lane & 15;
     const bool col_used = col < REC_CH0 + D || col >= REC_ABSX;
@@ -627,7 +634,8 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
 #endif
                 int pcur = p & (NPIX - 1);
                 v4f c0, c1, cst;
-                row_issue(pix_base + pcur * 48, c0, c1, cst, pcur);
+                const uint32_t row_addr = pix_base + pcur * 48;        // LDS byte address of the pixel's row (read now, state written back at the end)
+                row_issue(row_addr, c0, c1, cst, pcur);
 #if DNS_BWD_COORD_TABLE
                 f2 pxy_next;
                 coord_issue(coord_base + (((p + 1) & (NPIX - 1)) << 3), pxy_next, pcur);
@@ -655,7 +663,11 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
                 const float al_a = CLAMP ? fminf((float)DNS_ALPHA_MAX, ov.x) : ov.x;
                 const float al_b = CLAMP ? fminf((float)DNS_ALPHA_MAX, ov.y) : ov.y;
                 // state arrives from the previous lane; lane 0 takes it from the pixel's LDS row
-#if DNS_BWD_PAIR_STATE
+#if DNS_BWD_LDS_STATE
+                // the pixel's state is what the row read of this step delivered: the lane before wrote it there at the end of its step
+                float T = cst.y;
+                float SA = cst.x, SB = cst.z;
+#elif DNS_BWD_PAIR_STATE
                 float T = dpp_wave_shr1(T_out, cst.y);
                 cst.x = dpp_wave_shr1(SA_out, cst.x);
                 cst.z = dpp_wave_shr1(SB_out, cst.z);
@@ -692,8 +704,8 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
                     f2 cva = zero2, cvb = zero2;
 #pragma unroll
                     for (int k = 0; k < D; ++k) {
-                        const f2 vk = (k & 1) ? __builtin_shufflevector(pp[k >> 1], pp[k >> 1], 1, 1)
-                                              : __builtin_shufflevector(pp[k >> 1], pp[k >> 1], 0, 0);
+                        [[maybe_unused]] const f2 vk = (k & 1) ? __builtin_shufflevector(pp[k >> 1], pp[k >> 1], 1, 1)
+                                                               : __builtin_shufflevector(pp[k >> 1], pp[k >> 1], 0, 0);
                         // one packed FMA with the cotangent broadcast by operand selection (hipcc would copy the
                         // broadcast pair into registers first, hence the inline instruction)
                         pk_fma_bcast(g_ch[k], fac, pp[k >> 1], k & 1);
@@ -751,9 +763,23 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
                     g_o = __builtin_elementwise_fma(ovm, va, g_o);             // / opacity at the flush
                     T = T2;
                 }
+#if DNS_BWD_LDS_STATE
+                {   // every lane hands its pixel on through the pixel's LDS row (the next lane reads the row anyway); lanes in an idle slot
+                    // must not write (their slot aliases a live pixel's row).  exec is narrowed and restored by hand: left to hipcc the
+                    // store sits behind a branch per step
+                    typedef float v3f __attribute__((ext_vector_type(3)));
+                    const v3f st = {SA, T, SB};
+                    const uint64_t act = dns_ballot(active);
+                    uint64_t saved;
+                    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b96 %2, %3 offset:32\n\ts_or_b64 exec, exec, %0"
+                                 : "=&s"(saved) : "s"(act), "v"(row_addr), "v"(st) : "memory", "scc");
+                }
+#else
                 T_out = T; SA_out = SA; SB_out = SB;
+#endif
                 // park the state of the pixel leaving the array for the next (nearer) bucket
-#if DNS_BWD_FOLD && DNS_BWD_PAIR_STATE
+#if DNS_BWD_LDS_STATE
+#elif DNS_BWD_FOLD && DNS_BWD_PAIR_STATE
                 if ((lane & 15) == 15 && active) {                        // to the next row / bucket; bin_final stays where it is
                     float *st = reinterpret_cast<float *>(&pix[pcur][2]);
                     typedef float v3f __attribute__((ext_vector_type(3)));

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
         // A kept splat nearly always hits some pixel of the strip, so the blend is unconditional (weight 0 for a skipped pair).
         while (todo) {
             const int t = __ffsll((unsigned long long)todo) - 1;
-            todo &= todo - 1;
+            asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(t));      // todo &= todo - 1 as one scalar instruction instead of three
             const float4 g0 = my[t][0];  // x y na nb
             const float4 g1 = my[t][1];  // nc opac ch0 ch1
             float4 g2, g3;
@@ -236,24 +236,25 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
 #endif
             const float alpha0 = fminf((float)DNS_ALPHA_MAX, g1.y * dns_exp2(e0));
             const float alpha1 = fminf((float)DNS_ALPHA_MAX, g1.y * dns_exp2(e1));
+            float ch[8];
+            ch[0] = g1.z; ch[1] = g1.w;
+            if (D > 2) { ch[2] = g2.x; ch[3] = g2.y; ch[4] = g2.z; ch[5] = g2.w; }
+            if (D > 6) { ch[6] = g3.x; ch[7] = g3.y; }
+            float nT0, nT1, v0, v1;
             const uint64_t valid0 = dns_ballot(e0 <= 0.f) & dns_ballot(alpha0 >= (float)DNS_ALPHA_MIN) & ~done0;
             const uint64_t valid1 = dns_ballot(e1 <= 0.f) & dns_ballot(alpha1 >= (float)DNS_ALPHA_MIN) & ~done1;
             // a skipped pair takes alpha = 0: its weight is 0 and T x (1 - 0) is T itself, so the blend and the transmittance update
             // below are unconditional.  Only a valid pair can lower T, so "T' <= 1e-4" alone says "this pair saturates the pixel".
             const float a0 = sel0(valid0, alpha0), a1 = sel0(valid1, alpha1);
-            float nT0 = T0 * (1.f - a0), nT1 = T1 * (1.f - a1);
+            nT0 = T0 * (1.f - a0); nT1 = T1 * (1.f - a1);
             const uint64_t stop0 = dns_ballot(nT0 <= (float)DNS_T_MIN), stop1 = dns_ballot(nT1 <= (float)DNS_T_MIN);
-            float v0 = a0 * T0, v1 = a1 * T1;
+            v0 = a0 * T0; v1 = a1 * T1;
             any0 |= valid0; any1 |= valid1;
             if (COUNT) {
                 n_walked += 1;
                 n_live += __popcll(~done0) + __popcll(~done1);            // pixels still open when the splat arrived
                 n_blend += __popcll(valid0 & ~stop0) + __popcll(valid1 & ~stop1);
             }
-            float ch[8];
-            ch[0] = g1.z; ch[1] = g1.w;
-            if (D > 2) { ch[2] = g2.x; ch[3] = g2.y; ch[4] = g2.z; ch[5] = g2.w; }
-            if (D > 6) { ch[6] = g3.x; ch[7] = g3.y; }
             // Some pixel saturates at this splat only about one splat in four: then the splat is NOT applied to it (weight 0), its T
             // stays, and the last index the backward has to visit for it is the one before (exactly: this entry must not be replayed).
             // The six selects sit behind a wave-uniform branch INSIDE one asm statement: written as a C++ `if`, hipcc copies every
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
             {
                 const int before = batch_start + t - 1;
                 float tmp;
+                [[maybe_unused]] uint64_t tmp_s;
                 asm volatile(
                     "s_or_b64 vcc, %9, %10\n\t"
                     "s_cmp_eq_u64 vcc, 0\n\t"
@@ -278,7 +280,16 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
                     : "+v"(v0), "+v"(v1), "+v"(nT0), "+v"(nT1), "+v"(last0), "+v"(last1), "+s"(done0), "+s"(done1), "=&v"(tmp)
                     : "s"(stop0), "s"(stop1), "v"(T0), "v"(T1), "s"(before)
                     : "vcc", "scc");
-                if ((done0 & done1) == ~0ull) todo = 0;      // all 128 pixels saturated (not a `break`: a second loop exit makes hipcc copy every accumulator at the latch)
+                // all 128 pixels saturated: nothing left to do (not a `break`: a second loop exit makes hipcc copy every accumulator at
+                // the latch).  As a data select on `todo`: written as an `if`, hipcc folds it into the loop condition as two
+                // compare-to-mask pairs, an and with them, one with exec and a branch on vcc — with the select (and s_bitset0 for
+                // todo &= todo - 1) the loop's exit is a plain scalar compare-and-branch: -7.2 % paired (C2), -6.2 % (C5).
+                // Measured and not kept: ten more scalar instructions taken out of the common path (per-lane alpha thresholds that
+                // turn +inf when a pixel saturates, the stop test as one v_min + v_cmp into vcc, done masks / all-done test /
+                // index only behind the branch): 7 instead of 17 scalar instructions per splat and no faster (-7.4 % vs -7.7 %) —
+                // it was the shape of the loop's exit, not the number of scalar instructions.
+                asm("s_and_b64 %1, %2, %3\n\ts_cmp_eq_u64 %1, -1\n\ts_cselect_b64 %0, 0, %0"
+                    : "+s"(todo), "=&s"(tmp_s) : "s"(done0), "s"(done1) : "scc");
             }
 #pragma unroll
             for (int k = 0; k < D; ++k) { acc0[k] += ch[k] * v0; acc1[k] += ch[k] * v1; }
