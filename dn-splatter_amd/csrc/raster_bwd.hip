@@ -12,11 +12,13 @@
 //     long and the launch's drain with them); lane l owns TWO SPLATS of the current bucket of 128 (lane 0 = back-most),
 //     carried as packed fp32 pairs, and keeps their 2 x 16 partial gradients in VGPRs;
 //   * the 128 pixels stream through the lanes, back to front: one pixel per lane per step, lane l one step behind lane
-//     l-1.  What travels with a pixel is only its running state (T, S_a, S_b) — three v_mov_dpp row_shr:1 per step — where
+//     l-1.  What travels with a pixel is only its running state (T, S_a, S_b), where
 //     S = sum_k buffer_k * v_k collapses the reference's per-channel `buffer` into one scalar per gradient group
 //     (v_alpha = T*(c.v) - S/(1-alpha));
-//   * the 64 lanes are four DPP ROWS of 16 linked through LDS: the last lane of a row parks the state in the pixel's LDS
-//     row, the first lane of the next row picks it up one step later — free, every lane reads its pixel's row anyway;
+//   * the state travels THROUGH THE PIXEL'S LDS ROW (DNS_BWD_LDS_STATE): every lane reads its pixel's whole row at the start of a
+//     step anyway, so the lane before only has to have written the three state words there at the end of its step — one
+//     ds_write_b96 per step, LDS operations of a wave complete in order.  (Until round 3: three v_mov_dpp row_shr:1 per step inside
+//     rows of 16 lanes, LDS only between the rows; -3.1 % paired.)  The switch of splats still happens in groups of 16 lanes;
 //   * per-pixel constants (upstream gradient, last contributing index) sit in a 6 KiB LDS table (128 rows of 48 bytes), read
 //     with conflict-free ds_read_b128 (48-byte stride over consecutive lanes), issued before and awaited after the
 //     row-independent arithmetic of the step;
