@@ -124,6 +124,17 @@ constexpr int TILE = 16;
 #ifndef DNS_BWD_LDS_STATE
 #define DNS_BWD_LDS_STATE 1
 #endif
+// measured and not kept: deciding "not an idle slot, sigma >= 0, alpha >= 1/255" ahead of the row wait and only "entry <= the pixel's
+// last index" behind it (two selects more, four compares earlier): +0.4 % at C2, +1.7 % at C5 — the step is bound by issue, not by
+// the latency of its tail
+#ifndef DNS_BWD_PREVALID
+#define DNS_BWD_PREVALID 0
+#endif
+// D < 8: the eighth cotangent slot of a pixel row is free and carries the x coordinate of the NEXT pixel's centre (the lane's pixel
+// of the next step), which saves that step an and, a convert and an add
+#ifndef DNS_BWD_PX_SLOT
+#define DNS_BWD_PX_SLOT 1
+#endif
 #ifndef DNS_BWD_FLUSH_ALL
 #define DNS_BWD_FLUSH_ALL 1
 #endif
@@ -382,6 +393,7 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
         coord[p] = make_float2((float)xi + 0.5f, (float)yi + 0.5f);
 #endif
         pix[p][0] = make_float4(v[0], v[1], v[2], v[3]);
+        if (DNS_BWD_PX_SLOT && D < 8) v[7] = (float)tile_x0 + 0.5f + (float)((p + 1) & 15);   // see DNS_BWD_PX_SLOT
         pix[p][1] = make_float4(v[4], v[5], v[6], v[7]);
 #if DNS_BWD_PAIR_STATE
         pix[p][2] = make_float4(sa, T_final, sb, __int_as_float(bin_final));
@@ -434,6 +446,7 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
     [[maybe_unused]] int p_first = 0, p_count = NPIX;
     [[maybe_unused]] bool folded = false;          // the bucket in the lanes is a folded (hence the last) one (wave-uniform)
     [[maybe_unused]] float T_out = 0.f, SA_out = 0.f, SB_out = 0.f;
+    [[maybe_unused]] float px_cur = 0.f;          // DNS_BWD_PX_SLOT: x of the centre of the pixel the lane works on in the coming step
 
     const int col = lane & 15;
     const bool col_used = col < REC_CH0 + D || col >= REC_ABSX;
@@ -596,6 +609,7 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
 #else
                 p = -(lane % GROUP);
 #endif
+                px_cur = fx0 + (float)(p & 15);
 #if DNS_BWD_COORD_TABLE
                 { const float2 c = coord[p & (NPIX - 1)]; pxy = f2{c.x, c.y}; }
 #endif
@@ -643,7 +657,7 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
                 coord_issue(coord_base + (((p + 1) & (NPIX - 1)) << 3), pxy_next, pcur);
                 const float px = pxy.x, py = pxy.y;
 #else
-                const float px = fx0 + (float)(pcur & 15), py = fy0 + (float)(pcur >> 4);
+                const float px = (DNS_BWD_PX_SLOT && D < 8) ? px_cur : fx0 + (float)(pcur & 15), py = fy0 + (float)(pcur >> 4);
 #endif
                 const f2 dx = sx - px, dy = sy - py;
                 // same fused-multiply-add sequence as dns_exponent(), two splats at a time (v_pk_*_f32)
@@ -655,6 +669,17 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
                 const f2 e = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(na, dx, nb * dy), (nc * dy) * dy);
 #endif
                 f2 vis = {dns_exp2(e.x), dns_exp2(e.y)};
+#if DNS_BWD_PREVALID
+                // everything of the pair's validity that does not need the pixel's row — the lane is not in an idle slot, sigma >= 0,
+                // alpha >= 1/255 — is decided while the row is on its way; behind the wait only "entry <= the pixel's last index" is left
+                const f2 ov = opac * vis;
+                const float al_a = CLAMP ? fminf((float)DNS_ALPHA_MAX, ov.x) : ov.x;
+                const float al_b = CLAMP ? fminf((float)DNS_ALPHA_MAX, ov.y) : ov.y;
+                const bool pre_a = active && e.x <= 0.f && al_a >= (float)DNS_ALPHA_MIN;
+                const bool pre_b = active && e.y <= 0.f && al_b >= (float)DNS_ALPHA_MIN;
+                f2 alpha_pre = {pre_a ? al_a : 0.f, pre_b ? al_b : 0.f};
+                row_wait(c0, c1, cst, alpha_pre);
+#else
 #if DNS_BWD_COORD_TABLE
                 row_wait(c0, c1, cst, pxy_next, vis);
                 pxy = pxy_next;
@@ -664,6 +689,7 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
                 const f2 ov = opac * vis;
                 const float al_a = CLAMP ? fminf((float)DNS_ALPHA_MAX, ov.x) : ov.x;
                 const float al_b = CLAMP ? fminf((float)DNS_ALPHA_MAX, ov.y) : ov.y;
+#endif
                 // state arrives from the previous lane; lane 0 takes it from the pixel's LDS row
 #if DNS_BWD_LDS_STATE
                 // the pixel's state is what the row read of this step delivered: the lane before wrote it there at the end of its step
@@ -680,15 +706,25 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
                 float SB = dpp_wave_shr1(SB_out, cst.z);
 #endif
                 const int bin_final = __float_as_int(cst.w);
+                if (DNS_BWD_PX_SLOT && D < 8) px_cur = c1.w;
+#if DNS_BWD_PREVALID
+                const bool valid_a = cmp_a <= bin_final && (COUNT || CLAMP ? pre_a : true);
+                const bool valid_b = cmp_b <= bin_final && (COUNT || CLAMP ? pre_b : true);
+#else
                 const bool valid_a = active && cmp_a <= bin_final && e.x <= 0.f && al_a >= (float)DNS_ALPHA_MIN;
                 const bool valid_b = active && cmp_b <= bin_final && e.y <= 0.f && al_b >= (float)DNS_ALPHA_MIN;
+#endif
                 if (COUNT) n_pairs += __popcll(dns_ballot(valid_a)) + __popcll(dns_ballot(valid_b));
                 {   // straight-line: an idle step costs the same as a busy one, but no phi copies at a join
 #if DNS_BWD_TOUCH_FLAGS
                     touched_a |= valid_a; touched_b |= valid_b;
 #endif
                     // an invalid pair takes alpha = 0 (=> 1/(1-alpha) = 1, weight 0: state and sums unchanged) and m = 0
+#if DNS_BWD_PREVALID
+                    const f2 alpha = {valid_a ? alpha_pre.x : 0.f, valid_b ? alpha_pre.y : 0.f};
+#else
                     const f2 alpha = {valid_a ? al_a : 0.f, valid_b ? al_b : 0.f};
+#endif
                     // opacity x vis where the pair is valid and alpha is not clamped, else 0: the weight of d/d(sigma)
                     // and, divided by the opacity again at the flush, of d/d(opacity)
                     const f2 ovm = CLAMP ? f2{(valid_a && ov.x <= (float)DNS_ALPHA_MAX) ? ov.x : 0.f,
@@ -769,12 +805,13 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
                 {   // every lane hands its pixel on through the pixel's LDS row (the next lane reads the row anyway); lanes in an idle slot
                     // must not write (their slot aliases a live pixel's row).  exec is narrowed and restored by hand: left to hipcc the
                     // store sits behind a branch per step
-                    typedef float v3f __attribute__((ext_vector_type(3)));
-                    const v3f st = {SA, T, SB};
+                    // two stores of loose registers (S_a and T, then S_b) rather than one ds_write_b96: the three values end the step in
+                    // the high halves of three different register pairs and a 96-bit operand would cost two copies
                     const uint64_t act = dns_ballot(active);
                     uint64_t saved;
-                    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b96 %2, %3 offset:32\n\ts_or_b64 exec, exec, %0"
-                                 : "=&s"(saved) : "s"(act), "v"(row_addr), "v"(st) : "memory", "scc");
+                    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write2_b32 %2, %3, %4 offset0:8 offset1:9\n\tds_write_b32 %2, %5 offset:40\n\t"
+                                 "s_or_b64 exec, exec, %0"
+                                 : "=&s"(saved) : "s"(act), "v"(row_addr), "v"(SA), "v"(T), "v"(SB) : "memory", "scc");
                 }
 #else
                 T_out = T; SA_out = SA; SB_out = SB;
