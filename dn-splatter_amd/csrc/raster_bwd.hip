@@ -16,8 +16,8 @@
 //     S = sum_k buffer_k * v_k collapses the reference's per-channel `buffer` into one scalar per gradient group
 //     (v_alpha = T*(c.v) - S/(1-alpha));
 //   * the state travels THROUGH THE PIXEL'S LDS ROW (DNS_BWD_LDS_STATE): every lane reads its pixel's whole row at the start of a
-//     step anyway, so the lane before only has to have written the three state words there at the end of its step — one
-//     ds_write_b96 per step, LDS operations of a wave complete in order.  (Until round 3: three v_mov_dpp row_shr:1 per step inside
+//     step anyway, so the lane before only has to have written the three state words there at the end of its step — a
+//     ds_write2_b32 + ds_write_b32 of the registers where they are, LDS operations of a wave complete in order.  (Until round 3: three v_mov_dpp row_shr:1 per step inside
 //     rows of 16 lanes, LDS only between the rows; -3.1 % paired.)  The switch of splats still happens in groups of 16 lanes;
 //   * per-pixel constants (upstream gradient, last contributing index) sit in a 6 KiB LDS table (128 rows of 48 bytes), read
 //     with conflict-free ds_read_b128 (48-byte stride over consecutive lanes), issued before and awaited after the
@@ -119,7 +119,7 @@ constexpr int TILE = 16;
 #endif
 // The per-pixel running state (T, S_a, S_b) moves from lane to lane THROUGH the pixel's LDS row instead of three v_mov_dpp: every
 // lane reads its pixel's whole row at the start of a step anyway (the state slots came along unused except in the first lane of
-// a DPP row), so the lane before only has to have written them — one ds_write_b96 per step, LDS operations of a wave are in order.
+// a DPP row), so the lane before only has to have written them — two small LDS stores per step, LDS operations of a wave are in order.
 // Needs the (S_a, T, S_b, bin_final) slot order and the folded layout's rule that every lane may park.
 #ifndef DNS_BWD_LDS_STATE
 #define DNS_BWD_LDS_STATE 1
