@@ -16,12 +16,12 @@ from .legacy import num_sh_bases, quat_to_rotmat, rasterize_gaussians  # noqa: F
 from .rendering import rasterization  # noqa: F401
 from .fused import render_dn  # noqa: F401
 from .model import Camera, DNSplatterRenderer, RendererConfig, get_viewmat  # noqa: F401
-from ._ops import set_bin_policy, set_grad_arena, set_sh_exchange  # noqa: F401
+from ._ops import set_bin_policy, set_deterministic, set_grad_arena, set_sh_exchange  # noqa: F401
 from . import dp  # noqa: F401
 from .densify import DensifyStats  # noqa: F401
 
 __all__ = [
     "rasterization", "rasterize_gaussians", "quat_to_rotmat", "num_sh_bases", "render_dn",
-    "DNSplatterRenderer", "RendererConfig", "Camera", "get_viewmat", "set_bin_policy", "set_grad_arena", "set_sh_exchange", "dp", "DensifyStats",
+    "DNSplatterRenderer", "RendererConfig", "Camera", "get_viewmat", "set_bin_policy", "set_deterministic", "set_grad_arena", "set_sh_exchange", "dp", "DensifyStats",
     "build_library", "load_library", "DnsplatError",
 ]

@@ -18,7 +18,7 @@ _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["DNSPLAT_LIB"]).resolve() if os.environ.get("DNSPLAT_LIB") else _PKG_DIR / "libdnsplat.so"
 CSRC_DIR = _PKG_DIR / "csrc"
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 RECORD_FLOATS = 16
 MAX_CHANNELS = 8
 
@@ -113,6 +113,14 @@ class RasterArgs(ctypes.Structure):
         ("dn", ctypes.POINTER(DnPost)),
         ("n_cameras", c_int32), ("keep_masks", c_void_p), ("keep_mask_stride", c_int64), ("pair_counters", c_void_p),
         ("saturation_flag", c_void_p), ("tile_ends", c_void_p), ("zero_fill", c_void_p), ("zero_fill_bytes", c_int64),
+        ("det_partials", c_void_p), ("det_capacity", c_int64),
+    ]
+
+
+class DetArgs(ctypes.Structure):
+    _fields_ = [
+        ("n_records", c_int32), ("capacity", c_int64), ("n_isects", c_void_p), ("flatten_ids", c_void_p),
+        ("partials", c_void_p), ("v_splats", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
     ]
 
 
@@ -134,7 +142,7 @@ EXPORTS = [
     "dnsplat_stamp",
     "dnsplat_project_fwd", "dnsplat_pack_splats",
     "dnsplat_bin_workspace_bytes", "dnsplat_bin_status_offset", "dnsplat_bin_prepare", "dnsplat_bin_emit_sort", "dnsplat_bin_isect_ids",
-    "dnsplat_raster_fwd", "dnsplat_raster_bwd",
+    "dnsplat_raster_fwd", "dnsplat_raster_bwd", "dnsplat_det_workspace_bytes", "dnsplat_det_reduce",
     "dnsplat_dn_depth_normals", "dnsplat_camera_prepare", "dnsplat_densify_stats", "dnsplat_densify_classify",
     "dnsplat_densify_split", "dnsplat_dn_loss", "dnsplat_sh_grads_from_factors", "dnsplat_sh_factors",
     "dnsplat_project_bwd",
@@ -184,6 +192,9 @@ def lib() -> ctypes.CDLL:
                                             c_void_p]
         L.dnsplat_raster_fwd.argtypes = [ctypes.POINTER(RasterArgs), c_void_p]
         L.dnsplat_raster_bwd.argtypes = [ctypes.POINTER(RasterArgs), c_void_p]
+        L.dnsplat_det_workspace_bytes.restype = c_size_t
+        L.dnsplat_det_workspace_bytes.argtypes = [c_int64]
+        L.dnsplat_det_reduce.argtypes = [ctypes.POINTER(DetArgs), c_void_p]
         L.dnsplat_dn_depth_normals.argtypes = [c_int32, c_int32, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p]
         L.dnsplat_densify_stats.argtypes = [c_int32, c_void_p, c_void_p, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]
@@ -194,7 +205,7 @@ def lib() -> ctypes.CDLL:
                                              c_void_p, c_int32, c_void_p]
         L.dnsplat_sh_factors.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         for name in EXPORTS:
-            if name not in ("dnsplat_strerror", "dnsplat_bin_workspace_bytes", "dnsplat_bin_status_offset"):
+            if name not in ("dnsplat_strerror", "dnsplat_bin_workspace_bytes", "dnsplat_bin_status_offset", "dnsplat_det_workspace_bytes"):
                 getattr(L, name).restype = ctypes.c_int
         if L.dnsplat_abi_version() != ABI_VERSION:
             raise DnsplatError(f"libdnsplat ABI {L.dnsplat_abi_version()} != binding {ABI_VERSION}; rebuild")

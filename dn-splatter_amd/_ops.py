@@ -132,10 +132,14 @@ class _Buffers:
             self.ring[key] = ring
         i = ring["next"]
         ring["next"] = (i + 1) % self.RING
-        # the slot about to be reused must have been looked at: at most RING - 1 frames are ever unverified
+        slot = ring["mem"][i:i + 1]
+        # the slot about to be reused must have been looked at — whoever owns it, also when counts were resolved out of order
+        # through Binning.n_isects — and at most RING - 1 frames are ever unverified
+        for p in [p for p in ring["pending"] if p.slot.data_ptr() == slot.data_ptr()]:
+            p.resolve()
         while len(ring["pending"]) >= self.RING - 1:
             ring["pending"][0].resolve()
-        return ring, ring["mem"][i:i + 1], ring["events"][i]
+        return ring, slot, ring["events"][i]
 
 
 BUFFERS = _Buffers()
@@ -199,12 +203,14 @@ class _PendingCount:
     def __init__(self, ring, slot, event, capacity, key):
         self.ring, self.slot, self.event, self.capacity, self.key = ring, slot, event, capacity, key
         self.n: Optional[int] = None
+        self.overflowed = False
 
     def ready(self) -> bool:
         return self.n is not None or self.event.query()
 
     def resolve(self) -> int:
-        """Waits for the count if it has not arrived yet, verifies it, returns it.  Raises on overflow."""
+        """Waits for the count if it has not arrived yet, verifies it, returns it.  Raises on overflow — on EVERY call for a frame
+        that overflowed (its lists are truncated: nobody may read its count or its list as if it were complete)."""
         if self.n is None:
             self.event.synchronize()
             self.n = int(self.slot.item())
@@ -212,27 +218,54 @@ class _PendingCount:
                 self.ring["pending"].remove(self)
             hint = BUFFERS.capacity_hint.get(self.key, 0)
             BUFFERS.capacity_hint[self.key] = max(hint, int(self.n * 1.25) + 4096)
-            if self.n > self.capacity:
-                raise _lib.DnsplatError(
-                    f"tile binning: {self.n} intersections exceed the capacity {self.capacity} guessed from earlier frames "
-                    "(bin policy 'deferred' verifies the count after the fact): the outputs and gradients of that frame are "
-                    "invalid. The capacity has been enlarged; run the step again (or use set_bin_policy('capacity'), which "
-                    "repairs an overflow itself at the price of one host wait per frame)")
+            self.overflowed = self.n > self.capacity
+        if self.overflowed:
+            raise _lib.DnsplatError(
+                f"tile binning: {self.n} intersections exceed the capacity {self.capacity} guessed from earlier frames "
+                "(bin policy 'deferred' verifies the count after the fact): the outputs and gradients of that frame are "
+                "invalid. The capacity has been enlarged; run the step again (or use set_bin_policy('capacity'), which "
+                "repairs an overflow itself at the price of one host wait per frame)")
         return self.n
 
 
 def static_overflow(device, stream=None) -> Optional[int]:
     """ "static" bin policy: the largest intersection count a frame binned on ``stream`` (default: the current one) produced, if
-    it exceeded the capacity the frames of that size ran with (their lists were then truncated), else None.  Synchronises."""
+    it exceeded the capacity the frames of that size ran with (their lists were then truncated), else None.  Synchronises.
+    An overflow is REPORTED ONCE and repaired for whoever captures next: the capacity guess of that frame size is raised to
+    1.25 x the count seen, the sticky device maximum and the recorded static capacity are cleared — a re-capture after the error
+    gets buffers that fit (before, a re-capture reused the same guess and overflowed again)."""
     skey = (device, (torch.cuda.current_stream(device) if stream is None else stream).cuda_stream)
     worst = None
-    for k, t in BUFFERS.n_max.items():
+    for k, t in list(BUFFERS.n_max.items()):
         if k[:2] != skey:
             continue
         n = int(t.item())
         if n > BUFFERS.static_cap.get(k, 0):
             worst = n if worst is None else max(worst, n)
+            hkey = k[2:]                                   # (device, N, width, height): the key of the capacity guesses
+            BUFFERS.capacity_hint[hkey] = max(BUFFERS.capacity_hint.get(hkey, 0), int(n * 1.25) + 4096)
+            t.zero_()
+            BUFFERS.static_cap.pop(k, None)
     return worst
+
+
+def forget_capacity_guesses(device=None) -> None:
+    """Drops what the bin policies remember about earlier frames (capacity guesses, static capacities, running maxima) — for
+    ``device`` or for all: the Gaussian set changed size (densify.after_refinement), the next frame of a size starts in "sync"."""
+    for d in (BUFFERS.capacity_hint, BUFFERS.static_cap, BUFFERS.n_max):
+        for k in [k for k in d if device is None or k[0] == device]:
+            del d[k]
+
+
+def forget_static(device, stream) -> None:
+    """Drops the "static" policy's per-stream records (running maxima, capacities) of ``stream``: called when the GraphedStep that
+    owned the stream is discarded, so that they do not accumulate across re-captures."""
+    skey = (device, stream.cuda_stream)
+    for d in (BUFFERS.n_max, BUFFERS.static_cap):
+        for k in [k for k in d if k[:2] == skey]:
+            del d[k]
+    for d in (BUFFERS.ws, BUFFERS.pinned, BUFFERS.ring, BUFFERS.side):
+        d.pop(skey, None)
 
 
 def verify_pending_counts(device, block: bool = False) -> None:
@@ -388,19 +421,14 @@ class _ProjectFn(torch.autograd.Function):
         if v_splats is None:
             v_splats = torch.zeros(C * N, RECORD_FLOATS, dtype=torch.float32, device=dev)
         v_splats = v_splats.contiguous()
-        # The compositing backward leaves means2d's gradient in columns 0-1 of the gradient records and hands autograd no
-        # separate tensor for it (_hand_over_means2d_grad).  A tensor arriving here is therefore something ELSE the caller hung
-        # on info["means2d"] (or the legacy pass fed with non-detached xys): the kernel takes g.v_means2d INSTEAD of the
-        # record's columns, so the two are added here.
+        # The screen-space gradient reaches this node in two parts that are ALWAYS added: columns 0-1 of the gradient records (what
+        # the compositing backward accumulated and did not hand to autograd separately, _hand_over_means2d_grad) and whatever
+        # autograd delivers for means2d itself (terms the caller hung on info["means2d"], the legacy pass fed with non-detached
+        # xys, or — when means2d was not retained — the compositing term, whose record columns were then cleared).  The kernel
+        # takes g.v_means2d INSTEAD of the record's columns, hence the sum here.  No state outside the autograd graph is involved:
+        # records summed over two compositing calls, or a backward that stops at means2d, cannot be double counted.
         v_m2d = None
-        via_autograd = v_splats.data_ptr() in _M2D_VIA_AUTOGRAD
-        _M2D_VIA_AUTOGRAD.discard(v_splats.data_ptr())
-        if v_means2d is not None and via_autograd:
-            # means2d was not retained: the compositing backward handed autograd the records' columns 0-1 themselves (a view), so
-            # what arrives is that view — nothing to do, the kernel reads the records — or its sum with the caller's extra terms
-            if not (v_means2d.data_ptr() == v_splats.data_ptr() and v_means2d.stride(-2) == RECORD_FLOATS):
-                v_m2d = v_means2d.reshape(C, N, 2).contiguous()
-        elif v_means2d is not None:
+        if v_means2d is not None:
             v_m2d = (v_means2d.reshape(C * N, 2) + v_splats[:, 0:2]).reshape(C, N, 2).contiguous()
         v_dep = v_depths.reshape(C, N).contiguous() if v_depths is not None else None
         v_con = v_conics.reshape(C, N, 3).contiguous() if v_conics is not None else None
@@ -507,7 +535,7 @@ class Binning:
     @property
     def n_isects(self) -> int:
         if self.pending is not None:
-            self._n = self.pending.resolve()
+            self._n = self.pending.resolve()      # raises (every time) if that frame overflowed: self.pending stays
             self.pending = None
         if self._n is None:                      # "static" policy: nobody has asked yet — read the device scalar (synchronises)
             self._n = int(self._n_dev.item())
@@ -601,7 +629,7 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
         _lib.run("dnsplat_bin_emit_sort", _lib.lib().dnsplat_bin_emit_sort, ctypes.byref(args), _stream())
         pend = _PendingCount(ring, slot, ev, capacity, key)
         ring["pending"].append(pend)
-        b = Binning(flatten_ids, tile_offsets, None, tw, th, n_cameras, pending=pend, tile_ends=tile_ends)
+        b = Binning(flatten_ids, tile_offsets, None, tw, th, n_cameras, pending=pend, tile_ends=tile_ends, n_dev=n_dev)
         if after_emit is not None:
             after_emit(b)
         return b
@@ -613,7 +641,7 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
         ev = torch.cuda.Event()
         ev.record()
         _lib.run("dnsplat_bin_emit_sort", _lib.lib().dnsplat_bin_emit_sort, ctypes.byref(args), _stream())
-        b = Binning(flatten_ids, tile_offsets, -1, tw, th, n_cameras, tile_ends=tile_ends)
+        b = Binning(flatten_ids, tile_offsets, -1, tw, th, n_cameras, tile_ends=tile_ends, n_dev=n_dev)
         if after_emit is not None:
             after_emit(b)
         ev.synchronize()  # waits for the (early) depth sort only; compositing keeps running
@@ -637,7 +665,7 @@ def bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tiles: Tensor, wid
     if ws1.data_ptr() != ws0.data_ptr():
         _lib.run("dnsplat_bin_prepare", _lib.lib().dnsplat_bin_prepare, ctypes.byref(args), _stream())
     _lib.run("dnsplat_bin_emit_sort", _lib.lib().dnsplat_bin_emit_sort, ctypes.byref(args), _stream())
-    b = Binning(flatten_ids, tile_offsets, n, tw, th, n_cameras, tile_ends=tile_ends)
+    b = Binning(flatten_ids, tile_offsets, n, tw, th, n_cameras, tile_ends=tile_ends, n_dev=n_dev)
     if after_emit is not None:
         after_emit(b)
     return b
@@ -702,8 +730,39 @@ def isect_ids(b: Binning, depths: Tensor) -> Tensor:
 
 
 
-# data_ptr of the gradient records whose columns 0-1 were ALSO returned to autograd as means2d's gradient (see below)
-_M2D_VIA_AUTOGRAD = set()
+# Deterministic gradient scatter (DNSPLAT_DETERMINISTIC=1 / set_deterministic(True); a test / debug mode, about 3x the backward's time
+# and 128 B per list entry of scratch): the compositing backward stores the row of every (half tile, splat) in its own slot
+# (dnsplat_raster_args.det_partials) and dnsplat_det_reduce adds each Gaussian's rows up in list order in float64 — the same bits in
+# every run, where the default path's fp32 atomics land in arrival order ("atomics-vs-deterministic-reduction mode").
+DETERMINISTIC = {"on": os.environ.get("DNSPLAT_DETERMINISTIC", "0") == "1"}
+
+
+def set_deterministic(on: bool) -> None:
+    DETERMINISTIC["on"] = bool(on)
+
+
+def _det_begin(a: "RasterArgs", b: "Binning", dev):
+    """Deterministic mode: the zero-filled slot buffer for this launch (None when the mode is off)."""
+    if not DETERMINISTIC["on"]:
+        return None
+    cap = max(int(b.flatten_ids.numel()), 1)
+    part = torch.zeros(2, cap, RECORD_FLOATS, dtype=torch.float32, device=dev)
+    a.det_partials, a.det_capacity = _ptr(part), cap
+    return part
+
+
+def _det_finish(part: Optional[Tensor], b: "Binning", v_splats: Tensor) -> None:
+    if part is None:
+        return
+    dev = v_splats.device
+    cap = part.shape[1]
+    n_dev = b._n_dev if b._n_dev is not None else torch.tensor([b.n_isects], dtype=torch.int64, device=dev)
+    ws = torch.empty(_lib.lib().dnsplat_det_workspace_bytes(cap), dtype=torch.uint8, device=dev)
+    d = _lib.DetArgs()
+    d.n_records, d.capacity = v_splats.shape[0], cap
+    d.n_isects, d.flatten_ids, d.partials, d.v_splats = _ptr(n_dev), _ptr(b.flatten_ids), _ptr(part), _ptr(v_splats)
+    d.workspace, d.workspace_bytes = _ptr(ws), ws.numel()
+    _lib.run("dnsplat_det_reduce", _lib.lib().dnsplat_det_reduce, ctypes.byref(d), _stream())
 
 
 def _hand_over_means2d_grad(means2d: Tensor, v_splats: Tensor):
@@ -712,18 +771,17 @@ def _hand_over_means2d_grad(means2d: Tensor, v_splats: Tensor):
     retain_grad hook CLONE that strided view (a 13 us copy kernel per frame at 1 M Gaussians) although the projection
     backward reads the same numbers from the records anyway.  So with retain_grad() autograd gets no separate gradient for
     means2d (None: the records carry it) and the view itself is stored in ``.grad`` — added to whatever is already there, as
-    the hook would.  WITHOUT retain_grad() the view is returned to autograd as usual, so that torch.autograd.grad(loss,
-    info["means2d"]) and hooks registered on the tensor see the rasterizer's term; the projection backward is told (through
-    _M2D_VIA_AUTOGRAD) that what it receives for means2d already contains the records' columns.
+    the hook would.  WITHOUT retain_grad() the term goes back through autograd as usual, so that torch.autograd.grad(loss,
+    info["means2d"]) and hooks registered on the tensor see it: a copy of the columns is returned and the columns themselves
+    are cleared, because the projection backward always ADDS what autograd delivers for means2d to the records' columns
+    (_ProjectFn.backward) — each term travels exactly one way, whatever else feeds the two tensors.
     Returns the gradient to hand to autograd for ``means2d``."""
     view = v_splats[:, 0:2].view(means2d.shape)
-    # every projection backward is preceded by the compositing backward that produced ITS gradient records: the entry for this
-    # address is rewritten here each time, so a stale one (a backward that stopped at means2d) can never be mistaken for ours
-    _M2D_VIA_AUTOGRAD.discard(v_splats.data_ptr())
     if not means2d.retains_grad:
         if means2d.requires_grad:
-            _M2D_VIA_AUTOGRAD.add(v_splats.data_ptr())
-            return view
+            g = view.clone()
+            v_splats[:, 0:2].zero_()
+            return g
         return None
     means2d.grad = view if means2d.grad is None else means2d.grad + view
     return None
@@ -762,6 +820,7 @@ class _RasterFn(torch.autograd.Function):
             holder["binning"] = b
         ctx.save_for_backward(means2d, splats, b.flatten_ids, b.tile_offsets, render, alphas, last_ids)
         ctx.bg = bg
+        ctx.binning = b
         ctx.cfg = (width, height, tile_size, D, ed_channel, xy_split, absgrad, C)
         ctx.set_materialize_grads(False)
         return render, alphas
@@ -789,7 +848,9 @@ class _RasterFn(torch.autograd.Function):
         a.v_render, a.v_alphas = _ptr(v_render), _ptr(v_alphas)
         a.xy_split = xy_split
         a.v_splats = _ptr(v_splats)
+        det = _det_begin(a, ctx.binning, dev)
         _lib.run("dnsplat_raster_bwd", _lib.lib().dnsplat_raster_bwd, ctypes.byref(a), _stream())
+        _det_finish(det, ctx.binning, v_splats)
         if absgrad:
             # gsplat contract (dn_model.py:512, consumed by nerfstudio after_train via self.xys.absgrad)
             means2d.absgrad = v_splats[:, 14:16].reshape(means2d.shape)
@@ -967,7 +1028,9 @@ class _RasterDnFn(torch.autograd.Function):
             a.keep_masks, a.keep_mask_stride = _ptr(ctx.keep["masks"]), ctx.keep["stride"]
         # "no visible opacity above the alpha cap in this frame" (written by the projection): lets the kernel drop the clamp handling
         a.saturation_flag = _ptr(ctx.saturation_flag) if SATURATION_FLAG else None
+        det = _det_begin(a, ctx.binning, dev) if counters is None else None
         _lib.run("dnsplat_raster_bwd", _lib.lib().dnsplat_raster_bwd, ctypes.byref(a), _stream())
+        _det_finish(det, ctx.binning, v_splats)
         if absgrad:
             means2d.absgrad = v_splats[:, 14:16].reshape(means2d.shape)
         return (_hand_over_means2d_grad(means2d, v_splats), v_splats) + none
@@ -1008,6 +1071,8 @@ def camera_prepare(c2w: Tensor, fx: float, fy: float, cx: float, cy: float, with
              _ptr(nf) if with_normal_frame else None, _ptr(flag), 1 + n_depth_max, _stream())
     if with_flag and n_depth_max:
         DEPTH_MAX_OF[flag.data_ptr()] = zeros[1:1 + n_depth_max]
+        while len(DEPTH_MAX_OF) > 16:          # prepared cameras nobody rendered (an exception in between): oldest first
+            DEPTH_MAX_OF.pop(next(iter(DEPTH_MAX_OF)))
     res = (viewmat.view(4, 4), K.view(3, 3), (nf if with_normal_frame else None))
     return res + (flag,) if with_flag else res
 

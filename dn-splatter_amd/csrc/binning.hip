@@ -736,7 +736,103 @@ int tile_bits(int n_tiles)
     return bits;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Deterministic gradient reduction (dnsplat_det_reduce): the sorted list is re-sorted by record id (stable, so a record's entries
+// stay in list order = ascending tile id) and every record's rows are added up by ONE group of 16 lanes in that order, in double.
+struct DetWs {
+    uint32_t *key_a, *key_b, *val_a, *val_b;   // [cap]
+    uint32_t *table;                           // [256 * nb]
+    uint32_t *totals;                          // [256]
+    uint32_t *count;                           // [1]
+    int nb;
+    size_t bytes;
+};
+
+DetWs det_carve(void *ws, int64_t cap)
+{
+    DetWs d{};
+    d.nb = (int)((cap + RS_THREADS * RS_ITEMS_N - 1) / (RS_THREADS * RS_ITEMS_N));
+    if (d.nb < 1) d.nb = 1;
+    size_t off = 0;
+    char *base = (char *)ws;
+    auto take = [&](size_t elems) {
+        uint32_t *p = (uint32_t *)(base + off);
+        off += align_up(elems * sizeof(uint32_t), 256);
+        return p;
+    };
+    const size_t c = (size_t)(cap > 0 ? cap : 1);
+    d.key_a = take(c); d.key_b = take(c); d.val_a = take(c); d.val_b = take(c);
+    d.table = take((size_t)RS_DIGITS * d.nb);
+    d.totals = take(RS_DIGITS);
+    d.count = take(1);
+    d.bytes = off;
+    return d;
+}
+
+__global__ __launch_bounds__(256) void det_iota_kernel(const int64_t *__restrict__ n_isects, uint32_t cap, uint32_t *__restrict__ vals,
+                                                       uint32_t *__restrict__ count)
+{
+    const uint32_t n = (uint32_t)min((int64_t)cap, max((int64_t)0, *n_isects));
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count = n;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) vals[i] = i;
+}
+
+// 16 lanes per entry of the record-sorted list (lane & 15 = column of the gradient record); the group whose entry is the first of
+// its record adds up the record's rows: for each of its entries in list order, half 0 then half 1 — a fixed order, in double.
+__global__ __launch_bounds__(256) void det_reduce_kernel(const uint32_t *__restrict__ count, const uint32_t *__restrict__ keys,
+                                                         const uint32_t *__restrict__ vals, const float *__restrict__ partials,
+                                                         size_t cap, int n_records, float *__restrict__ v_splats)
+{
+    const uint32_t n = *count;
+    const uint32_t i = (uint32_t)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+    const int col = threadIdx.x & 15;
+    if (i >= n) return;
+    const uint32_t g = keys[i];
+    if ((i > 0 && keys[i - 1] == g) || g >= (uint32_t)n_records) return;
+    double acc = 0.0;
+    for (uint32_t j = i; j < n && keys[j] == g; ++j) {
+        const size_t e = vals[j];
+        acc += (double)partials[e * DNS_REC + col];
+        acc += (double)partials[(cap + e) * DNS_REC + col];
+    }
+    v_splats[(size_t)g * DNS_REC + col] = (float)acc;
+}
+
 }  // namespace
+
+extern "C" size_t dnsplat_det_workspace_bytes(int64_t capacity)
+{
+    if (capacity < 0) return 0;
+    return det_carve(nullptr, capacity).bytes;
+}
+
+extern "C" int dnsplat_det_reduce(const dnsplat_det_args *a, dnsplat_stream_t stream_)
+{
+    if (!a || a->n_records < 0 || a->capacity < 0 || a->capacity > 0x7fffffffLL) return DNSPLAT_ERR_INVALID_ARG;
+    if (a->capacity == 0 || a->n_records == 0) return DNSPLAT_OK;
+    if (!a->n_isects || !a->flatten_ids || !a->partials || !a->v_splats || !a->workspace) return DNSPLAT_ERR_INVALID_ARG;
+    if (a->workspace_bytes < det_carve(nullptr, a->capacity).bytes) return DNSPLAT_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const DetWs w = det_carve(a->workspace, a->capacity);
+    const uint32_t cap = (uint32_t)a->capacity;
+    hipLaunchKernelGGL(det_iota_kernel, dim3(1024), dim3(256), 0, stream, a->n_isects, cap, w.val_a, w.count);
+    int bits = 1;
+    while ((1ll << bits) < (long long)a->n_records) ++bits;
+    const int passes = (bits + 7) / 8;
+    const uint32_t *ka = reinterpret_cast<const uint32_t *>(a->flatten_ids);
+    uint32_t *va = w.val_a, *kb = w.key_a, *vb = w.val_b;
+    for (int pass = 0; pass < passes; ++pass) {
+        radix_pass<uint32_t, RS_ITEMS_N>(stream, ka, va, kb, vb, w.count, cap, 8 * pass, 8, w.table, w.totals, w.nb);
+        ka = kb; va = vb;
+        kb = (kb == w.key_a) ? w.key_b : w.key_a;
+        vb = (vb == w.val_b) ? w.val_a : w.val_b;
+    }
+    const size_t groups = (size_t)cap;
+    hipLaunchKernelGGL(det_reduce_kernel, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0, stream, w.count, ka, va, a->partials,
+                       (size_t)a->capacity, a->n_records, a->v_splats);
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}
 
 extern "C" size_t dnsplat_bin_workspace_bytes(int32_t N, int64_t isect_capacity, int32_t n_tiles)
 {
@@ -826,6 +922,9 @@ extern "C" int dnsplat_bin_emit_sort(const dnsplat_bin_args *a, dnsplat_stream_t
     const uint32_t cap = (uint32_t)a->isect_capacity;
     if (a->N == 0 || cap == 0) {
         if (hipMemsetAsync(a->tile_offsets, 0, sizeof(int32_t) * (size_t)(n_tiles + 1), stream) != hipSuccess)
+            return DNSPLAT_ERR_LAUNCH;
+        // every list is [0, 0): the compositing kernels of the fused path read tile_ends, which must not stay uninitialised
+        if (a->tile_ends && hipMemsetAsync(a->tile_ends, 0, sizeof(int32_t) * (size_t)n_tiles, stream) != hipSuccess)
             return DNSPLAT_ERR_LAUNCH;
         return DNSPLAT_OK;
     }

@@ -184,6 +184,10 @@ struct BwdArgs {
     const float *__restrict__ v_alphas;
     int xy_split;
     float *__restrict__ v_splats;
+    // DET instantiations (dnsplat_raster_args.det_partials): the record of (half tile `part`, list entry idx) is STORED at
+    // det + (part * det_cap + idx) * 16 instead of being added atomically to v_splats[gaussian]
+    float *__restrict__ det;
+    long long det_cap;
     // fused dn-splatter epilogue (DN instantiation only): cotangents of rgb / filled depth / normal / accumulation
     const float *__restrict__ bg_rgb;
     const float *__restrict__ dn_v_rgb;
@@ -272,8 +276,13 @@ __device__ __forceinline__ float dpp_wave_shr1(float from_prev, float lane0_valu
 // the projection reports in a device word (dnsplat_proj_out.saturation_flag).  Nothing on the host knows the answer without a
 // sync, so both instantiations are launched and the one that does not apply leaves at its first instruction (a few us).  Two loop
 // bodies inside ONE kernel were tried in round 1 / 2: 154 VGPRs, or 36 spilled values under the 128-VGPR pin (+28 %).
-template <int D, int SPLIT, bool DN, bool COUNT = false, bool MASKS = false, bool CLAMP_LOOP = true>
-__global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) void raster_bwd_kernel(BwdArgs a)
+// DET: deterministic gradient scatter (DNSPLAT_DETERMINISTIC, a test / debug mode).  The sums of a (half tile, splat) are the same
+// numbers in every run — they are formed in registers in stream order — but the order in which the atomic rows of the ~14 tiles x 2
+// halves a Gaussian touches reach its gradient record is not, and fp32 addition does not commute with that.  DET stores every
+// row in its own slot of a buffer indexed by (half, sorted list index) instead; dnsplat_det_reduce adds up each Gaussian's slots in
+// list order.  The last bucket is not folded (a folded splat sits in 2 or 4 lanes, i.e. would have 2 or 4 rows for one slot).
+template <int D, int SPLIT, bool DN, bool COUNT = false, bool MASKS = false, bool CLAMP_LOOP = true, bool DET = false>
+__global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT && !DET) void raster_bwd_kernel(BwdArgs a)
 {
     if (a.sat_flag && (*a.sat_flag != 0u) != CLAMP_LOOP) return;
     __shared__ float4 pix[NPIX][3];            // [p][0..1] = v_k, [p][2] = (S_a, T, S_b, bin_final) (DNS_BWD_PAIR_STATE) or (T, S_a, S_b, bin_final)
@@ -493,7 +502,7 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
         const bool last = take == 0;          // nothing new: only drain what is still in the lanes
 #if DNS_BWD_FOLD
         // take < BUCKET only when the list is exhausted: this is the unit's last bucket.  fold = number of independent arrays
-        const int fold = (take > 0 && take <= BUCKET / 4) ? 4 : (take > 0 && take <= BUCKET / 2) ? 2 : 1;
+        const int fold = DET ? 1 : (take > 0 && take <= BUCKET / 4) ? 4 : (take > 0 && take <= BUCKET / 2) ? 2 : 1;
         const int fold_lanes = DNS_WAVE / fold;                 // lanes per array
         // after a folded bucket every lane is finished when its steps end: the closing pass only flushes (all four groups)
         const bool flush_only = last && folded;
@@ -552,9 +561,12 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
                     for (int j = 0; j < FLUSH_REC / 4; ++j) {
                         const int rec = j * 4 + (lane >> 4);                         // record within the round
                         const int src = GROUP * grp + FLUSH_REC * sub + rec;         // the lane that owns that splat
-                        const int rgid = __shfl(gid, src, DNS_WAVE);
+                        // DET: the row's own slot, keyed by the splat's list index (every (half tile, entry) is flushed exactly once)
+                        const int rgid = __shfl(DET ? (half ? cmp_b : cmp_a) : gid, src, DNS_WAVE);
                         const float val = fl[j * 64 + lane];
-                        if (((tmask >> src) & 1) && col_used) unsafeAtomicAdd(a.v_splats + (size_t)rgid * DNS_REC + col, val);
+                        if (DET) {
+                            if ((tmask >> src) & 1) a.det[((size_t)part * (size_t)a.det_cap + (size_t)rgid) * DNS_REC + col] = col_used ? val : 0.f;
+                        } else if (((tmask >> src) & 1) && col_used) unsafeAtomicAdd(a.v_splats + (size_t)rgid * DNS_REC + col, val);
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -862,6 +874,11 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT) 
 template <int D, int SPLIT, bool DN = false, bool COUNT = false, bool MASKS = false>
 int launch_bwd(const BwdArgs &ba, hipStream_t stream)
 {
+    if constexpr (!COUNT) if (ba.det) {                  // deterministic scatter: always the clamping loop, never folded
+        hipLaunchKernelGGL((raster_bwd_kernel<D, SPLIT, DN, false, MASKS, true, true>), dim3(ba.n_tiles * ba.n_cameras * PARTS), dim3(DNS_WAVE), 0, stream, ba);
+        DNS_CHECK_LAUNCH();
+        return DNSPLAT_OK;
+    }
     hipLaunchKernelGGL((raster_bwd_kernel<D, SPLIT, DN, COUNT, MASKS, true>), dim3(ba.n_tiles * ba.n_cameras * PARTS), dim3(DNS_WAVE), 0, stream, ba);
     DNS_CHECK_LAUNCH();
     if constexpr (DN && !COUNT) if (ba.sat_flag) {       // its clamp-free twin; exactly one of the two does the work
@@ -905,6 +922,8 @@ extern "C" int dnsplat_raster_bwd(const dnsplat_raster_args *a, dnsplat_stream_t
     ba.v_render = a->v_render; ba.v_alphas = a->v_alphas;
     ba.xy_split = a->xy_split;
     ba.v_splats = a->v_splats;
+    ba.det = a->det_partials; ba.det_cap = a->det_capacity;
+    if (ba.det && (a->det_capacity <= 0 || a->pair_counters)) return DNSPLAT_ERR_INVALID_ARG;
     ba.bg_rgb = ba.dn_v_rgb = ba.dn_v_depth = ba.dn_v_normal = ba.dn_v_acc = nullptr;
     if (a->n_cameras < 0) return DNSPLAT_ERR_INVALID_ARG;
     ba.n_cameras = a->n_cameras > 1 ? a->n_cameras : 1;
@@ -912,7 +931,7 @@ extern "C" int dnsplat_raster_bwd(const dnsplat_raster_args *a, dnsplat_stream_t
     ba.keep_masks = reinterpret_cast<const unsigned long long *>(a->keep_masks);
     ba.keep_mask_stride = a->keep_mask_stride;
     // the fused pass only (the generic and the counting instantiations have no clamp-free twin and always clamp)
-    ba.sat_flag = (a->dn && !a->pair_counters) ? a->saturation_flag : nullptr;
+    ba.sat_flag = (a->dn && !a->pair_counters && !a->det_partials) ? a->saturation_flag : nullptr;
     if (ba.keep_masks && a->keep_mask_stride <= 0) return DNSPLAT_ERR_INVALID_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     if (a->dn) {

@@ -242,6 +242,10 @@ def after_refinement(new_params: Dict[str, Tensor], stats=None, report: Optional
 
     if stats is not None:
         stats.reset(int(new_params["means"].shape[0]))
+    # the capacity guesses / static capacities / running maxima are keyed by the number of Gaussians: those of the old size would
+    # only accumulate (the scratch buffers themselves are grow-only and stay)
+    dev = new_params["means"].device
+    _ops.forget_capacity_guesses(dev if dev.type == "cuda" else None)
     arena = None
     if _ops.GRAD_ARENA is not None:
         arena = dp.GradArena({k: new_params[k] for k in dp.GRAD_KEYS})

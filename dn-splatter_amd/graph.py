@@ -51,6 +51,7 @@ class GraphedStep:
         self.done = [torch.cuda.Event() for _ in range(copies)]     # recorded behind every replay of a copy
         self.launched = [False] * copies
         self.replays = 0
+        self.overflowed = None
         prev = _ops.BIN_POLICY["mode"]
         try:
             self._capture(warmup, copies, before_capture)
@@ -109,10 +110,20 @@ class GraphedStep:
 
     def check(self) -> None:
         """Raises if any frame replayed so far produced more intersections than the captured buffers hold (its lists were
-        truncated).  Synchronises with the capture stream."""
+        truncated).  Synchronises with the capture stream.  After the error this step stays invalid (``overflowed``; every later
+        ``check()`` raises again, replaying it keeps truncating): build a new GraphedStep — the capacity guess has been raised to
+        1.25 x the count that did not fit, so the new capture gets buffers that hold it."""
         self.stream.synchronize()
         over = self._overflow()
         if over is not None:
+            self.overflowed = max(self.overflowed or 0, over)
+        if self.overflowed:
             raise _lib.DnsplatError(
-                f"GraphedStep: a replayed frame produced {over} intersections, more than the captured buffers hold; "
-                "re-capture (the capacity guess has been raised) — the results of that frame are invalid")
+                f"GraphedStep: a replayed frame produced {self.overflowed} intersections, more than the captured buffers hold; "
+                "the results of that frame (and of every frame with as many) are invalid. The capacity guess has been raised: "
+                "discard this step and capture a new GraphedStep")
+
+    def close(self) -> None:
+        """Releases the graphs and the per-stream bookkeeping of the bin policy (call before capturing a replacement)."""
+        self.graphs, self.results = [], []
+        _ops.forget_static(self.device, self.stream)

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DNSPLAT_ABI_VERSION 9
+#define DNSPLAT_ABI_VERSION 10
 #define DNSPLAT_RECORD_FLOATS 16
 #define DNSPLAT_MAX_CHANNELS 8
 
@@ -146,10 +146,10 @@ int dnsplat_pack_splats(int32_t N, const float *means2d, const float *conics, co
  * and (3) a stable radix sort on the tile id only. */
 size_t dnsplat_bin_workspace_bytes(int32_t N, int64_t isect_capacity, int32_t n_tiles);
 
-/* Byte offset, inside a workspace of that geometry, of a 32-bit status word: non-zero after dnsplat_bin_emit_sort iff a
- * look-back wait of the tile sort ran into its 20 ms bound (the lists of that frame are then wrong).  By construction a
- * wait only depends on workgroups that have already started, so this is a safety net against a hung device, not an
- * expected event; tests read it after the large frames. */
+/* Byte offset, inside a workspace of that geometry, of a reserved 32-bit status word.  dnsplat_bin_emit_sort sets it to 0 and no
+ * kernel of this build ever raises it: the tile sort has no inter-workgroup wait left that could time out (the decoupled look-back
+ * of an earlier build, whose 20 ms bound this word reported, was removed — DESIGN.md 3.1).  Kept so that the workspace layout and
+ * the symbol stay stable; tests read it after the large frames and expect 0. */
 size_t dnsplat_bin_status_offset(int32_t N, int64_t isect_capacity);
 
 typedef struct dnsplat_bin_args {
@@ -256,10 +256,34 @@ typedef struct dnsplat_raster_args {
     void *zero_fill;                    /* dnsplat_raster_fwd only: NULL, or a device buffer of zero_fill_bytes (multiple of 16) the launch clears
                                            on the way — meant for the v_splats buffer the backward of the same frame accumulates into */
     int64_t zero_fill_bytes;
+    float *det_partials;                /* dnsplat_raster_bwd only: NULL (gradient records accumulated into v_splats with fp32 atomics, in arrival
+                                           order), or a ZERO-FILLED device buffer [2, det_capacity, 16]: the deterministic mode.  The row a 16x8 half
+                                           tile (half h) contributes to the splat at sorted list index i is then STORED at [h][i][:] and v_splats is
+                                           not touched; dnsplat_det_reduce adds the rows up per gradient record in a fixed order */
+    int64_t det_capacity;               /* >= the isect capacity of the lists (entries flatten_ids can hold) */
 } dnsplat_raster_args;
 
 int dnsplat_raster_fwd(const dnsplat_raster_args *args, dnsplat_stream_t stream);
 int dnsplat_raster_bwd(const dnsplat_raster_args *args, dnsplat_stream_t stream);
+
+/* Deterministic reduction of the rows dnsplat_raster_bwd left in det_partials (test / debug mode, DNSPLAT_DETERMINISTIC=1 in the
+ * Python binding): the sorted list is stably re-sorted by record id (hand-written LSD radix, as the binning), and each record g
+ * that has list entries receives
+ *     v_splats[g][:] = sum over its entries in ascending list order of (partials[0][entry] + partials[1][entry]),
+ * accumulated in float64 and rounded once.  Rows of records without entries are left as they are (the caller zero-fills).  Same
+ * inputs give the same bits in every run, whatever order the compositing workgroups finished in.  Enqueued on `stream`, no sync. */
+typedef struct dnsplat_det_args {
+    int32_t n_records;          /* gradient records (cameras x Gaussians) */
+    int64_t capacity;           /* dnsplat_raster_args.det_capacity */
+    const int64_t *n_isects;    /* device scalar: number of valid list entries (dnsplat_bin_args.n_isects); clamped to capacity */
+    const int32_t *flatten_ids; /* [capacity] the sorted list the compositing walked */
+    const float *partials;      /* [2, capacity, 16] */
+    float *v_splats;            /* [n_records, 16] */
+    void *workspace;            /* dnsplat_det_workspace_bytes(capacity) */
+    size_t workspace_bytes;
+} dnsplat_det_args;
+size_t dnsplat_det_workspace_bytes(int64_t capacity);
+int dnsplat_det_reduce(const dnsplat_det_args *args, dnsplat_stream_t stream);
 
 /* Depth fill + depth->normal stencil of get_outputs (dn_model.py:533-537 and 589-603 with
  * utils/normal_utils.py:9-48, utils/camera_utils.py:92-144, called with c2w = identity):

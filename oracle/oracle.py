@@ -207,9 +207,10 @@ def isect_offset_encode(isect_ids, tile_width, tile_height):
 
 
 def rasterize_fwd(means2d, conics, colors, opacities, background, width, height, tile_size,
-                  isect_offsets, flatten_ids, borderline=None):
+                  isect_offsets, flatten_ids, borderline=None, flip_weight=None):
     """``borderline``: optional uint8 [H,W] output, 1 where a hard decision of the rule set fell inside the fp32
-    rounding envelope (see orc_rasterize_fwd)."""
+    rounding envelope (see orc_rasterize_fwd); ``flip_weight``: optional float32 [H,W] output (needs ``borderline``), the
+    compositing weight those decisions can move at the pixel."""
     N, D = colors.shape
     dt = colors.dtype
     render = torch.zeros(height, width, D, dtype=dt)
@@ -221,7 +222,7 @@ def rasterize_fwd(means2d, conics, colors, opacities, background, width, height,
        _p(background.contiguous() if background is not None else None),
        ctypes.c_int(width), ctypes.c_int(height), ctypes.c_int(tile_size),
        _p(isect_offsets.contiguous()), _p(flatten_ids.contiguous()), ctypes.c_int64(flatten_ids.shape[0]),
-       _p(render), _p(alphas), _p(last_ids), _p(borderline))
+       _p(render), _p(alphas), _p(last_ids), _p(borderline), _p(flip_weight))
     return render, alphas, last_ids
 
 
@@ -290,10 +291,10 @@ class _SphericalHarmonics(torch.autograd.Function):
 class _RasterizeToPixels(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, background, width, height, tile_size,
-                isect_offsets, flatten_ids, absgrad, borderline=None):
+                isect_offsets, flatten_ids, absgrad, borderline=None, flip_weight=None):
         # means2d may arrive as [1,N,2] (the tensor dn_model.py:517-519 retains grad on) or [N,2]
         render, alphas, last_ids = rasterize_fwd(means2d.reshape(-1, 2), conics, colors, opacities, background,
-                                                 width, height, tile_size, isect_offsets, flatten_ids, borderline)
+                                                 width, height, tile_size, isect_offsets, flatten_ids, borderline, flip_weight)
         ctx.save_for_backward(means2d, conics, colors, opacities, isect_offsets, flatten_ids, alphas, last_ids)
         ctx.background = background
         ctx.cfg = (width, height, tile_size, absgrad)
@@ -308,7 +309,7 @@ class _RasterizeToPixels(torch.autograd.Function):
             flatten_ids, alphas, last_ids, v_render, v_alphas, absgrad)
         if absgrad:
             means2d.absgrad = v_abs.reshape(means2d.shape)
-        return (v_means2d.reshape(means2d.shape), v_conics, v_colors, v_opac) + (None,) * 8
+        return (v_means2d.reshape(means2d.shape), v_conics, v_colors, v_opac) + (None,) * 9
 
 
 # --------------------------------------------------------------------------- gsplat-shaped API
@@ -366,8 +367,15 @@ def rasterization(
     assert bg is None or bg.shape[0] == cols.shape[-1], (bg.shape, cols.shape)
     means2d_c = means2d[None]  # [1,N,2]: the object the caller retains grad / reads .absgrad on
     borderline = torch.zeros(height, width, dtype=torch.uint8)
+    flip_weight = torch.zeros(height, width, dtype=torch.float32)
     render, alphas = _RasterizeToPixels.apply(means2d_c, conics, cols, opacities, bg, width, height,
-                                              tile_size, isect_offsets, flatten_ids, absgrad, borderline)
+                                              tile_size, isect_offsets, flatten_ids, absgrad, borderline, flip_weight)
+    # what one flipped decision can move, per channel: the largest |colour| any visible splat (or the background) contributes
+    vis_rows = cols.detach()[radii > 0]
+    channel_absmax = vis_rows.abs().amax(0) if vis_rows.numel() else cols.new_zeros(cols.shape[-1])
+    if bg is not None:
+        channel_absmax = torch.maximum(channel_absmax, bg.detach().abs().to(channel_absmax.dtype))
+    raw_last = render.detach()[..., -1].clone()     # the depth channel before the ED division
     if render_mode in ("ED", "RGB+ED"):
         render = torch.cat([render[..., :-1], render[..., -1:] / alphas[..., None].clamp(min=1e-10)], dim=-1)
 
@@ -381,6 +389,9 @@ def rasterization(
         # not gsplat keys: pixels whose skip / stop / clamp decisions fell inside the fp32 rounding envelope, and
         # Gaussians whose integer outputs hinge on the last place of the activated inputs
         "borderline": borderline.bool(),
+        # per pixel: the compositing weight the flagged decisions can move (orc_rasterize_fwd), and the per-channel |colour| bound
+        # that turns it into a bound on the image (tests/_scenes.py flip_bound_*)
+        "flip_weight": flip_weight, "channel_absmax": channel_absmax.float(), "raw_depth_channel": raw_last,
         "edge_gaussians": project_edge(means.detach(), quats.detach(), scales.detach(), viewmat, K, width, height, eps2d,
                                        near_plane, far_plane, radius_clip, tile_size),
     }
@@ -407,8 +418,9 @@ def _rasterization_batch(means, quats, scales, opacities, colors, viewmats, Ks, 
     meta = dict(infos[0])
     for k in ("radii", "means2d", "depths", "conics", "opacities", "tiles_per_gauss"):      # each [1, N, ...]
         meta[k] = torch.cat([i[k] for i in infos], 0)
-    for k in ("borderline", "edge_gaussians"):                                              # [H, W] / [N]
+    for k in ("borderline", "edge_gaussians", "flip_weight", "raw_depth_channel"):          # [H, W] / [N]
         meta[k] = torch.stack([i[k] for i in infos])
+    meta["channel_absmax"] = torch.stack([i["channel_absmax"] for i in infos]).amax(0)
     meta["per_camera_means2d"] = [i["means2d"] for i in infos]     # the leaves that receive .grad / .absgrad
     meta.update(flatten_ids=torch.cat(flat), isect_ids=torch.cat(ids), isect_offsets=torch.cat(offs, 0), n_cameras=C)
     return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0), meta
@@ -430,15 +442,18 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
         out = torch.ones(img_height, img_width, colors.shape[-1], dtype=colors.dtype) * background
         return (out, torch.zeros(img_height, img_width, dtype=colors.dtype)) if return_alpha else out
     opac = opacity.reshape(-1)
-    global last_borderline
+    global last_borderline, last_flip_weight
     border = torch.zeros(img_height, img_width, dtype=torch.uint8)
+    flip = torch.zeros(img_height, img_width, dtype=torch.float32)
     render, alphas = _RasterizeToPixels.apply(xys, conics, colors, opac, background, img_width, img_height,
-                                              block_width, offsets, flatten_ids, False, border)
-    last_borderline = border.bool()     # the legacy call returns no info dict: parity tests read the mask here
+                                              block_width, offsets, flatten_ids, False, border, flip)
+    last_borderline = border.bool()     # the legacy call returns no info dict: parity tests read the mask (and the weight) here
+    last_flip_weight = flip
     return (render, alphas) if return_alpha else render
 
 
 last_borderline: Optional[Tensor] = None
+last_flip_weight: Optional[Tensor] = None
 
 
 def tight_tile_boxes(means2d: Tensor, conics: Tensor, opacities: Tensor, radii: Tensor, tile_size: int, tile_width: int,

@@ -33,21 +33,81 @@ def rel_err(a, b) -> float:
 # differ in the last place (libm expf in the oracle, v_exp_f32 on the GPU, ex2.approx in gsplat's CUDA) take the other
 # side of a cut-off for a handful of (pixel, splat) pairs per frame.  The oracle therefore reports, per pixel, whether
 # any of its decisions fell inside the fp32 rounding envelope of its threshold (info["borderline"], see
-# orc_rasterize_fwd in oracle/oracle_impl.inc).  Only those pixels are set aside: images are compared on all other
-# pixels, and the cotangents fed to both backward passes are zero on them, so they contribute exactly nothing to any
-# gradient on either side.  Everything that is compared is held to REL_TOL with no allowance.
+# orc_rasterize_fwd in oracle/oracle_impl.inc), and how much compositing weight those decisions can move at the pixel
+# (info["flip_weight"]).  What the tests do with it:
+#   * FORWARD: every pixel is compared.  A pixel without a flagged decision is held to REL_TOL; a borderline pixel is held to
+#     REL_TOL + the finite bound that follows from its flip weight (flip_bound_* below: one flipped skip moves at most
+#     2 alpha_k T_k max|c|, i.e. <= (2/255) T max|c|; a flipped stop at most what is left, ~1e-4 max|c|).  A kernel that wrote
+#     garbage there fails.
+#   * BACKWARD: the cotangents fed to BOTH backward passes are zero on the borderline pixels, so they contribute exactly
+#     nothing to any gradient on either side; every gradient entry is held to REL_TOL (+ the fp64 envelope, assert_close).
 EXCLUDED = []    # (what, n_borderline, n_pixels) of every masked comparison, printed by the tests
 
 
 def keep_mask(borderline, what=""):
-    """bool [H,W] of the pixels that ARE compared; records and prints how many were set aside."""
+    """bool [H,W] of the pixels WITHOUT a flagged decision (they carry the cotangents of the backward comparison); records and
+    prints how many are borderline."""
     b = borderline.reshape(borderline.shape[-2], borderline.shape[-1]).bool().cpu()
     n, tot = int(b.sum()), b.numel()
     EXCLUDED.append((what, n, tot))
-    print(f"[parity] {what}: {n} of {tot} pixels borderline ({100.0 * n / max(tot, 1):.4f} %), compared separately")
+    print(f"[parity] {what}: {n} of {tot} pixels borderline ({100.0 * n / max(tot, 1):.4f} %): images held to the flip bound there, "
+          "cotangents zero on both sides")
     # a mask that swallowed a visible share of the image would make the comparison meaningless
     assert n <= max(8, 0.01 * tot), f"{what}: {n} of {tot} pixels flagged borderline"
     return ~b
+
+
+# ---- finite bounds for the image values of borderline pixels (all float64, shaped like the image they bound) -------------
+FLIP_SLACK = 1.05    # the weights are evaluated on the oracle's own trajectory; the other side's T differs by rounding
+
+
+def flip_bound_linear(flip, cmax):
+    """raw composite channels out_c = sum_i w_i c_ic (+ T bg_c): [..., H, W] flip weights, [C] per-channel max |c| -> [..., H, W, C]"""
+    return FLIP_SLACK * 2.0 * flip.double()[..., None] * cmax.double().reshape(*([1] * flip.dim()), -1)
+
+
+def flip_bound_alpha(flip):
+    """alpha image = sum_i w_i"""
+    return FLIP_SLACK * flip.double()
+
+
+def flip_bound_ratio(flip, cmax, value, alpha):
+    """expected depth = acc / max(alpha, 1e-10): |d| <= (|d acc| + |value| |d alpha|) / (alpha - |d alpha|); unbounded (inf) where
+    the flagged weight is the whole of the pixel's alpha.  All [..., H, W]; cmax a number."""
+    f = FLIP_SLACK * flip.double()
+    den = alpha.double() - f
+    b = (2.0 * f * float(cmax) + value.double().abs() * f) / den.clamp_min(1e-300)
+    return torch.where(f > 0, torch.where(den > 0, b, torch.full_like(b, float("inf"))), torch.zeros_like(b))
+
+
+def flip_bound_unit(flip, cmax, norm):
+    """(n / |n| + 1) / 2 of a composited vector n [..., H, W, 3] with |n| = ``norm`` [..., H, W]: |d n|_2 <= sqrt(3) 2 w cmax and
+    |d (n/|n|)| <= 2 |d n| / max(|n|, |n'|)"""
+    dn = FLIP_SLACK * 2.0 * (3.0 ** 0.5) * float(cmax) * flip.double()
+    b = torch.minimum(torch.ones_like(dn), dn / (norm.double() - dn).clamp_min(1e-300))
+    return torch.where(dn > 0, torch.where(norm.double() > dn, b, torch.ones_like(b)), torch.zeros_like(b))[..., None].expand(*flip.shape, 3)
+
+
+def render_bounds(info, render, alphas, render_mode):
+    """Bounds for the outputs of a rasterization() call (oracle info dict): (bound like ``render``, bound like ``alphas``)."""
+    flip = info["flip_weight"].reshape(render.shape[:-1])
+    cmax = info["channel_absmax"]
+    rb = flip_bound_linear(flip, cmax)
+    if render_mode in ("ED", "RGB+ED"):
+        rb = rb.clone()
+        rb[..., -1] = flip_bound_ratio(flip, float(cmax[-1]), render.detach()[..., -1], alphas.detach().reshape(flip.shape))
+    return rb, flip_bound_alpha(flip).reshape(alphas.shape)
+
+
+def assert_borderline_bounded(r_g, r_o, info_o, what, alpha=False, render_mode="RGB+ED", alphas_o=None):
+    """The forward comparison of one output of a rasterization() call over ALL pixels (tools/parity_seed_sweep.py)."""
+    if alpha:
+        assert_close(r_g, r_o, what, bound=flip_bound_alpha(info_o["flip_weight"].reshape(r_o.shape[:-1]))[..., None])
+        return
+    a_o = alphas_o if alphas_o is not None else info_o["_alphas"]
+    rb, _ = render_bounds(info_o, r_o, a_o, render_mode)
+    nc = r_o.shape[-1]
+    assert_close_groups(r_g, r_o, what, [("colour", 0, nc - 1), ("depth", nc - 1, nc)], bound=rb)
 
 
 def image_pixels(t, keep):
@@ -80,13 +140,14 @@ def assert_close_groups(a, b, what, groups, dim=-1, **kw):
     """assert_close on slices of ``dim`` taken separately, each against the scale of ITS slice of the reference: rgb and expected
     depth of a render (depth ~ 3-13 would otherwise set the scale for the colours), the SH bands of a coefficient gradient
     (band 0 is an order of magnitude above the rest).  ``groups``: [(name, lo, hi), ...]."""
-    env, keep = kw.pop("envelope", None), kw.get("keep")
+    env, keep, bound = kw.pop("envelope", None), kw.get("keep"), kw.pop("bound", None)
     for name, lo, hi in groups:
         idx = [slice(None)] * a.dim()
         idx[dim] = slice(lo, hi)
         if lo >= a.shape[dim]:
             continue
-        assert_close(a[tuple(idx)], b[tuple(idx)], f"{what}[{name}]", envelope=None if env is None else env[tuple(idx)], **kw)
+        assert_close(a[tuple(idx)], b[tuple(idx)], f"{what}[{name}]", envelope=None if env is None else env[tuple(idx)],
+                     bound=None if bound is None else bound[tuple(idx)], **kw)
 
 
 def sh_band_groups(K):
@@ -98,8 +159,9 @@ def sh_band_groups(K):
     return [("all", 0, K)]
 
 
-def assert_close(a, b, what, tol=REL_TOL, atol=0.0, keep=None, envelope=None):
-    """|a-b| <= tol * max|b| + atol (+ envelope) at every entry (over the pixels selected by ``keep`` for images).
+def assert_close(a, b, what, tol=REL_TOL, atol=0.0, keep=None, envelope=None, bound=None):
+    """|a-b| <= tol * max|b| + atol (+ envelope) (+ bound) at every entry (over the pixels selected by ``keep`` for images).
+    ``bound``: per-entry finite bound for the image values of borderline pixels (flip_bound_*; 0 everywhere else), shaped like ``b``.
     ``atol`` is only for tensors that are mathematically zero (e.g. the quaternion gradient of isotropic
     Gaussians), where both sides hold nothing but fp32 rounding noise.
     ``envelope``: per-entry rounding envelope of the REFERENCE algorithm itself, FP32_ENVELOPE x |oracle in fp32 - the same
@@ -126,6 +188,16 @@ def assert_close(a, b, what, tol=REL_TOL, atol=0.0, keep=None, envelope=None):
     if envelope is not None:
         assert keep is None and envelope.shape == b.shape
         allow = allow + envelope.detach().cpu().double().reshape(-1)
+    if bound is not None:
+        assert keep is None and tuple(bound.shape) == tuple(b.shape), (what, tuple(bound.shape), tuple(b.shape))
+        bd = bound.detach().cpu().double().reshape(-1)
+        n_b = int((bd > 0).sum())
+        if n_b:
+            over = d[bd > 0] > (tol * scale + atol)
+            print(f"[parity] {what}: {n_b} entries of borderline pixels held to their flip bound (median {float(bd[bd > 0].median()):.2e}); "
+                  f"{int(over.sum())} of them differ by more than the plain tolerance, worst error / bound = "
+                  f"{float((d[bd > 0] / (allow[bd > 0] + bd[bd > 0])).max()):.3f}")
+        allow = allow + bd
     ratio = (d / allow.clamp_min(1e-300)) if d.numel() else d
     worst = ratio.max().item() if d.numel() else 0.0
     log = os.environ.get("DNSPLAT_MARGIN_LOG")

@@ -32,6 +32,8 @@ def rasterization_case(path, N=3000, W=128, H=96, focal=90, seed=17, cot_seed=23
     ((r * v_r).sum() + (a * v_a).sum()).backward()
     out = dict(N=N, W=W, H=H, focal=focal, seed=seed, cot_seed=cot_seed,
                render=r.detach().numpy(), alpha=a.detach().numpy(), borderline=info["borderline"].numpy(),
+               # what the flagged decisions can move at each pixel (oracle/oracle_impl.inc): the GPU test holds borderline pixels to it
+               flip_weight=info["flip_weight"].numpy(), channel_absmax=info["channel_absmax"].numpy(),
                radii=info["radii"].numpy(), tiles_per_gauss=info["tiles_per_gauss"].numpy(),
                flatten_ids=info["flatten_ids"].numpy(), isect_offsets=info["isect_offsets"].numpy(),
                isect_ids=info["isect_ids"].numpy(),

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(dns, built):
 
 def test_abi_version_and_strerror(dns, built):
     L = dns.load_library()
-    assert L.dnsplat_abi_version() == 9
+    assert L.dnsplat_abi_version() == 10
     msgs = {L.dnsplat_strerror(c).decode() for c in (0, -1, -2, -3, -4)}
     assert len(msgs) == 5 and "ok" in msgs
     assert "unknown" in L.dnsplat_strerror(-99).decode()
@@ -79,7 +79,7 @@ def test_struct_layouts_match_the_c_compiler(dns, tmp_path):
     structs = {"dnsplat_scene": _lib.Scene, "dnsplat_camera": _lib.Camera, "dnsplat_proj_out": _lib.ProjOut,
                "dnsplat_bin_args": _lib.BinArgs, "dnsplat_raster_args": _lib.RasterArgs,
                "dnsplat_proj_grads": _lib.ProjGrads, "dnsplat_dn_post": _lib.DnPost, "dnsplat_dn_loss_args": _lib.DnLossArgs,
-               "dnsplat_densify_args": _lib.DensifyArgs}
+               "dnsplat_densify_args": _lib.DensifyArgs, "dnsplat_det_args": _lib.DetArgs}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){']
     for cname, cls in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

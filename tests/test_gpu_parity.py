@@ -11,7 +11,8 @@ import pytest
 import torch
 
 from _scenes import (REL_TOL, assert_close, assert_close_groups, sh_band_groups, fp64_envelope, assert_equal_int, cotangents, gsplat_inputs,
-                     keep_mask, rel_err, to_leaf, zero_borderline)
+                     keep_mask, rel_err, to_leaf, zero_borderline, render_bounds, flip_bound_linear, flip_bound_alpha, flip_bound_ratio,
+                     flip_bound_unit)
 
 pytestmark = pytest.mark.gpu
 
@@ -49,7 +50,8 @@ def _fp64_gradients(info_o, v_r, v_a):
 
 
 def _keep(o, what="scene"):
-    """Pixels compared strictly: everything outside the oracle's borderline mask (_scenes.py)."""
+    """Pixels without a flagged decision (the oracle's borderline mask, _scenes.py): they carry the cotangents of the backward
+    comparison.  The forward comparison covers every pixel, the borderline ones at their flip bound."""
     info_o = o[2]
     if "_keep" not in info_o:
         info_o["_keep"] = keep_mask(info_o["borderline"], what)
@@ -65,14 +67,16 @@ def _check_forward(o, g, tol=REL_TOL, what="scene"):
     assert info_g["n_isects"] == info_o["flatten_ids"].shape[0]
     for k in FLOAT_KEYS:
         assert_close(info_g[k], info_o[k], k, tol)
-    keep = _keep(o, what)
+    _keep(o, what)            # prints / bounds the number of borderline pixels
     # colour channels and the depth channel against their OWN scales (expected depth ~ 3-13 would let rgb be off by 1e-3)
     nc = r_o.shape[-1]
     mode = info_o.get("_call", (None,) * 7)[6].get("render_mode", "RGB") if "_call" in info_o else "RGB"
     n_depth = 1 if mode in ("RGB+D", "RGB+ED", "D", "ED") else 0
     groups = ([("colour", 0, nc - n_depth)] if nc - n_depth > 0 else []) + ([("depth", nc - n_depth, nc)] if n_depth else [])
-    assert_close_groups(r_g, r_o, "render", groups, tol=tol, keep=keep)
-    assert_close(a_g, a_o, "alpha", tol, keep=keep)
+    # EVERY pixel is compared: plain tolerance where no decision was flagged, tolerance + the finite flip bound where one was
+    rb, ab = render_bounds(info_o, r_o, a_o, mode)
+    assert_close_groups(r_g, r_o, "render", groups, tol=tol, bound=rb)
+    assert_close(a_g, a_o, "alpha", tol, bound=ab)
 
 
 def _check_backward(o, g, tol=REL_TOL, seed=1, absgrad=True, quat_atol=0.0, what="scene"):
@@ -128,16 +132,36 @@ def _mirror_pair(dns, orc, gp, cam, hip_kw, cot_seed=2, what="mirror", config=No
     def leaves(device):
         return {k: v.detach().to(device).clone().requires_grad_(k != "normals") for k, v in gp.items()}
 
+    def rasterize_gaussians_spy(*a, **kw):
+        out = orc.rasterize_gaussians(*a, **kw)
+        captured["normal_raw"] = out.detach()
+        return out
+
     p_o = leaves("cpu")
     m_o = dns.DNSplatterRenderer(p_o, config=config, fused=False, rasterization_fn=rasterization_spy,
-                                 rasterize_gaussians_fn=orc.rasterize_gaussians)
+                                 rasterize_gaussians_fn=rasterize_gaussians_spy)
     if step is not None:
         m_o.step = step
     orc.last_borderline = None
+    orc.last_flip_weight = None
     out_o = m_o.get_outputs(cam)
     border = captured["info"]["borderline"].clone()
+    flip = captured["info"]["flip_weight"].clone()
     if orc.last_borderline is not None and orc.last_borderline.shape == border.shape:
         border |= orc.last_borderline                       # the second (legacy normal) pass
+        flip = torch.maximum(flip, orc.last_flip_weight)
+    # finite bounds for the image values of the borderline pixels (0 elsewhere), through the post-ops of dn_model.py:526-537, 577-578
+    info_c, bg_c = captured["info"], out_o["background"].detach()
+    cmax = info_c["channel_absmax"]
+    a_img = captured["alpha"][0, ..., 0]
+    m_o.flip_bounds = {
+        # rgb = clamp(render + (1 - alpha) bg, 0, 1): 1-Lipschitz in the composite, plus the background's share of d alpha
+        "rgb": flip_bound_linear(flip, cmax[:3]) + flip_bound_alpha(flip)[..., None] * bg_c.abs().double(),
+        "accumulation": flip_bound_alpha(flip)[..., None],
+        "depth": flip_bound_ratio(flip, float(cmax[3]), captured["render"][0, ..., 3], a_img)[..., None],
+    }
+    if "normal_raw" in captured:
+        m_o.flip_bounds["normal"] = flip_bound_unit(flip, 1.0, captured["normal_raw"].norm(dim=-1))
     pre = captured["render"][0, ..., :3] + (1 - captured["alpha"][0]) * out_o["background"]
     border |= ((pre.abs() < 4e-6) | ((pre - 1).abs() < 4e-6)).any(-1)
     keep = keep_mask(border, what)
@@ -243,9 +267,11 @@ def _check_mirror(hip, ora, keep, what="mirror", quat_atol=0.0, ints=True):
             assert_equal_int(fid_g, fid_o, what + " flatten_ids (rounding-sensitive Gaussians taken out)")
             assert_equal_int(torch.bincount(tile_g, minlength=n_t), torch.bincount(tile_o, minlength=n_t),
                              what + " tile list lengths (rounding-sensitive Gaussians taken out)")
+    bounds = getattr(m_o, "flip_bounds", {})
     for k in OUT_KEYS:
         assert out_g[k].shape == out_o[k].shape
-        assert_close(out_g[k], out_o[k], what + " " + k, keep=keep)
+        # every pixel: plain tolerance, plus the finite flip bound on the borderline ones (no pixel is left out)
+        assert_close(out_g[k], out_o[k], what + " " + k, bound=bounds.get(k))
     g64 = getattr(m_o, "fp64_grads", None)
 
     def env(name, g32):
@@ -373,9 +399,10 @@ def test_legacy_rasterize_gaussians_options(dns, orc):
     dev = lambda t: t.to(DEV)   # noqa: E731
     out_g, al_g = dns.rasterize_gaussians(dev(info["means2d"][0]), *[dev(t) for t in common], dev(cols),
                                           dev(inp["opacities"][:, None]), 64, 96, 16, background=dev(bg), return_alpha=True)
-    keep = keep_mask(orc.last_borderline, "legacy options")
-    assert_close(out_g, out_o, "legacy render with background", keep=keep)
-    assert_close(al_g, al_o, "legacy alpha", keep=keep)
+    keep_mask(orc.last_borderline, "legacy options")
+    cmax5 = torch.maximum(cols.abs().amax(0), bg.abs())
+    assert_close(out_g, out_o, "legacy render with background", bound=flip_bound_linear(orc.last_flip_weight, cmax5))
+    assert_close(al_g, al_o, "legacy alpha", bound=flip_bound_alpha(orc.last_flip_weight))
     u8 = (cols[:, :3] * 255).to(torch.uint8)
     out_u8 = dns.rasterize_gaussians(dev(info["means2d"][0]), *[dev(t) for t in common], dev(u8), dev(inp["opacities"][:, None]),
                                      64, 96, 16)
@@ -510,7 +537,7 @@ def test_rasterize_gaussians_legacy_dropin(dns, orc):
                                     info["tiles_per_gauss"][0].to(DEV), cg["colors"], cg["opacity"], 112, 160, 16)
     assert out_g.shape == (112, 160, 3)
     keep = keep_mask(orc.last_borderline, "legacy drop-in")
-    assert_close(out_g, out_o, "legacy render", keep=keep)
+    assert_close(out_g, out_o, "legacy render", bound=flip_bound_linear(orc.last_flip_weight, torch.ones(3)))
     (v,) = cotangents([out_o.shape], 4)
     v = zero_borderline(v, keep)
     (out_o * v).sum().backward()
@@ -950,8 +977,8 @@ def test_background_width_follows_gsplat(dns, orc):
         r_g, a_g, _ = dns.rasterization(**gi, viewmats=viewmat.to(DEV), Ks=K.to(DEV), backgrounds=bg3.to(DEV), **kw)
         r_4, _a, _ = dns.rasterization(**gi, viewmats=viewmat.to(DEV), Ks=K.to(DEV),
                                        backgrounds=torch.tensor([[0.2, 0.4, 0.6, 0.0]], device=DEV), **kw)
-    keep = keep_mask(info_o["borderline"], "background width")
-    assert_close(r_g, r_o, "render with a 3-wide background in RGB+ED", keep=keep)
+    keep_mask(info_o["borderline"], "background width")
+    assert_close(r_g, r_o, "render with a 3-wide background in RGB+ED", bound=render_bounds(info_o, r_o, a_o, "RGB+ED")[0])
     assert torch.equal(r_g, r_4)
     with pytest.raises(ValueError):
         dns.rasterization(**gi, viewmats=viewmat.to(DEV), Ks=K.to(DEV), backgrounds=torch.zeros(1, 2, device=DEV), **kw)
@@ -1034,8 +1061,11 @@ def test_against_golden_fixture(dns):
     for k in INT_KEYS:
         assert_equal_int(info[k], torch.from_numpy(gold[k]), "golden " + k)
     keep = keep_mask(torch.from_numpy(gold["borderline"]), "golden c1_small")
-    assert_close(r, torch.from_numpy(gold["render"]), "golden render", keep=keep)
-    assert_close(a, torch.from_numpy(gold["alpha"]), "golden alpha", keep=keep)
+    g_r, g_a = torch.from_numpy(gold["render"]), torch.from_numpy(gold["alpha"])
+    rb, ab = render_bounds({"flip_weight": torch.from_numpy(gold["flip_weight"]), "channel_absmax": torch.from_numpy(gold["channel_absmax"])},
+                           g_r, g_a, "RGB+ED")
+    assert_close_groups(r, g_r, "golden render", [("colour", 0, 3), ("depth", 3, 4)], bound=rb)
+    assert_close(a, g_a, "golden alpha", bound=ab)
     v_r, v_a = cotangents([r.shape, a.shape], int(gold["cot_seed"]))
     v_r, v_a = zero_borderline(v_r, keep), zero_borderline(v_a[..., 0], keep)[..., None]
     ((r * v_r.to(DEV)).sum() + (a * v_a.to(DEV)).sum()).backward()
@@ -1484,8 +1514,72 @@ def test_graphed_step_replays_equal_eager_frames(dns):
                 _ops.BUFFERS.static_cap[kk] = 10
         with pytest.raises(_lib.DnsplatError, match="more than the captured buffers hold"):
             step.check()
+        with pytest.raises(_lib.DnsplatError, match="more than the captured buffers hold"):
+            step.check()                      # sticky: the step stays invalid
+        step.close()
     finally:
         dns.set_bin_policy("sync")
         for kk in list(_ops.BUFFERS.static_cap):
             if kk[3:] == (20_000, 320, 240):
                 del _ops.BUFFERS.static_cap[kk]
+
+
+def test_graphed_step_overflow_is_reported_and_a_recapture_fits(dns):
+    """a pose copied into a captured step may need more intersections than the buffers captured at the
+    warm-up pose hold.  check() must say so, and a NEW capture after the error must get buffers that fit (the capacity guess is
+    raised from the device's running maximum) instead of overflowing again in its warm-up."""
+    from dn_splatter_amd import _lib, _ops, dp, synthetic
+    from dn_splatter_amd.graph import GraphedStep
+
+    N, W, H = 30_000, 256, 192
+    gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=11, device=DEV)
+    far = synthetic.orbit_camera(0, width=W, height=H, focal=60.0).to(DEV)         # wide view: small splats, few pairs
+    near = synthetic.orbit_camera(0, width=W, height=H, focal=60.0).to(DEV)
+    near.camera_to_worlds[..., :3, 3] *= 0.35                                       # inside the cloud: several times the pairs
+    cam = synthetic.orbit_camera(0, width=W, height=H, focal=60.0).to(DEV)
+    keys = ("rgb", "depth", "normal", "accumulation")
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    cot = [torch.rand((H, W, c), device=DEV, generator=gen) * 2 - 1 for c in (3, 1, 3, 1)]
+    r = dns.DNSplatterRenderer(gp, fused=True)
+
+    def compute():
+        out = r.get_outputs(cam)
+        torch.autograd.backward([out[k] for k in keys], cot)
+        return out
+
+    def count(c):
+        dns.set_bin_policy("sync")
+        r.forget()
+        with torch.no_grad():
+            r.get_outputs(c)
+        n = int(r.last_info["n_isects"])
+        r.forget()
+        return n
+
+    hkey = (torch.device(DEV), N, W, H)
+    try:
+        n_far, n_near = count(far), count(near)
+        assert n_near > 1.6 * n_far, (n_far, n_near)
+        _ops.BUFFERS.capacity_hint.pop(hkey, None)                                   # the guesses of the two counting frames
+        cam.camera_to_worlds.copy_(far.camera_to_worlds)
+        for v in gp.values():
+            v.grad = None
+        step = GraphedStep(compute, params={k: gp[k] for k in dp.GRAD_KEYS})
+        step(); step.check()
+        cam.camera_to_worlds.copy_(near.camera_to_worlds)
+        step()
+        with pytest.raises(_lib.DnsplatError, match="more than the captured buffers hold"):
+            step.check()
+        assert _ops.BUFFERS.capacity_hint[hkey] >= n_near
+        step.close()
+        for v in gp.values():
+            v.grad = None
+        step2 = GraphedStep(compute, params={k: gp[k] for k in dp.GRAD_KEYS})        # warm-up at the near pose, enlarged buffers
+        out = step2()
+        step2.check()
+        torch.cuda.synchronize()
+        assert int(r.last_info["_binning"]._n_dev.item()) == n_near
+        step2.close()
+    finally:
+        dns.set_bin_policy("sync")
+        _ops.BUFFERS.capacity_hint.pop(hkey, None)

@@ -1,8 +1,11 @@
 """Robustness of the strict parity policy: the C1-size rasterization test (isotropic and anisotropic) on seeds the test-suite
 does not use.  Every compared entry must stay within 1e-4 of its tensor's scale (plus, for gradients, the per-entry fp32
-rounding envelope of the reference algorithm: 4 x |oracle fp32 - oracle fp64|, tests/_scenes.py) outside the oracle's
-borderline mask; prints the worst error / allowance per seed, and in brackets the same without the envelope.
-    python tools/parity_seed_sweep.py [first_seed] [count]"""
+rounding envelope of the reference algorithm: 4 x |oracle fp32 - oracle fp64|, tests/_scenes.py); borderline pixels carry no
+cotangent and their images are held to the oracle's flip bound (tests/_scenes.py).  Prints the worst error / allowance per
+seed, and in brackets the same without the envelope.
+    python tools/parity_seed_sweep.py [first_seed] [count] [repeats]
+repeats > 1 runs the HIP side that many times per scene: under DNSPLAT_DETERMINISTIC=1 every repeat must give the same bits
+(reported as "bit-identical" / "VARIES"); the worst ratio over the repeats is what is printed."""
 import os
 import sys
 
@@ -12,43 +15,63 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 import dn_splatter_amd as dns  # noqa: E402
-from _scenes import FP32_ENVELOPE, cotangents, gsplat_inputs, image_pixels, to_leaf, zero_borderline  # noqa: E402
+from _scenes import FP32_ENVELOPE, assert_borderline_bounded, cotangents, gsplat_inputs, image_pixels, to_leaf, zero_borderline  # noqa: E402
+from dn_splatter_amd import _ops  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 DEV = "cuda:0"
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 100), (int(sys.argv[2]) if len(sys.argv) > 2 else 12)
-worst_all = 0.0
+repeats = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+print(f"deterministic gradient mode: {_ops.DETERMINISTIC['on']}; repeats per scene: {repeats}")
+worst_all, n_fail, n_vary = 0.0, 0, 0
 for seed in range(first, first + count):
     for aniso in (False, True):
         inp, viewmat, K, _ = gsplat_inputs(10_000, 256, 256, focal=160.0, seed=seed, anisotropic=aniso, view=seed % 8)
-        ci, gi = to_leaf(inp, "cpu"), to_leaf(inp, DEV)
+        ci = to_leaf(inp, "cpu")
         kw = dict(width=256, height=256, packed=False, sh_degree=3, render_mode="RGB+ED", absgrad=True)
         r_o, a_o, info_o = orc.rasterization(**ci, viewmats=viewmat, Ks=K, **kw)
-        r_g, a_g, info_g = dns.rasterization(**gi, viewmats=viewmat.to(DEV), Ks=K.to(DEV), **kw)
         keep = ~info_o["borderline"]
-        ints = all(torch.equal(info_g[k].cpu(), info_o[k]) for k in ("radii", "tiles_per_gauss", "flatten_ids", "isect_offsets"))
         v_r, v_a = cotangents([r_o.shape, a_o.shape], seed)
         v_r, v_a = zero_borderline(v_r, keep), zero_borderline(v_a[..., 0], keep)[..., None]
         ((r_o * v_r).sum() + (a_o * v_a).sum()).backward()
-        ((r_g * v_r.to(DEV)).sum() + (a_g * v_a.to(DEV)).sum()).backward()
         c64 = {k: v.detach().double().requires_grad_(True) for k, v in inp.items()}
         r_d, a_d, _ = orc.rasterization(**c64, viewmats=viewmat.double(), Ks=K.double(), **kw)
         ((r_d * v_r.double()).sum() + (a_d * v_a.double()).sum()).backward()
-        worst, where, worst_plain = 0.0, "", 0.0
-        pairs = [("render", image_pixels(r_g, keep), image_pixels(r_o, keep), r_o, None), ("alpha", image_pixels(a_g, keep), image_pixels(a_o, keep), a_o, None)]
-        pairs += [("grad " + k, gi[k].grad.cpu(), ci[k].grad, ci[k].grad, c64[k].grad) for k in ci if not (k == "quats" and not aniso)]
-        for name, a, b, ref, b64 in pairs:
-            scale = float(ref.detach().abs().max()) + 1e-30
-            d = (a.detach().cpu().double() - b.detach().double()).abs()
-            allow = torch.full_like(d, 1e-4 * scale)
-            if b64 is not None:
-                allow = allow + FP32_ENVELOPE * (b.detach().double() - b64.detach()).abs()
-            e = float((d / allow).max())
-            worst_plain = max(worst_plain, float(d.max()) / (1e-4 * scale))
-            if e > worst:
-                worst, where = e, name
+        worst, where, worst_plain, ints, first_run, same = 0.0, "", 0.0, True, None, True
+        for rep in range(repeats):
+            gi = to_leaf(inp, DEV)
+            r_g, a_g, info_g = dns.rasterization(**gi, viewmats=viewmat.to(DEV), Ks=K.to(DEV), **kw)
+            ints = ints and all(torch.equal(info_g[k].cpu(), info_o[k]) for k in ("radii", "tiles_per_gauss", "flatten_ids", "isect_offsets"))
+            ((r_g * v_r.to(DEV)).sum() + (a_g * v_a.to(DEV)).sum()).backward()
+            grads = {k: gi[k].grad.detach().cpu().clone() for k in gi}
+            if first_run is None:
+                first_run = grads
+                try:
+                    assert_borderline_bounded(r_g, r_o, info_o, "render", alphas_o=a_o)
+                    assert_borderline_bounded(a_g, a_o, info_o, "alpha", alpha=True)
+                except AssertionError as e:
+                    print("   borderline bound violated:", e)
+                    worst = max(worst, 9.99)
+            else:
+                same = same and all(torch.equal(grads[k], first_run[k]) for k in grads)
+            pairs = [("render", image_pixels(r_g, keep), image_pixels(r_o, keep), r_o, None), ("alpha", image_pixels(a_g, keep), image_pixels(a_o, keep), a_o, None)]
+            pairs += [("grad " + k, grads[k], ci[k].grad, ci[k].grad, c64[k].grad) for k in ci if not (k == "quats" and not aniso)]
+            for name, a, b, ref, b64 in pairs:
+                scale = float(ref.detach().abs().max()) + 1e-30
+                d = (a.detach().cpu().double() - b.detach().double()).abs()
+                allow = torch.full_like(d, 1e-4 * scale)
+                if b64 is not None:
+                    allow = allow + FP32_ENVELOPE * (b.detach().double() - b64.detach()).abs()
+                e = float((d / allow).max())
+                worst_plain = max(worst_plain, float(d.max()) / (1e-4 * scale))
+                if e > worst:
+                    worst, where = e, name
         worst_all = max(worst_all, worst)
+        bad = worst > 1.0 or not ints
+        n_fail += int(bad)
+        n_vary += int(not same)
         print(f"seed {seed} aniso {int(aniso)}: ints {'bit-exact' if ints else 'DIFFER'}, borderline {int((~keep).sum())} px, "
               f"worst error / allowance = {worst:.3f} ({where}) [{worst_plain:.3f} without the fp64 envelope]"
-              + ("   <-- FAIL" if worst > 1.0 or not ints else ""))
-print(f"worst over the sweep: {worst_all:.3f} of the allowance")
+              + (f", {repeats} runs {'bit-identical' if same else 'VARY'}" if repeats > 1 else "")
+              + ("   <-- FAIL" if bad else ""), flush=True)
+print(f"worst over the sweep: {worst_all:.3f} of the allowance; {n_fail} scenes FAIL; {n_vary} scenes vary between repeats")
