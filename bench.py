@@ -38,7 +38,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import faulthandler  # noqa: E402
+
 import torch  # noqa: E402
+
+faulthandler.enable()    # a crash inside a native call leaves the Python stack on stderr instead of a bare exit code
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, guides/MI355X_MICROARCH.md "Chip-level parameters"
 VALU_PEAK_TFLOPS = 157.3  # fp32 vector peak (256 CUs x 4 SIMD32 x 2 flops x 2.4 GHz x packed 2), cdna_hip_programming.md
@@ -155,6 +159,126 @@ def cpu_baseline(workload, crop=None):
     }
 
 
+def side_section(workload, steps, losses=None, tight=True, shared=None, rank=0):
+    """One more configuration measured AFTER the timed region of the headline workload, by the same method at a smaller scale:
+    parameters resident in HBM, the whole step (get_outputs + backward) captured into a HIP graph, PREROLL_STEPS untimed replays,
+    then ``steps`` replays timed between two synchronisations.  Per-stage times come from PROBE_STEPS instrumented eager steps
+    before the capture.  ``shared`` = (gp, renderer, cam, cot) re-uses the headline scene (the index-exact configuration);
+    otherwise the BASELINE workload ``workload`` is built here and freed afterwards.  ``tight=False``: gsplat's own tile boxes
+    (DNSPLAT_TIGHT_TILES=0), i.e. flatten_ids / isect_offsets are the reference's bit for bit."""
+    import dn_splatter_amd as dns
+    from dn_splatter_amd import _lib, _ops, dp, synthetic
+    from dn_splatter_amd.graph import GraphedStep
+
+    N, W, H, focal = WORKLOADS[workload]
+    P, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    prev = dict(arena=_ops.GRAD_ARENA, tight=_ops.TIGHT_TILES, policy=_ops.BIN_POLICY["mode"])
+    gstep = None
+    try:
+        _ops.TIGHT_TILES = bool(tight)
+        if shared is not None:
+            gp, renderer, cam, cot = shared
+            arena = prev["arena"]
+        else:
+            gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=0, device=dev)
+            cam = synthetic.orbit_camera(rank % 8, n_views=8, width=W, height=H, focal=focal).to(dev)
+            renderer = dns.DNSplatterRenderer(gp, fused=True)
+            arena = dp.GradArena(gp)
+            dns.set_grad_arena(arena)
+            gen = torch.Generator(device=dev).manual_seed(1 + rank)
+            shapes = {"rgb": (H, W, 3), "depth": (H, W, 1), "normal": (H, W, 3), "accumulation": (H, W, 1)}
+            cot = {k: torch.rand(shapes[k], device=dev, generator=gen) * 2 - 1 for k in OUT_KEYS}
+        batch = loss_counts = None
+        if losses:
+            from dn_splatter_amd import fused_loss, torch_losses
+            batch = torch_losses.synthetic_batch(W, H, dev, seed=rank)
+            if losses == "fused":
+                loss_counts = fused_loss.depth_counts(batch["mono_depth"])
+
+        def compute():
+            for k in dp.GRAD_KEYS:
+                gp[k].grad = None
+            out = renderer.get_outputs(cam)
+            if batch is not None and losses == "fused":
+                fused_loss.dn_loss_fused(out, batch, gp["scales"], counts=loss_counts).backward()
+            elif batch is not None:
+                torch_losses.dn_loss(out, batch, gp["scales"]).backward()
+            else:
+                torch.autograd.backward([out[k] for k in OUT_KEYS], [cot[k] for k in OUT_KEYS])
+
+        renderer.forget()
+        dns.set_bin_policy("capacity")          # a first frame that outgrows an older capacity guess is repaired in place
+        for _ in range(FIRST_TOUCH_STEPS + 1):
+            compute()
+        torch.cuda.synchronize()
+        for _ in range(PREROLL_STEPS):
+            compute()
+        torch.cuda.synchronize()
+        probe = _lib.StageTimer()
+        _lib.TIMER = probe
+        for _ in range(PROBE_STEPS):
+            compute()
+        torch.cuda.synchronize()
+        _lib.TIMER = None
+        pst = probe.summary()
+        info = renderer.last_info
+        I_sorted = int(info["n_isects"])
+        Nv = int((renderer.radii > 0).sum())
+        renderer.forget()
+        launch = "one HIP graph replay per step"
+        try:
+            gstep = GraphedStep(compute, params={k: gp[k] for k in dp.GRAD_KEYS})
+            run = gstep
+        except Exception as e:
+            launch = f"eager launches from Python (graph capture failed: {e!r})"
+            dns.set_bin_policy("deferred")
+            run = compute
+        for _ in range(PREROLL_STEPS):
+            run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if gstep is not None:
+            gstep.check()
+        else:
+            _ops.verify_pending_counts(dev, block=True)
+
+        def sms(name):
+            if name == "binning":
+                return sum(pst[k][2] for k in ("dnsplat_bin_prepare", "dnsplat_bin_emit_sort") if k in pst) / PROBE_STEPS
+            return pst[name][1] if name in pst else None
+
+        sb = stage_bytes(N, Nv, I_sorted, P, T)
+        B = sum(sb.values())
+        ms_bwd = sms("dnsplat_raster_bwd")
+        res = {"workload": workload, "value": round(steps / dt, 3), "unit": "frames/s", "ms_per_step": round(1e3 * dt / steps, 4),
+               "steps": steps, "launch": launch, "losses": losses or "random dense cotangents",
+               "tile_boxes": "tight (fused path)" if tight else "gsplat 3-sigma (index-exact)",
+               "N": N, "Nv": Nv, "n_isects_sorted": I_sorted, "pixels": P,
+               "stages_ms": {n: round(sms(n), 4) for n in STAGE_NAMES if sms(n) is not None},
+               "stages_measured": f"{PROBE_STEPS} instrumented eager steps before the capture",
+               "frame_roofline_frac": round(B * (steps / dt) / 1e9 / HBM_PEAK_GBS, 4),
+               "raster_bwd_roofline_frac": (round(sb["dnsplat_raster_bwd"] / (ms_bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_bwd else None)}
+        return res
+    except Exception as e:
+        return {"workload": workload, "value": None, "error": repr(e)}
+    finally:
+        _lib.TIMER = None
+        if gstep is not None:
+            gstep.close()
+        _ops.TIGHT_TILES = prev["tight"]
+        dns.set_grad_arena(prev["arena"])
+        dns.set_bin_policy(prev["policy"])
+        if shared is None:
+            _ops.forget_capacity_guesses(dev)
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,6 +303,9 @@ def main():
     ap.add_argument("--lean", action="store_true",
                     help="profiling runs (rocprofv3 --kernel-trace / --pmc serialise every launch): eager launches, no pre-roll, no "
                          "counting step, no strict-index-parity section")
+    ap.add_argument("--no-strict", action="store_true", help="skip the index-exact (gsplat tile boxes) section after the timed region")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="skip the short C3 / C5 / C5-with-fused-losses sections a default C2 run appends (extra_workloads in the JSON line)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, count them with one all-reduce and print {n_gpus, ranks_seen} without rendering (works "
                          "without a GPU over gloo: the CPU test of the --gpus N self-launch)")
@@ -297,10 +424,13 @@ def main():
     # ring (HIP events cannot be recorded into a graph under capture on ROCm 7.2).  Every replay of the timed region leaves its
     # pair; the tick is calibrated below against HIP events around a stamped interval.
     gstep, graph_note, stamps, tick_ms = None, None, None, None
-    want_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and exchange is None and not args.two_call
+    # with an exchange step (N > 1 ranks, or DNSPLAT_FORCE_DIST=1): the compute is one graph, the collectives follow each replay
+    # eagerly (graph.GraphedDpStep); a dense all-reduce (--dense-allreduce) keeps the eager step
+    want_graph = args.graph == "on" or (args.graph == "auto" and (world == 1 or exchange is not None) and not args.two_call
                                         and not args.torch_postops)
+    gdp = None
     if want_graph:
-        from dn_splatter_amd.graph import GraphedStep
+        from dn_splatter_amd.graph import GraphedDpStep, GraphedStep
 
         def compute():
             for k in dp.GRAD_KEYS:
@@ -320,7 +450,11 @@ def main():
 
         try:
             renderer.forget()          # the autograd graph of the last eager frame (its AccumulateGrad nodes live on the eager stream)
-            gstep = GraphedStep(compute, params={k: gp[k] for k in dp.GRAD_KEYS}, before_capture=before_capture)
+            if exchange is not None:
+                gdp = GraphedDpStep(compute, gp, arena, exchange=exchange, before_capture=before_capture)
+                gstep = gdp.step
+            else:
+                gstep = GraphedStep(compute, params={k: gp[k] for k in dp.GRAD_KEYS}, before_capture=before_capture)
         except Exception as e:      # the eager path is always there
             if args.graph == "on":
                 raise
@@ -328,7 +462,11 @@ def main():
             dns.set_bin_policy(args.bin_policy)
         finally:
             _lib.TIMER = None
-        if gstep is not None:
+        if gdp is not None:
+            def step():     # noqa: F811
+                gdp()
+                return gdp.wire
+        elif gstep is not None:
             def step():     # noqa: F811
                 gstep()
                 return 0
@@ -476,44 +614,21 @@ def main():
     # The fused path bins over tight tile boxes: its sorted lists are a sub-list of gsplat's (the pairs left out cannot reach
     # alpha >= 1/255 anywhere in their tile; images and gradients are the same numbers).  With gsplat's own boxes
     # (DNSPLAT_TIGHT_TILES=0) flatten_ids / isect_offsets are the reference's bit for bit — that configuration is timed here.
-    strict = None
+    strict, extras = None, None
     from dn_splatter_amd import _ops as _ops_mod2
-    if world == 1 and exchange is None and not args.two_call and not args.torch_postops and _ops_mod2.TIGHT_TILES and not args.lean:
-        _ops_mod2.TIGHT_TILES = False
-        try:
-            renderer.forget()
-            K3 = max(5, min(20, args.steps))
-            dns.set_bin_policy("capacity")      # the first frame outgrows the capacity the tight lists needed: repaired in place
-            for _ in range(3):
-                step_eager()
-            torch.cuda.synchronize()
-            dns.set_bin_policy("deferred")
-            sprobe = _lib.StageTimer()
-            _lib.TIMER = sprobe
-            for _ in range(PROBE_STEPS):
-                step_eager()
-            torch.cuda.synchronize()
-            _lib.TIMER = None
-            sst = sprobe.summary()
-            for _ in range(PREROLL_STEPS):
-                step_eager()
-            torch.cuda.synchronize()
-            ts = time.perf_counter()
-            for _ in range(K3):
-                step_eager()
-            torch.cuda.synchronize()
-            dts = time.perf_counter() - ts
-            strict = {"what": "same step with gsplat's 3-sigma tile boxes (DNSPLAT_TIGHT_TILES=0): flatten_ids / isect_offsets / "
-                              "tiles_per_gauss are the reference's bit for bit (tests/test_gpu_parity.py)",
-                      "value": round(K3 / dts, 3), "unit": "frames/s", "ms_per_step": round(1e3 * dts / K3, 4), "steps": K3,
-                      "launch": "eager launches from Python", "n_isects_sorted": int(renderer.last_info["n_isects"]),
-                      "stages_ms": {name: round(stage_ms(sst, name, PROBE_STEPS), 4) for name in STAGE_NAMES
-                                    if stage_ms(sst, name, PROBE_STEPS) is not None}}
-        except Exception as e:
-            strict = {"value": None, "error": repr(e)}
-        finally:
-            _lib.TIMER = None
-            _ops_mod2.TIGHT_TILES = True
+    if (world == 1 and exchange is None and not args.two_call and not args.torch_postops and _ops_mod2.TIGHT_TILES and not args.lean
+            and not args.no_strict):
+        if gstep is not None:
+            gstep.close()
+        K3 = max(5, min(20, args.steps))
+        strict = side_section(args.workload, K3, losses=args.losses, tight=False, shared=(gp, renderer, cam, cot), rank=rank)
+        strict["what"] = ("same step with gsplat's 3-sigma tile boxes (DNSPLAT_TIGHT_TILES=0): flatten_ids / isect_offsets / "
+                          "tiles_per_gauss are the reference's bit for bit (tests/test_gpu_parity.py)")
+        # ---- the other BASELINE configurations, so that the driver's record carries them
+        if args.workload == "c2" and not args.no_extra_workloads and not args.losses:
+            extras = {}
+            for name, wl, ls in (("c3", "c3", None), ("c5", "c5", None), ("c5_fused_loss", "c5", "fused")):
+                extras[name] = side_section(wl, max(5, min(10, args.steps)), losses=ls, tight=True, rank=rank)
 
     # ---- multi-GPU accounting, all outside the timed region ----------------------------------------
     multi = None
@@ -521,6 +636,8 @@ def main():
         K2 = max(3, min(10, args.steps))
 
         def timed(fn, n):
+            for _ in range(PREROLL_STEPS):       # operating clocks (see PREROLL_STEPS): each of the three figures is taken the same way
+                fn()
             dp.barrier(); torch.cuda.synchronize()
             t = time.perf_counter()
             for _ in range(n):
@@ -541,16 +658,25 @@ def main():
                 exchange.launch()
             dp.allreduce_gradients(gp, arena, exchange=exchange)
 
-        dns.set_sh_exchange(None)                # kernels write the SH rows themselves, no collective is started
-        t_compute = timed(compute_only, K2)
-        dns.set_sh_exchange(exchange)
-        step(); step()
-        t_step = timed(step, K2)
-        t_comm = timed(exchange_only, K2)
+        if gdp is not None:
+            # the graphed step: the same replay with and without the exchange behind it, and the exchange alone on the same buffers
+            t_compute = timed(gdp.compute_only, K2)
+            step(); step()
+            t_step = timed(step, K2)
+            t_comm = timed(gdp.exchange_only, K2)
+        else:
+            dns.set_sh_exchange(None)                # kernels write the SH rows themselves, no collective is started
+            t_compute = timed(compute_only, K2)
+            dns.set_sh_exchange(exchange)
+            step(); step()
+            t_step = timed(step, K2)
+            t_comm = timed(exchange_only, K2)
         exposed = max(0.0, t_step - t_compute)
         per_rank_I = dp.gather_over_ranks(float(I), dev)
         multi = {"step_ms": round(t_step, 4), "compute_only_ms": round(t_compute, 4), "exchange_alone_ms": round(t_comm, 4),
                  "exchange_exposed_ms": round(exposed, 4), "exchange_hidden_ms": round(max(0.0, t_comm - exposed), 4),
+                 "launch": ("compute = one HIP graph replay per step, the collectives issued eagerly behind it (graph.GraphedDpStep)"
+                            if gdp is not None else "eager launches from Python"),
                  "bytes_exchanged_per_gpu_per_step": int(wire),
                  "bytes_per_xgmi_link_per_step": int(wire / (world - 1)) if world > 1 else None,
                  "link_note": ("per-GPU bytes spread evenly over the W-1 direct xGMI links of the fully connected node" if world > 1
@@ -591,6 +717,7 @@ def main():
             "roofline_valu": roofline_valu,
             "frame_roofline": frame_roofline,
             "strict_index_parity": strict,
+            "extra_workloads": extras,
             "multi_gpu": multi,
             "stages": stages,
             "other_ms_torch_postops_autograd_host": round(1e3 * elapsed / args.steps - gpu_stage_ms, 4),

@@ -190,6 +190,30 @@ __device__ __forceinline__ void gen_pair(const uint32_t *owner, const GenArgs &g
     val = r.x;
 }
 
+// gen_pair for ITEMS pairs at once, in three phases — all owner reads (LDS), all record loads, then the arithmetic — so that the
+// record loads of a thread are in flight together (one by one, each was an LDS read, a wait, a 16-byte load and another wait).
+// i[r] = pair index within the chunk (callers clamp out-of-range items to a valid one).
+template <int ITEMS>
+__device__ __forceinline__ void gen_pairs(const uint32_t *owner, const GenArgs &g, uint32_t j0, uint32_t q0, const uint32_t (&i)[ITEMS],
+                                          uint32_t (&key)[ITEMS], uint32_t (&val)[ITEMS])
+{
+    uint32_t o[ITEMS];
+    uint4 rec[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) o[r] = owner[gen_pad((int)i[r])];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) rec[r] = *reinterpret_cast<const uint4 *>(g.jrec + (j0 + o[r] - 1u));
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const uint32_t t = q0 + i[r] - rec[r].y;
+        uint32_t row;
+        if (g.exact) row = (uint32_t)(((float)t + 0.5f) * (1.f / (float)rec[r].w));
+        else row = t / rec[r].w;
+        key[r] = rec[r].z + row * (uint32_t)g.tw + (t - row * rec[r].w);
+        val[r] = rec[r].x;
+    }
+}
+
 // FIRST = first pass of the depth sort (keys synthesised from radii / depths, n given by value: n_ptr may be NULL)
 // GEN = first pass of the tile sort: the keys are the tile ids of the pairs the workgroup re-creates (see GenArgs)
 // TH = threads per workgroup (chunk = TH x ITEMS keys): 256 x 8 for the N-sized depth passes, 512 x 8 for the tile passes
@@ -220,17 +244,33 @@ __global__ __launch_bounds__(TH) void radix_hist_kernel(const K *__restrict__ ke
     if (base < n) {
         uint32_t j0 = 0;
         if (GEN) j0 = gen_owners<ITEMS, TH>(owner, lds_wave, gen, blockIdx.x, base, min((uint32_t)(TH * ITEMS), n - base));
+        // Two phases, and NO branch around the loads (out-of-range items re-read the last valid one): written as
+        // `if (idx < n) { k = keys[idx]; atomicAdd(...) }` per item, every item became its own basic block with
+        // load -> s_waitcnt vmcnt(0) -> ds_add, i.e. ITEMS memory round trips in a row per thread (round 4, from the ISA).
+        uint32_t k[ITEMS];
+        bool ok[ITEMS];
+        if (GEN) {
+            uint32_t ii[ITEMS], vv[ITEMS];
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) ii[i] = min(base + i * TH + threadIdx.x, n - 1u) - base;
+            gen_pairs<ITEMS>(owner, gen, j0, base, ii, k, vv);
+        }
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
-            uint32_t idx = base + i * TH + threadIdx.x;
-            if (idx < n) {
-                uint32_t k;
-                if (GEN) { uint32_t v; gen_pair(owner, gen, j0, base, idx - base, k, v); }
-                else k = FIRST ? depth_key(radii, depths, idx) : (uint32_t)keys[idx];
+            const uint32_t idx = base + i * TH + threadIdx.x;
+            const uint32_t idc = min(idx, n - 1u);
+            ok[i] = idx < n;
+            if (GEN) {}
+            else if (FIRST) {
                 // the first depth pass drops the culled Gaussians: they emit nothing, so nothing downstream needs their rank
-                if (!FIRST || radii[idx] > 0) atomicAdd(&hist[(k >> shift) & mask], 1u);
-            }
+                const int32_t r = radii[idc];
+                k[i] = __float_as_uint(depths[idc]);
+                ok[i] = ok[i] && r > 0;
+            } else k[i] = (uint32_t)keys[idc];
         }
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i)
+            if (ok[i]) atomicAdd(&hist[(k[i] >> shift) & mask], 1u);
     }
     __syncthreads();
     if (threadIdx.x <= mask) table[(size_t)threadIdx.x * nb + blockIdx.x] = hist[threadIdx.x];
@@ -324,13 +364,28 @@ __global__ __launch_bounds__(TH) void radix_scatter_kernel(
     uint32_t key[ITEMS], val[ITEMS], rnk[ITEMS];
     uint32_t live = 0u;                                   // FIRST: bit r = item r is a visible Gaussian (the others are dropped here)
     const uint32_t wave_start = base + w * (DNS_WAVE * ITEMS);
+    // every item's key / value is requested up front, without a branch around the loads (out-of-range items re-read the last
+    // valid one): inside the ranking loop each load sat between two rounds of ballots and was waited for before the next was issued
+    [[maybe_unused]] int32_t rad[ITEMS];
     if (GEN) {
         // all pairs first: the owner table is overwritten by the staging stores below
+        uint32_t ii[ITEMS];
 #pragma unroll
-        for (int r = 0; r < ITEMS; ++r) {
-            const uint32_t idx = wave_start + r * DNS_WAVE + lane;
-            key[r] = 0u; val[r] = 0u;
-            if (idx < n) gen_pair(vals_s, gen, j0, base, idx - base, key[r], val[r]);
+        for (int r = 0; r < ITEMS; ++r) ii[r] = min(wave_start + r * DNS_WAVE + lane, n - 1u) - base;
+        gen_pairs<ITEMS>(vals_s, gen, j0, base, ii, key, val);
+    }
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const uint32_t idx = wave_start + r * DNS_WAVE + lane;
+        const uint32_t idc = min(idx, n - 1u);
+        if (GEN) {
+        } else if (FIRST) {
+            rad[r] = radii[idc];
+            key[r] = __float_as_uint(depths[idc]);
+            val[r] = idx;
+        } else {
+            key[r] = (uint32_t)keys_in[idc];               // plain loads: non-temporal ones measured +7 % on this pass (2- and
+            val[r] = vals_in[idc];                         // 4-byte accesses, and the histogram kernel has just read the same keys)
         }
     }
 #pragma unroll
@@ -338,14 +393,10 @@ __global__ __launch_bounds__(TH) void radix_scatter_kernel(
         const uint32_t idx = wave_start + r * DNS_WAVE + lane;
         bool valid = idx < n;
         if (FIRST) {
-            valid = valid && radii[idx] > 0;
-            key[r] = valid ? __float_as_uint(depths[idx]) : 0u;
-            val[r] = idx;
+            valid = valid && rad[r] > 0;
             live |= (valid ? 1u : 0u) << r;
-        } else if (!GEN) {
-            key[r] = valid ? (uint32_t)keys_in[idx] : 0u;      // plain loads: non-temporal ones measured +7 % on this pass (2- and
-            val[r] = valid ? vals_in[idx] : 0u;                // 4-byte accesses, and the histogram kernel has just read the same keys)
         }
+        if (!valid) { key[r] = 0u; if (!FIRST) val[r] = 0u; }
         const uint32_t d = (key[r] >> shift) & DMASK;
         // match-any by digit: DBITS ballots partition the wave into equal-digit lane sets
         uint64_t m = dns_ballot(valid);
@@ -432,11 +483,15 @@ __global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(int N, const uint
     const int base = blockIdx.x * SC_CHUNK + threadIdx.x * SC_ITEMS;
     uint32_t s = 0;
     if (blockIdx.x * SC_CHUNK < n) {
+        // the eight (order -> tiles) gathers of a thread are issued together: first all ranks, then all counts (no branch around the
+        // loads: a rank past the end re-reads the last valid one), instead of eight dependent round-trip pairs in a row
+        uint32_t o[SC_ITEMS], t[SC_ITEMS];
 #pragma unroll
-        for (int i = 0; i < SC_ITEMS; ++i) {
-            int j = base + i;
-            if (j < n) s += (uint32_t)tiles[order[j]];
-        }
+        for (int i = 0; i < SC_ITEMS; ++i) o[i] = order[min(base + i, n - 1)];
+#pragma unroll
+        for (int i = 0; i < SC_ITEMS; ++i) t[i] = (uint32_t)tiles[o[i]];
+#pragma unroll
+        for (int i = 0; i < SC_ITEMS; ++i) s += (base + i < n) ? t[i] : 0u;
     }
     uint32_t tot;
     block_incl_scan_256(s, lds_wave, tot);
@@ -497,11 +552,17 @@ __global__ __launch_bounds__(SC_THREADS) void scan_final_kernel(int N, const uin
     const int base = blockIdx.x * SC_CHUNK + threadIdx.x * SC_ITEMS;
     uint32_t v[SC_ITEMS];
     uint32_t s = 0;
+    {
+        uint32_t o[SC_ITEMS];          // as in scan_sums_kernel: all ranks, then all counts
 #pragma unroll
-    for (int i = 0; i < SC_ITEMS; ++i) {
-        int j = base + i;
-        v[i] = (j < n) ? (uint32_t)tiles[order[j]] : 0u;
-        s += v[i];
+        for (int i = 0; i < SC_ITEMS; ++i) o[i] = order[min(base + i, n - 1)];
+#pragma unroll
+        for (int i = 0; i < SC_ITEMS; ++i) v[i] = (uint32_t)tiles[o[i]];
+#pragma unroll
+        for (int i = 0; i < SC_ITEMS; ++i) {
+            if (base + i >= n) v[i] = 0u;
+            s += v[i];
+        }
     }
     // exclusive prefix of the chunk sums: every workgroup adds up the (few hundred) sums of the chunks before it itself,
     // which is cheaper than a separate single-workgroup scan launch between the two passes

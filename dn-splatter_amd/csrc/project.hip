@@ -301,11 +301,42 @@ __device__ __forceinline__ int sh_lds_index(int e)
 #endif
 typedef float dns_v4f __attribute__((ext_vector_type(4)));
 
+// DNS_PROJ_STAGE_UNROLL: all 16-byte loads of a workgroup's coefficient span are ISSUED before the first one is waited for.
+// Round 4 find, from the ISA: the rolled loop below compiled to  global_load_dwordx4 -> s_waitcnt vmcnt(0) -> ds_write_b128  per
+// iteration — ONE kilobyte in flight per wave, twelve HBM round trips in a row per workgroup, 12 KB in flight per CU with the 12
+// waves the kernels' registers allow: about 3 MB on the whole chip where HBM needs bandwidth x latency = 6-8 MB.  That, not the
+// occupancy, is what held the per-Gaussian kernels at 3.7-4.3 TB/s.  Unrolled, a wave has its whole 11.5 KB span in flight.
+#ifndef DNS_PROJ_STAGE_UNROLL
+#define DNS_PROJ_STAGE_UNROLL 1
+#endif
 template <int L>
 __device__ __forceinline__ void sh_stage_in(const float *__restrict__ gbase, int nfloats, float *lds)
 {
     const dns_v4f *g4 = reinterpret_cast<const dns_v4f *>(gbase);
     const int n4 = nfloats >> 2;
+#if DNS_PROJ_STAGE_UNROLL
+    constexpr int MAXIT = (SH_STAGE_THREADS * ShRowTraits<L>::ROW / 4 + SH_STAGE_THREADS - 1) / SH_STAGE_THREADS;
+    dns_v4f v[MAXIT];
+#pragma unroll
+    for (int k = 0; k < MAXIT; ++k) {
+        const int i = (int)threadIdx.x + k * SH_STAGE_THREADS;
+        if (i < n4) {
+#if DNS_PROJ_NT & 1
+            v[k] = __builtin_nontemporal_load(g4 + i);
+#else
+            v[k] = g4[i];
+#endif
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXIT; ++k) {
+        const int i = (int)threadIdx.x + k * SH_STAGE_THREADS;
+        if (i < n4) {
+            const int o = sh_lds_index<L>(4 * i);   // ROW % 4 == 0 in the padded layout: the 4 floats share a row
+            lds[o] = v[k].x; lds[o + 1] = v[k].y; lds[o + 2] = v[k].z; lds[o + 3] = v[k].w;
+        }
+    }
+#else
     for (int i = threadIdx.x; i < n4; i += SH_STAGE_THREADS) {
 #if DNS_PROJ_NT & 1
         const dns_v4f v = __builtin_nontemporal_load(g4 + i);
@@ -315,6 +346,7 @@ __device__ __forceinline__ void sh_stage_in(const float *__restrict__ gbase, int
         const int o = sh_lds_index<L>(4 * i);   // ROW % 4 == 0 in the padded layout: the 4 floats share a row
         lds[o] = v.x; lds[o + 1] = v.y; lds[o + 2] = v.z; lds[o + 3] = v.w;
     }
+#endif
     for (int e = (n4 << 2) + threadIdx.x; e < nfloats; e += SH_STAGE_THREADS) lds[sh_lds_index<L>(e)] = gbase[e];
 }
 

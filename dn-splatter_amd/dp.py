@@ -105,6 +105,13 @@ class ShFactorExchange:
         self.meta = None
         self.means: Optional[Tensor] = None
         self.work = None      # the all-gather in flight (launch())
+        # True: launch() does nothing and finish() runs the all-gather itself — for a backward that is being captured into a HIP
+        # graph (graph.GraphedDpStep): no collective is issued from inside the capture, the exchange follows the replay eagerly
+        self.deferred = False
+
+    def drop(self) -> None:
+        """Forgets factors that were produced but never rebuilt (warm-up frames of a graph capture)."""
+        self.meta, self.work = None, None
 
     @staticmethod
     def slab_floats(N: int) -> int:
@@ -138,7 +145,7 @@ class ShFactorExchange:
         """Start the all-gather of the slabs (enqueued after whatever filled ``mine`` on the current stream) without
         waiting for it: the projection backward calls this right after ``dnsplat_sh_factors`` and BEFORE
         ``dnsplat_project_bwd``, so the 12 B/Gaussian travel while the geometry gradients are computed."""
-        if self.meta is None or not _collectives_on(group):
+        if self.meta is None or self.deferred or not _collectives_on(group):
             return
         buf = self._gather_buffer(world_size(group))
         self.work = dist.all_gather_into_tensor(buf.view(-1), self.mine.view(-1), group=group, async_op=True)

@@ -127,3 +127,61 @@ class GraphedStep:
         """Releases the graphs and the per-stream bookkeeping of the bin policy (call before capturing a replacement)."""
         self.graphs, self.results = [], []
         _ops.forget_static(self.device, self.stream)
+
+
+class GraphedDpStep:
+    """The data-parallel step with the host out of the way: ``fn`` (get_outputs + loss + backward of THIS rank's camera) is
+    captured into one HIP graph, and the exchange step — the all-gather of the SH colour-gradient slabs, the all-reduce of
+    the geometry gradients, the rebuild kernel (``dp.allreduce_gradients``) — is issued eagerly right behind each replay.
+
+    Why not the collectives inside the graph: RCCL kernels captured into a HIP graph cannot be exercised on the one-GPU boxes
+    this code is developed on, and a hang on an 8-GPU node is not an acceptable way to find out.  What the eager step loses
+    to the host are the ~35 kernel launches of the frame (about 2 ms of Python per 2.3 ms of GPU at the 1 M / 1080p
+    workload); behind a replay the host issues two collectives and one kernel.  The price: the all-gather no longer starts
+    before ``dnsplat_project_bwd`` (it used to travel behind that kernel: 0.12 ms at 1 M Gaussians, 0.6 ms at 5 M).
+
+    Gradients land in the ``dp.GradArena`` slices autograd installed during the capture; ``wire`` holds the bytes the last
+    step exchanged."""
+
+    def __init__(self, fn: Callable[[], object], params: Dict[str, Tensor], arena, exchange=None, group=None, **kw):
+        from . import dp
+
+        self._dp = dp
+        self.params, self.arena, self.exchange, self.group = params, arena, exchange, group
+        self.wire = 0
+        if exchange is not None:
+            exchange.deferred = True
+
+        def compute():
+            if exchange is not None:
+                exchange.drop()          # an eager warm-up frame leaves factors nobody rebuilds
+            return fn()
+
+        self.step = GraphedStep(compute, params={k: params[k] for k in dp.GRAD_KEYS}, **kw)
+        # what ShFactorExchange.begin() recorded while the backward was captured: restored before every exchange, because a replay
+        # runs no Python
+        self._meta = exchange.meta if exchange is not None else None
+
+    def compute_only(self):
+        """Replay without the exchange (bench.py: what the step costs when nothing travels)."""
+        return self.step()
+
+    def exchange_only(self) -> int:
+        if self.exchange is not None:
+            self.exchange.meta = self._meta
+        self.wire = self._dp.allreduce_gradients(self.params, self.arena, self.group, exchange=self.exchange)
+        return self.wire
+
+    def __call__(self):
+        out = self.step()
+        self.exchange_only()
+        return out
+
+    def check(self) -> None:
+        self.step.check()
+
+    def close(self) -> None:
+        self.step.close()
+        if self.exchange is not None:
+            self.exchange.deferred = False
+            self.exchange.drop()

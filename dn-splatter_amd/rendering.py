@@ -112,7 +112,6 @@ def rasterization(
         "tile_width": tw,
         "tile_height": th,
         "tiles_per_gauss": pr["tiles_per_gauss"],
-        "isect_ids": _LazyIsectIds(b, pr["depths"]),
         "flatten_ids": b.flatten_ids[: b.n_isects],
         "isect_offsets": b.tile_offsets[:-1].reshape(C, th, tw),
         "width": width,
@@ -124,6 +123,10 @@ def rasterization(
     }
     if pr["compensations"] is not None:
         meta["compensations"] = pr["compensations"]
+    # gsplat's sorted 64-bit keys: nothing in dn-splatter reads them and the binning never forms them, so the entry is built (one
+    # small kernel) when it is first read — and is then a plain int64 Tensor like every other entry
+    depths = pr["depths"]
+    meta = _ops.LazyInfo(meta, lazy={"isect_ids": lambda: _ops.isect_ids(b, depths.detach())})
     return render, alphas[..., None], meta
 
 
@@ -146,19 +149,3 @@ def _background_row(backgrounds: Optional[Tensor], n_feat: int, with_depth: bool
         raise ValueError(f"backgrounds has {backgrounds.shape[-1]} channels; expected {n_feat} (the colour channels)"
                          + (f" or {D} (colour channels + depth)" if with_depth else ""))
     return row
-
-
-class _LazyIsectIds:
-    """``info["isect_ids"]`` — gsplat's sorted 64-bit keys.  Nothing in dn-splatter reads them, so
-    they are only materialised (one small kernel) when somebody calls ``.get()`` / ``torch.as_tensor``."""
-
-    def __init__(self, binning, depths):
-        self._b, self._d, self._v = binning, depths, None
-
-    def get(self) -> Tensor:
-        if self._v is None:
-            self._v = _ops.isect_ids(self._b, self._d.detach())
-        return self._v
-
-    def __len__(self):
-        return self._b.n_isects

@@ -25,6 +25,15 @@
 #define CAT_(a, b) a##b
 #define CAT(a, b) CAT_(a, b)
 
+/* Gradient scatter of the compositing backward (orc_rasterize_bwd): 0 = every term is added to the fp32 output arrays with omp
+ * atomics, in whatever order the threads arrive (what gsplat's CUDA atomics do: the fp32 result varies from run to run on
+ * ill-conditioned entries); 1 = the terms — still evaluated in REAL arithmetic — are accumulated in double and rounded once, so the
+ * result does not depend on the order (to the last bit except where the sum sits within 1e-12 of a rounding boundary).  The
+ * deterministic-mode tests of the HIP path (tests/test_gpu_determinism.py, tools/parity_seed_sweep.py) compare against that. */
+int orc_exact_accum = 0;
+void orc_set_exact_accum(int on) { orc_exact_accum = on; }
+int orc_get_exact_accum(void) { return orc_exact_accum; }
+
 /* ---- fp32 instantiation ---- */
 #define REAL float
 #define FN(name) CAT(name, _f32)

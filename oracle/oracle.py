@@ -57,6 +57,15 @@ def lib() -> ctypes.CDLL:
 _KEEP: list = []  # tensors whose storage must outlive the current C call (``x.contiguous()`` temporaries)
 
 
+def set_exact_accumulation(on: bool) -> bool:
+    """Compositing backward: accumulate the gradient scatter in double instead of fp32 omp atomics (dnsplat_oracle.c
+    ``orc_exact_accum``) — an order-independent result for the deterministic-mode checks.  Returns the previous setting."""
+    L = lib()
+    prev = bool(L.orc_get_exact_accum())
+    L.orc_set_exact_accum(ctypes.c_int(1 if on else 0))
+    return prev
+
+
 def _p(t: Optional[Tensor]):
     """Pointer to a contiguous CPU tensor.  The tensor is parked in _KEEP so a temporary made by
     ``.contiguous()`` cannot be freed (and its storage recycled) before the C call runs."""

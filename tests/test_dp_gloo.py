@@ -146,6 +146,25 @@ def _worker(rank, world, port, ret):
     assert torch.allclose(fpar["means"].grad, torch.full((n_g, 3), (world - 1) / 2))
     assert torch.equal(fpar["features_dc"].grad, want_dc) and torch.equal(fpar["features_rest"].grad, want_rest)
 
+    # the deferred form graph.GraphedDpStep relies on: the backward runs (here: is replayed) WITHOUT any collective — launch() is a
+    # no-op, nothing is in flight — and the whole exchange follows it; begin()'s bookkeeping is restored by hand as a replay runs
+    # no Python.  Same gradients as the two forms above.
+    ex.deferred = True
+    _LaunchInBackward.apply(torch.zeros(1, requires_grad=True)).sum().backward()
+    assert ex.work is None and ex.meta is not None
+    meta = ex.meta
+    ex.drop()                                   # "warm-up frame": factors produced, never rebuilt
+    _LaunchInBackward.apply(torch.zeros(1, requires_grad=True)).sum().backward()      # begin() must not complain
+    for rep in range(2):                        # two "replays"
+        ex.meta = meta
+        for k in dp.GEOMETRY_KEYS:
+            fpar[k].grad.fill_(float(rank))
+        fpar["features_dc"].grad.zero_(); fpar["features_rest"].grad.zero_()
+        assert dp.allreduce_gradients(fpar, far, exchange=ex) == got_bytes and ex.meta is None
+        assert torch.allclose(fpar["scales"].grad, torch.full((n_g, 3), (world - 1) / 2))
+        assert torch.equal(fpar["features_dc"].grad, want_dc) and torch.equal(fpar["features_rest"].grad, want_rest)
+    ex.deferred = False
+
     # densification statistics: sums over the step's increments, max over ranks (densify.py)
     from dn_splatter_amd.densify import DensifyStats
     prev = DensifyStats(8, "cpu")

@@ -63,7 +63,8 @@ def _check_forward(o, g, tol=REL_TOL, what="scene"):
     r_g, a_g, info_g, _ = g
     for k in INT_KEYS:
         assert_equal_int(info_g[k], info_o[k], k)
-    assert_equal_int(info_g["isect_ids"].get(), info_o["isect_ids"], "isect_ids")
+    assert torch.is_tensor(info_g["isect_ids"]) and info_g["isect_ids"].dtype == torch.int64
+    assert_equal_int(info_g["isect_ids"], info_o["isect_ids"], "isect_ids")
     assert info_g["n_isects"] == info_o["flatten_ids"].shape[0]
     for k in FLOAT_KEYS:
         assert_close(info_g[k], info_o[k], k, tol)
@@ -574,11 +575,25 @@ def test_get_outputs_mirror_matches_reference_sequence(dns, orc, mode):
     assert_equal_int(m_g.num_tiles_hit.reshape(-1), m_o.num_tiles_hit.reshape(-1), "num_tiles_hit")
     if m_g.last_info.get("tight_tiles"):
         assert bool((m_g.last_info["tiles_bin"].reshape(-1).cpu() <= m_o.num_tiles_hit.reshape(-1)).all())
-    # surface_normal is a finite-difference stencil of the depth image: depth noise is amplified by ~fx/d, so it
-    # is compared on the 99.9 % quantile of the error; the border must be exactly the reference's 0.5
-    d_sn = (out_g["surface_normal"].detach().cpu() - out_o["surface_normal"].detach()).abs().reshape(-1)
-    assert float(torch.quantile(d_sn[::7], 0.999)) < 5e-3, float(torch.quantile(d_sn[::7], 0.999))
-    assert float(d_sn.max()) < 0.5
+    # surface_normal is a finite-difference stencil of the depth image (dn_model.py:589-603): depth differences of 1e-5 are
+    # amplified by ~fx/d, so the IMAGES of the two sides are not comparable at a fixed tolerance.  What is pinned instead, at a
+    # stated tolerance: (1) the product's stencil (dnsplat_dn_depth_normals) applied to the ORACLE's depth image equals the
+    # reference sequence's surface_normal of that same depth to 2e-5 absolute (values in [0, 1]); (2) the product's
+    # surface_normal IS that stencil of the product's own depth image (2e-5; the fused HIP post-ops produce both in one launch)
+    def hip_stencil(depth_hw1):
+        from dn_splatter_amd import _lib, _ops
+        d = depth_hw1.detach().reshape(H, W).to(DEV).float().contiguous()
+        ones, dmax = torch.ones_like(d), torch.zeros(1, device=DEV)
+        d_out, sn_out = torch.empty_like(d), torch.empty(H, W, 3, device=DEV)
+        _lib.run("dnsplat_dn_depth_normals", _lib.lib().dnsplat_dn_depth_normals, W, H, float(cam.fx), float(cam.fy), float(cam.cx),
+                 float(cam.cy), _ops._ptr(d), _ops._ptr(ones), _ops._ptr(dmax), _ops._ptr(d_out), _ops._ptr(sn_out), _ops._stream())
+        torch.cuda.synchronize()
+        return sn_out.cpu()
+
+    d1 = (hip_stencil(out_o["depth"]) - out_o["surface_normal"].detach()).abs().max().item()
+    assert d1 <= 2e-5, f"HIP depth->normal stencil on the oracle's depth vs the reference sequence: {d1:.3e}"
+    d2 = (hip_stencil(out_g["depth"]) - out_g["surface_normal"].detach().cpu()).abs().max().item()
+    assert d2 <= 2e-5, f"product surface_normal vs the stencil of the product's own depth: {d2:.3e}"
     sn = out_g["surface_normal"].detach().cpu()
     assert torch.equal(sn[0], torch.full_like(sn[0], 0.5)) and torch.equal(sn[:, -1], torch.full_like(sn[:, -1], 0.5))
     assert_close(p_g["normals"], p_o["normals"], "gauss_params['normals'] (dn_model.py:558)", 1e-5)
@@ -810,7 +825,7 @@ def test_multi_camera_rasterization_equals_sequential_calls_and_oracle(dns, orc,
         _r, _a, info_o = orc.rasterization(**inp, viewmats=vms, Ks=Ks, **kw)
     for k in INT_KEYS:
         assert_equal_int(info_b[k], info_o[k], "batch " + k)
-    assert_equal_int(info_b["isect_ids"].get(), info_o["isect_ids"], "batch isect_ids (camera bits)")
+    assert_equal_int(info_b["isect_ids"], info_o["isect_ids"], "batch isect_ids (camera bits)")
 
 
 @pytest.mark.parametrize("layout", ["split", "cat"])

@@ -56,8 +56,37 @@ def _worker(rank, world, port, path):
         wire = dp.allreduce_gradients(gp, arena, exchange=exchange)
         assert all(arena.holds(gp[k].grad) for k in KEYS)
     torch.cuda.synchronize()
+    eager = {k: gp[k].grad.detach().clone() for k in KEYS}
+
+    # the same step with the compute captured into a HIP graph and the exchange issued eagerly behind each replay
+    # (graph.GraphedDpStep — what bench.py --gpus N times): same averaged gradients
+    from dn_splatter_amd.graph import GraphedDpStep
+
+    cam = synthetic.orbit_camera(rank, n_views=8, width=W, height=H, focal=220.0).to(dev)
+    renderer = dns.DNSplatterRenderer(gp, fused=True)
+    gen = torch.Generator(device=dev).manual_seed(100 + rank)
+    shapes = {"rgb": (H, W, 3), "depth": (H, W, 1), "normal": (H, W, 3), "accumulation": (H, W, 1)}
+    cots = [torch.rand(shapes[k], device=dev, generator=gen) * 2 - 1 for k in OUT]
+
+    def compute():
+        out = renderer.get_outputs(cam)
+        torch.autograd.backward([out[k] for k in OUT], cots)
+
+    for k in KEYS:
+        gp[k].grad = None
+    gdp = GraphedDpStep(compute, gp, arena, exchange=exchange)
+    worst = 0.0
+    for it in range(3):
+        gdp()
+        torch.cuda.synchronize()
+        assert all(arena.holds(gp[k].grad) for k in KEYS) and gdp.wire == wire
+        for k in KEYS:
+            scale = float(eager[k].abs().max()) + 1e-30
+            worst = max(worst, float((gp[k].grad - eager[k]).abs().max()) / scale)
+    gdp.check()
+    gdp.close()
     if rank == 0:
-        torch.save({"grads": {k: gp[k].grad.detach().cpu() for k in KEYS}, "wire": int(wire)}, path)
+        torch.save({"grads": {k: eager[k].cpu() for k in KEYS}, "wire": int(wire), "graph_vs_eager": worst}, path)
     dns.set_grad_arena(None)
     dns.set_sh_exchange(None)
     torch.distributed.barrier()
@@ -85,3 +114,5 @@ def test_two_ranks_on_one_gpu_average_like_one_process(tmp_path):
         assert_close(got["grads"][k].reshape(ref[k].shape), (ref[k] / world).float(), f"two ranks: grad {k}", tol=2e-5)
     # what travelled: 11 geometry floats per Gaussian in the all-reduce + the (3 N + 4)-float slab of every rank
     assert got["wire"] > 0
+    # graph replay + eager exchange gave the gradients of the fully eager step (same kernels; the atomics' order differs)
+    assert got["graph_vs_eager"] <= 2e-5, got["graph_vs_eager"]

@@ -22,7 +22,10 @@ from oracle import oracle as orc  # noqa: E402
 DEV = "cuda:0"
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 100), (int(sys.argv[2]) if len(sys.argv) > 2 else 12)
 repeats = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-print(f"deterministic gradient mode: {_ops.DETERMINISTIC['on']}; repeats per scene: {repeats}")
+if _ops.DETERMINISTIC["on"]:
+    orc.set_exact_accumulation(True)      # the oracle's gradient scatter order-independent as well (double accumulators)
+print(f"deterministic gradient mode: {_ops.DETERMINISTIC['on']} (oracle scatter accumulated in double: {_ops.DETERMINISTIC['on']}); "
+      f"repeats per scene: {repeats}")
 worst_all, n_fail, n_vary = 0.0, 0, 0
 for seed in range(first, first + count):
     for aniso in (False, True):
