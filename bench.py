@@ -222,10 +222,12 @@ def side_section(workload, steps, losses=None, tight=True, shared=None, rank=0):
         torch.cuda.synchronize()
         _lib.TIMER = None
         pst = probe.summary()
-        info = renderer.last_info
-        I_sorted = int(info["n_isects"])
+        I_sorted = int(renderer.last_info["n_isects"])
         Nv = int((renderer.radii > 0).sum())
+        # nothing may keep the last eager frame's autograd graph alive (its AccumulateGrad nodes belong to the eager stream; a
+        # capture on another stream that meets them drags that stream into the capture)
         renderer.forget()
+        gc.collect()
         launch = "one HIP graph replay per step"
         try:
             gstep = GraphedStep(compute, params={k: gp[k] for k in dp.GRAD_KEYS})
@@ -277,6 +279,36 @@ def side_section(workload, steps, losses=None, tight=True, shared=None, rank=0):
             _ops.forget_capacity_guesses(dev)
         gc.collect()
         torch.cuda.empty_cache()
+
+
+def child_workload(workload, losses, steps):
+    """Another BASELINE workload measured by THIS script in a process of its own (same method as the headline: graph replay,
+    pre-roll, device stamps around the dominant stage, counting step), started after the headline's timed region; returns the
+    fields of its JSON line that BASELINE.md section 2 asks for.  A process of its own, because a second and third HIP-graph
+    capture with other buffer sizes inside one process crashed the HIP runtime in hipStreamEndCapture on ROCm 7.2 (round 4,
+    gpurun_out/r04b) and a crash there must not take the headline line with it."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps), "--warmup", "3",
+           "--no-cpu-baseline", "--no-strict", "--no-extra-workloads"] + (["--losses", losses] if losses else [])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "DNSPLAT_FORCE_DIST")}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"workload": workload, "value": None, "error": repr(e)}
+    cfg, rv = d.get("config", {}), d.get("roofline_valu") or {}
+    return {"workload": cfg.get("workload"), "value": d.get("value"), "unit": d.get("unit"), "ms_per_step": d.get("ms_per_step"),
+            "steps": d.get("steps"), "launch": d.get("launch"), "losses": losses or "random dense cotangents",
+            "N": cfg.get("N"), "Nv": cfg.get("Nv"), "n_isects": cfg.get("n_isects"), "n_isects_sorted": cfg.get("n_isects_sorted"),
+            "mean_blended_gaussians_per_pixel": cfg.get("mean_blended_gaussians_per_pixel"),
+            "stages_ms": {k: v.get("ms") for k, v in (d.get("stages") or {}).items()},
+            "stages_GBps": {k: v.get("GBps") for k, v in (d.get("stages") or {}).items()},
+            "roofline": {k: (d.get("roofline") or {}).get(k) for k in ("kernel", "achieved", "frac", "ms_per_launch")},
+            "frame_roofline_frac": (d.get("frame_roofline") or {}).get("frac"),
+            "useful_pair_fraction": {k: v.get("useful_pair_fraction") for k, v in rv.items() if isinstance(v, dict) and "useful_pair_fraction" in v},
+            "measured": "a child process running this script on that workload, after the headline's timed region"}
 
 
 def main():
@@ -628,7 +660,7 @@ def main():
         if args.workload == "c2" and not args.no_extra_workloads and not args.losses:
             extras = {}
             for name, wl, ls in (("c3", "c3", None), ("c5", "c5", None), ("c5_fused_loss", "c5", "fused")):
-                extras[name] = side_section(wl, max(5, min(10, args.steps)), losses=ls, tight=True, rank=rank)
+                extras[name] = child_workload(wl, ls, max(5, min(10, args.steps)))
 
     # ---- multi-GPU accounting, all outside the timed region ----------------------------------------
     multi = None

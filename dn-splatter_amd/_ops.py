@@ -509,8 +509,9 @@ def project(means, quats, scales, opacities, *, coeffs=None, sh0=None, shN=None,
         means, quats, scales, opacities, coeffs, sh0, shN, colors, viewmat, K, normal_frame, cfg, saturation_flag, side)
     # tiles_per_gauss: gsplat's count (A.3), always.  tiles_bin: what dnsplat_bin_* must be given — the same tensor, or the count
     # over the tight boxes when cfg.tight_tiles (the flag travels WITH the counts: rasterize* take both from here)
-    return dict(means2d=m2d, depths=dep, conics=con, compensations=comp if comp.numel() else None, splats=splats,
-                radii=radii, tiles_per_gauss=tiles, normals_world=nworld if nworld.numel() else None,
+    # "was it asked for", not "has it elements": with N == 0 every output is empty and still has to be there
+    return dict(means2d=m2d, depths=dep, conics=con, compensations=comp if cfg.antialiased else None, splats=splats,
+                radii=radii, tiles_per_gauss=tiles, normals_world=nworld if cfg.want_normals_world else None,
                 tiles_bin=tiles_bin if cfg.tight_tiles else tiles, tight_tiles=bool(cfg.tight_tiles), tile_boxes=tile_boxes)
 
 

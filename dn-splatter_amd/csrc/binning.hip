@@ -50,6 +50,11 @@ constexpr int TI_THREADS = DNS_TI_THREADS;
 constexpr int TI_ITEMS = RS_THREADS * RS_ITEMS_I / TI_THREADS;
 static_assert(TI_THREADS * TI_ITEMS == RS_THREADS * RS_ITEMS_I && TI_THREADS % DNS_WAVE == 0 && TI_THREADS >= 256, "tile-pass chunk");
 constexpr int RS_DIGITS = 256;
+// Measured and removed (round 4): building the per-chunk digit counts of depth passes 1-3 with global atomics in the scatter kernel of
+// the pass before (nine launches instead of twelve).  Every lane of such an atomic hits another cache line (256 next digits x the
+// destination chunks), and scattered 4-byte atomics complete at ~12 G/s on this chip: 0.72 M of them cost 60 us per pass at C2 (a
+// histogram kernel: 6 us), 3.6 M cost 290 us at C5 (13 us) — binning 0.29 -> 1.16 ms.  The compositing backward's atomics are fast
+// because 16 neighbouring lanes share one 64-byte record; a histogram's do not.  LDS counters + one coalesced table row it stays.
 
 constexpr int SC_THREADS = 256;
 constexpr int SC_ITEMS = 8;
@@ -473,10 +478,14 @@ __global__ __launch_bounds__(TH) void radix_scatter_kernel(
 // ------------------------------------------------------------------------------------------------
 // 3. inclusive scan of tiles_per_gauss gathered in depth order  -> cum[n], total; n = the number of depth ranks (visible Gaussians),
 // a device word the first depth pass leaves behind
+// Also leaves the gathered counts in depth order (tiles_sorted): scan_final_kernel reads them coalesced instead of repeating the
+// random gather through `order` (at 5 M Gaussians: 57 -> 18 us).  Gathering the tile boxes here as well, for emit_prep_kernel, was
+// measured too: this kernel 54 -> 154 us for the 73 -> 19 us it saved there — a second random line per Gaussian costs the same
+// wherever it is fetched; left where it was.
 __global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(int N, const uint32_t *__restrict__ n_ptr,
                                                                const uint32_t *__restrict__ order,
                                                                const int32_t *__restrict__ tiles,
-                                                               uint32_t *__restrict__ sums)
+                                                               uint32_t *__restrict__ sums, uint32_t *__restrict__ tiles_sorted)
 {
     __shared__ uint32_t lds_wave[4];
     const int n = (int)min(*n_ptr, (uint32_t)N);
@@ -491,7 +500,11 @@ __global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(int N, const uint
 #pragma unroll
         for (int i = 0; i < SC_ITEMS; ++i) t[i] = (uint32_t)tiles[o[i]];
 #pragma unroll
-        for (int i = 0; i < SC_ITEMS; ++i) s += (base + i < n) ? t[i] : 0u;
+        for (int i = 0; i < SC_ITEMS; ++i)
+            if (base + i < n) {
+                s += t[i];
+                tiles_sorted[base + i] = t[i];
+            }
     }
     uint32_t tot;
     block_incl_scan_256(s, lds_wave, tot);
@@ -553,11 +566,9 @@ __global__ __launch_bounds__(SC_THREADS) void scan_final_kernel(int N, const uin
     uint32_t v[SC_ITEMS];
     uint32_t s = 0;
     {
-        uint32_t o[SC_ITEMS];          // as in scan_sums_kernel: all ranks, then all counts
+        // the counts in depth order, as scan_sums_kernel left them (`tiles` here IS that array: no gather through `order`)
 #pragma unroll
-        for (int i = 0; i < SC_ITEMS; ++i) o[i] = order[min(base + i, n - 1)];
-#pragma unroll
-        for (int i = 0; i < SC_ITEMS; ++i) v[i] = (uint32_t)tiles[o[i]];
+        for (int i = 0; i < SC_ITEMS; ++i) v[i] = (uint32_t)tiles[min(base + i, n - 1)];
 #pragma unroll
         for (int i = 0; i < SC_ITEMS; ++i) {
             if (base + i >= n) v[i] = 0u;
@@ -655,6 +666,7 @@ constexpr int MAX_CHUNKS = (int)((0x80000000ull + RS_THREADS * RS_ITEMS_I - 1) /
 struct BinWs {
     uint32_t *key_a, *key_b, *val_a, *val_b;  // [N]
     uint32_t *cum;                            // [N]
+    uint32_t *tiles_sorted;                   // [N] tile counts in depth order
     EmitRec *jrec;                            // [N]
     uint32_t *chunk_first;                    // [MAX_CHUNKS]
     uint32_t *tab_n;                          // [256 * nb_n]
@@ -692,6 +704,7 @@ BinWs carve(void *ws, int N, int64_t cap)
     // N-sized front: same layout for every capacity
     b.key_a = take(n); b.key_b = take(n); b.val_a = take(n); b.val_b = take(n);
     b.cum = take(n);
+    b.tiles_sorted = take(n);
     b.jrec = reinterpret_cast<EmitRec *>(take(4 * n));
     b.chunk_first = take(MAX_CHUNKS);
     b.tab_n = take((size_t)RS_DIGITS * b.nb_n);
@@ -947,7 +960,7 @@ extern "C" int dnsplat_bin_prepare(const dnsplat_bin_args *a, dnsplat_stream_t s
         }
         // after 4 passes the sorted order is back in val_a
         hipLaunchKernelGGL(scan_sums_kernel, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.n_ranked, w.val_a, a->tiles_per_gauss,
-                           w.sums);
+                           w.sums, w.tiles_sorted);
         EmitPrep ep;
         ep.jrec = w.jrec; ep.chunk_first = w.chunk_first; ep.nb_chunks = MAX_CHUNKS; ep.chunk = RS_THREADS * RS_ITEMS_I;
         ep.n_per_cam = N / (a->n_cameras > 1 ? a->n_cameras : 1);
@@ -957,7 +970,7 @@ extern "C" int dnsplat_bin_prepare(const dnsplat_bin_args *a, dnsplat_stream_t s
         ep.splats = a->tight_tiles ? reinterpret_cast<const float4 *>(a->splats) : nullptr;
         ep.boxes = reinterpret_cast<const int2 *>(a->tile_boxes);
         hipLaunchKernelGGL(scan_final_kernel, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.n_ranked, w.val_a,
-                           a->tiles_per_gauss, w.sums, w.cum, w.total, a->n_isects, a->n_isects_max);
+                           (const int32_t *)w.tiles_sorted, w.sums, w.cum, w.total, a->n_isects, a->n_isects_max);
         hipLaunchKernelGGL(emit_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, w.n_ranked, w.val_a, w.cum, ep);
         DNS_CHECK_LAUNCH();
     }

@@ -23,6 +23,7 @@ constexpr int LS_TW = 32, LS_TH = 16;          // output tile of one 256-thread 
 constexpr int LS_K = 11, LS_R = LS_K - 1;      // window, halo
 constexpr int LS_IW = LS_TW + LS_R, LS_IH = LS_TH + LS_R;
 constexpr int LS_THREADS = 256;
+constexpr int LS_SLOTS = 64;
 
 struct Gauss11 { float g[LS_K]; };
 
@@ -39,6 +40,8 @@ struct LossArgs {
     float *__restrict__ maps;             // [3][H,W,3] sensitivity maps a, b, c (only the valid-window region is written and read)
     float *__restrict__ v_rgb, *__restrict__ v_depth, *__restrict__ v_normal;
     float *__restrict__ sums;             // [8]: ssim, l1, ea_x, ea_y, n_l1, tv_h, tv_w, (unused)
+    float *__restrict__ slots;            // [LS_SLOTS][8] partial sums: a workgroup adds into copy blockIdx % LS_SLOTS (thousands of
+                                          // atomics on ONE address queue up behind each other), dn_loss_fold_kernel adds the copies up
     Gauss11 win;
 };
 
@@ -96,17 +99,40 @@ __global__ __launch_bounds__(LS_THREADS) void dn_ssim_stats_kernel(LossArgs a)
     const int VW = a.W - LS_R, VH = a.H - LS_R;               // valid window positions
     const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
     float ssim_sum = 0.f;
+    // The workgroup's whole input tile — all three channels of prediction and ground truth — is requested up front, one batch of
+    // loads per thread (out-of-image elements re-read a clamped pixel and are zeroed afterwards).  Loaded channel by channel inside
+    // the loop, every element was a load followed by its own wait: thirteen memory round trips in a row per workgroup (round 4).
+    constexpr int LD_IT = (LS_IH * LS_IW + LS_THREADS - 1) / LS_THREADS;
+    float px_[LD_IT][3], py_[LD_IT][3];
+    uint32_t in_mask = 0u;
+#pragma unroll
+    for (int it = 0; it < LD_IT; ++it) {
+        const int e = min((int)threadIdx.x + it * LS_THREADS, LS_IH * LS_IW - 1);
+        const int r = e / LS_IW, j = e - r * LS_IW;
+        const int yy = oy + r, xx = ox + j;
+        const bool in = yy < a.H && xx < a.W;
+        const size_t p = ((size_t)min(yy, a.H - 1) * a.W + min(xx, a.W - 1)) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { px_[it][c] = a.rgb[p + c]; py_[it][c] = a.gt_rgb[p + c]; }
+        in_mask |= (in ? 1u : 0u) << it;
+    }
+#pragma unroll
+    for (int it = 0; it < LD_IT; ++it)       // masked in a loop of its own: a use right behind each load would be waited for there
+        if (!((in_mask >> it) & 1u)) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { px_[it][c] = 0.f; py_[it][c] = 0.f; }
+        }
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
-        for (int e = threadIdx.x; e < LS_IH * LS_IW; e += LS_THREADS) {
-            const int r = e / LS_IW, j = e - r * LS_IW;
-            const int yy = oy + r, xx = ox + j;
-            float x = 0.f, y = 0.f;
-            if (yy < a.H && xx < a.W) {
-                const size_t p = ((size_t)yy * a.W + xx) * 3 + c;
-                x = a.rgb[p]; y = a.gt_rgb[p];
+#pragma unroll
+        for (int it = 0; it < LD_IT; ++it) {
+            const int e = (int)threadIdx.x + it * LS_THREADS;
+            if (e < LS_IH * LS_IW) {
+                const int r = e / LS_IW, j = e - r * LS_IW;
+                const float x = px_[it][c], y = py_[it][c];
+                in_tile[0][r][j] = x; in_tile[1][r][j] = y; in_tile[2][r][j] = x * x; in_tile[3][r][j] = y * y;
+                in_tile[4][r][j] = x * y;
             }
-            in_tile[0][r][j] = x; in_tile[1][r][j] = y; in_tile[2][r][j] = x * x; in_tile[3][r][j] = y * y;
-            in_tile[4][r][j] = x * y;
         }
         __syncthreads();
         float o[5][2];
@@ -131,7 +157,7 @@ __global__ __launch_bounds__(LS_THREADS) void dn_ssim_stats_kernel(LossArgs a)
         }
     }
     const float tot = block_sum(ssim_sum, red);
-    if (threadIdx.x == 0) atomicAdd(a.sums + 0, tot);
+    if (threadIdx.x == 0) atomicAdd(a.slots + 8 * ((blockIdx.y * gridDim.x + blockIdx.x) % LS_SLOTS) + 0, tot);
 }
 
 __global__ __launch_bounds__(LS_THREADS) void dn_loss_grad_kernel(LossArgs a)
@@ -148,17 +174,45 @@ __global__ __launch_bounds__(LS_THREADS) void dn_loss_grad_kernel(LossArgs a)
     const float w_l1 = (1.f - a.ssim_lambda) / (3.f * P), w_ss = -a.ssim_lambda / M;   // loss has + l (1 - mean s)
     float s_l1 = 0.f, s_eax = 0.f, s_eay = 0.f, s_nl1 = 0.f, s_tvh = 0.f, s_tvw = 0.f;
 
-    // ---- RGB: L1 + transposed blur of the SSIM sensitivities
+    // ---- RGB: L1 + transposed blur of the SSIM sensitivities.  As in the statistics kernel, everything the workgroup reads for the
+    // three channels (the sensitivity maps of its halo tile, prediction and ground truth of its own pixels) is requested up front.
+    constexpr int LD_IT = (LS_IH * LS_IW + LS_THREADS - 1) / LS_THREADS;
+    float ma[LD_IT][3], mb[LD_IT][3], mc[LD_IT][3];
+    uint32_t in_mask = 0u;
+#pragma unroll
+    for (int it = 0; it < LD_IT; ++it) {
+        const int e = min((int)threadIdx.x + it * LS_THREADS, LS_IH * LS_IW - 1);
+        const int r = e / LS_IW, j = e - r * LS_IW;
+        const int yy = oy + r - LS_R, xx = ox + j - LS_R;   // transposed window: input origin shifted by the halo
+        const bool in = yy >= 0 && xx >= 0 && yy < VH && xx < VW;
+        const size_t p = ((size_t)min(max(yy, 0), VH - 1) * W + min(max(xx, 0), VW - 1)) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { ma[it][c] = a.maps[p + c]; mb[it][c] = a.maps[plane + p + c]; mc[it][c] = a.maps[2 * plane + p + c]; }
+        in_mask |= (in ? 1u : 0u) << it;
+    }
+    float xk[2][3], yk[2][3];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = min(oy + ty + 8 * k, H - 1), j = min(ox + tx, W - 1);
+        const size_t p = ((size_t)i * W + j) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { xk[k][c] = a.rgb[p + c]; yk[k][c] = a.gt_rgb[p + c]; }
+    }
+#pragma unroll
+    for (int it = 0; it < LD_IT; ++it)       // masked only now: a use right behind each load would be waited for there
+        if (!((in_mask >> it) & 1u)) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { ma[it][c] = 0.f; mb[it][c] = 0.f; mc[it][c] = 0.f; }
+        }
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
-        for (int e = threadIdx.x; e < LS_IH * LS_IW; e += LS_THREADS) {
-            const int r = e / LS_IW, j = e - r * LS_IW;
-            const int yy = oy + r - LS_R, xx = ox + j - LS_R;   // transposed window: input origin shifted by the halo
-            float va = 0.f, vb = 0.f, vc = 0.f;
-            if (yy >= 0 && xx >= 0 && yy < VH && xx < VW) {
-                const size_t p = ((size_t)yy * W + xx) * 3 + c;
-                va = a.maps[p]; vb = a.maps[plane + p]; vc = a.maps[2 * plane + p];
+#pragma unroll
+        for (int it = 0; it < LD_IT; ++it) {
+            const int e = (int)threadIdx.x + it * LS_THREADS;
+            if (e < LS_IH * LS_IW) {
+                const int r = e / LS_IW, j = e - r * LS_IW;
+                in_tile[0][r][j] = ma[it][c]; in_tile[1][r][j] = mb[it][c]; in_tile[2][r][j] = mc[it][c];
             }
-            in_tile[0][r][j] = va; in_tile[1][r][j] = vb; in_tile[2][r][j] = vc;
         }
         __syncthreads();
         float o[3][2];
@@ -168,7 +222,7 @@ __global__ __launch_bounds__(LS_THREADS) void dn_loss_grad_kernel(LossArgs a)
             const int i = oy + ty + 8 * k, j = ox + tx;
             if (i < H && j < W) {
                 const size_t p = ((size_t)i * W + j) * 3 + c;
-                const float x = a.rgb[p], y = a.gt_rgb[p];
+                const float x = xk[k][c], y = yk[k][c];
                 const float d = x - y;
                 s_l1 += fabsf(d);
                 a.v_rgb[p] = w_l1 * sgn(d) + w_ss * (o[0][k] + 2.f * x * o[1][k] + y * o[2][k]);
@@ -185,29 +239,46 @@ __global__ __launch_bounds__(LS_THREADS) void dn_loss_grad_kernel(LossArgs a)
         const int i = oy + ty + 8 * k, j = ox + tx;
         if (i >= H || j >= W) continue;
         const size_t px = (size_t)i * W + j;
+        // every value the pixel's stencils read, requested together: neighbours beyond the image are clamped to the pixel itself and
+        // masked by the same conditions as before (the branchy form compiled to ~25 dependent round trips per pixel)
+        const bool has_r = j < W - 1, has_l = j > 0, has_b = i < H - 1, has_t = i > 0;
+        const size_t pr = has_r ? px + 1 : px, pl = has_l ? px - 1 : px, pb = has_b ? px + W : px, pt = has_t ? px - W : px;
+        float gd = 0.f, dd = 0.f, g0[3], gr[3], gb[3];
         if (a.gt_depth) {
-            const float gd = a.gt_depth[px];
+            gd = a.gt_depth[px]; dd = a.depth[px];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { g0[c] = yk[k][c]; gr[c] = a.gt_rgb[pr * 3 + c]; gb[c] = a.gt_rgb[pb * 3 + c]; }
+        }
+        float nc[3], nr[3], nl[3], nb[3], nt[3], gn[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            nc[c] = a.normal[px * 3 + c];
+            if (a.gt_normal) {
+                gn[c] = a.gt_normal[px * 3 + c];
+                nr[c] = a.normal[pr * 3 + c]; nl[c] = a.normal[pl * 3 + c]; nb[c] = a.normal[pb * 3 + c]; nt[c] = a.normal[pt * 3 + c];
+            }
+        }
+        if (a.gt_depth) {
             float vd = 0.f;
             if (gd > a.depth_tolerance) {
-                const float d = a.depth[px] - gd;
+                const float d = dd - gd;
                 const float l = logf(1.f + fabsf(d));
                 const float dl = sgn(d) / (1.f + fabsf(d));
                 // edge weights from the ground-truth image clamped at 10/255 (dn_model.py:633)
-                float g0[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) g0[c] = fmaxf(a.gt_rgb[px * 3 + c], 10.f / 255.f);
-                if (j < W - 1) {
+                for (int c = 0; c < 3; ++c) g0[c] = fmaxf(g0[c], 10.f / 255.f);
+                if (has_r) {
                     float m = 0.f;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) m += fabsf(g0[c] - fmaxf(a.gt_rgb[(px + 1) * 3 + c], 10.f / 255.f));
+                    for (int c = 0; c < 3; ++c) m += fabsf(g0[c] - fmaxf(gr[c], 10.f / 255.f));
                     const float lam = expf(-m / 3.f);
                     s_eax += lam * l;
                     vd += lam / n_x;
                 }
-                if (i < H - 1) {
+                if (has_b) {
                     float m = 0.f;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) m += fabsf(g0[c] - fmaxf(a.gt_rgb[(px + W) * 3 + c], 10.f / 255.f));
+                    for (int c = 0; c < 3; ++c) m += fabsf(g0[c] - fmaxf(gb[c], 10.f / 255.f));
                     const float lam = expf(-m / 3.f);
                     s_eay += lam * l;
                     vd += lam / n_y;
@@ -221,17 +292,17 @@ __global__ __launch_bounds__(LS_THREADS) void dn_loss_grad_kernel(LossArgs a)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const size_t p = px * 3 + c;
-            const float n = a.normal[p];
+            const float n = nc[c];
             float v = 0.f;
             if (a.gt_normal) {
-                const float d = n - a.gt_normal[p];
+                const float d = n - gn[c];
                 s_nl1 += fabsf(d);
                 v += w_nl1 * sgn(d);
                 // TVLoss (losses.py:279-295)
-                if (j < W - 1) { const float t = n - a.normal[p + 3]; s_tvh += fabsf(t); v += w_tvh * sgn(t); }
-                if (j > 0) v -= w_tvh * sgn(a.normal[p - 3] - n);
-                if (i < H - 1) { const float t = n - a.normal[p + (size_t)3 * W]; s_tvw += fabsf(t); v += w_tvw * sgn(t); }
-                if (i > 0) v -= w_tvw * sgn(a.normal[p - (size_t)3 * W] - n);
+                if (has_r) { const float t = n - nr[c]; s_tvh += fabsf(t); v += w_tvh * sgn(t); }
+                if (has_l) v -= w_tvh * sgn(nl[c] - n);
+                if (has_b) { const float t = n - nb[c]; s_tvw += fabsf(t); v += w_tvw * sgn(t); }
+                if (has_t) v -= w_tvw * sgn(nt[c] - n);
             }
             a.v_normal[p] = v;
         }
@@ -240,11 +311,56 @@ __global__ __launch_bounds__(LS_THREADS) void dn_loss_grad_kernel(LossArgs a)
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
         const float tot = block_sum(part[q], red);
-        if (threadIdx.x == 0 && tot != 0.f) atomicAdd(a.sums + 1 + q, tot);
+        if (threadIdx.x == 0 && tot != 0.f) atomicAdd(a.slots + 8 * ((blockIdx.y * gridDim.x + blockIdx.x) % LS_SLOTS) + 1 + q, tot);
     }
 }
 
+// sums[q] = sum over the LS_SLOTS copies (one wave)
+__global__ __launch_bounds__(DNS_WAVE) void dn_loss_fold_kernel(const float *__restrict__ slots, float *__restrict__ sums)
+{
+    const int q = threadIdx.x & 7, part = threadIdx.x >> 3;      // 8 lanes per quantity... 8 partial sums of LS_SLOTS / 8 copies each
+    float v = 0.f;
+    for (int s = part; s < LS_SLOTS; s += 8) v += slots[8 * s + q];
+#pragma unroll
+    for (int off = 32; off >= 8; off >>= 1) v += __shfl_xor(v, off, DNS_WAVE);
+    if (threadIdx.x < 8) sums[q] = v;
+}
+
+// dn-splatter's per-Gaussian scale regulariser (regularization_strategy.py:195-199): mean over the Gaussians of the SMALLEST
+// activated scale, min_k exp(s_k).  One lane per Gaussian: adds its term to *sum and writes the gradient row
+// d/d(s_k) = [k == argmin] exp(s_k) * weight  (weight = 1 / N for the mean; ties -> the first minimal component, as torch.min).
+__global__ __launch_bounds__(256) void scale_reg_kernel(int N, const float *__restrict__ scales, float weight,
+                                                        float *__restrict__ v_scales, float *__restrict__ sum)
+{
+    __shared__ float red[4];
+    float term_sum = 0.f;
+    // grid-stride: a few hundred workgroups, ONE atomic on the loss word each.  With a workgroup per 256 Gaussians the 19 500
+    // same-address atomics of a 5 M-Gaussian scene queued up behind each other: 253 us for a kernel that moves 120 MB (round 4).
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < N; g += gridDim.x * blockDim.x) {
+        const float e0 = expf(scales[3 * g]), e1 = expf(scales[3 * g + 1]), e2 = expf(scales[3 * g + 2]);
+        const int k = (e1 < e0) ? ((e2 < e1) ? 2 : 1) : ((e2 < e0) ? 2 : 0);
+        const float m = k == 0 ? e0 : (k == 1 ? e1 : e2);
+        const float term = m * weight;
+        term_sum += term;
+        v_scales[3 * g] = k == 0 ? term : 0.f;
+        v_scales[3 * g + 1] = k == 1 ? term : 0.f;
+        v_scales[3 * g + 2] = k == 2 ? term : 0.f;
+    }
+    const float tot = block_sum(term_sum, red);
+    if (threadIdx.x == 0 && tot != 0.f) atomicAdd(sum, tot);
+}
+
 }  // namespace
+
+extern "C" int dnsplat_scale_reg(int32_t N, const float *scales_log, float weight, float *v_scales, float *sum, dnsplat_stream_t stream)
+{
+    if (N < 0 || (N > 0 && (!scales_log || !v_scales)) || !sum) return DNSPLAT_ERR_INVALID_ARG;
+    if (N == 0) return DNSPLAT_OK;
+    const int blocks = (N + 255) / 256 < 1024 ? (N + 255) / 256 : 1024;
+    hipLaunchKernelGGL(scale_reg_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, scales_log, weight, v_scales, sum);
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}
 
 extern "C" int dnsplat_dn_loss(const dnsplat_dn_loss_args *u, dnsplat_stream_t stream_)
 {
@@ -264,11 +380,16 @@ extern "C" int dnsplat_dn_loss(const dnsplat_dn_loss_args *u, dnsplat_stream_t s
     double g[LS_K], tot = 0.0;
     for (int t = 0; t < LS_K; ++t) { const double x = t - LS_K / 2; g[t] = exp(-(x * x) / (2.0 * 1.5 * 1.5)); tot += g[t]; }
     for (int t = 0; t < LS_K; ++t) a.win.g[t] = (float)(g[t] / tot);
-    if (hipMemsetAsync(u->sums, 0, 8 * sizeof(float), stream) != hipSuccess) return DNSPLAT_ERR_LAUNCH;
+    // the partial sums live at the front of the scratch `maps` (9 H W floats, of which the kernels use the valid-window part): the
+    // first LS_SLOTS x 8 floats are NOT map entries — see LossArgs::maps below
+    a.slots = u->maps;
+    a.maps = u->maps + LS_SLOTS * 8;
+    if (hipMemsetAsync(a.slots, 0, LS_SLOTS * 8 * sizeof(float), stream) != hipSuccess) return DNSPLAT_ERR_LAUNCH;
     dim3 grid_v((a.W - LS_R + LS_TW - 1) / LS_TW, (a.H - LS_R + LS_TH - 1) / LS_TH);
     dim3 grid((a.W + LS_TW - 1) / LS_TW, (a.H + LS_TH - 1) / LS_TH);
     hipLaunchKernelGGL(dn_ssim_stats_kernel, grid_v, dim3(LS_THREADS), 0, stream, a);
     hipLaunchKernelGGL(dn_loss_grad_kernel, grid, dim3(LS_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(dn_loss_fold_kernel, dim3(1), dim3(DNS_WAVE), 0, stream, (const float *)a.slots, a.sums);
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;
 }

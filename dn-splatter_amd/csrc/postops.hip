@@ -16,12 +16,6 @@
 
 namespace {
 
-__device__ __forceinline__ float filled_depth(const float *__restrict__ depth, const float *__restrict__ alphas,
-                                              float dmax, int idx)
-{
-    return alphas[idx] > 0.f ? depth[idx] : dmax;
-}
-
 __global__ __launch_bounds__(256) void dn_depth_normals_kernel(int W, int H, float fx, float fy, float cx, float cy,
                                                                const float *__restrict__ depth,
                                                                const float *__restrict__ alphas,
@@ -32,14 +26,20 @@ __global__ __launch_bounds__(256) void dn_depth_normals_kernel(int W, int H, flo
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= W * H) return;
     const int i = idx / W, j = idx - i * W;
+    // all eleven loads of the pixel are issued together (neighbours clamped into the image, used only away from the border):
+    // `alpha > 0 ? depth[..] : dmax` per stencil point compiled to ten dependent round trips in a row
+    const bool inner = i >= 1 && i < H - 1 && j >= 1 && j < W - 1;
+    const int il = inner ? idx - 1 : idx, ir = inner ? idx + 1 : idx, it = inner ? idx - W : idx, ib = inner ? idx + W : idx;
     const float dmax = *depth_max;
-    depth_out[idx] = filled_depth(depth, alphas, dmax, idx);
+    const float a_c = alphas[idx], a_l = alphas[il], a_r = alphas[ir], a_t = alphas[it], a_b = alphas[ib];
+    const float d_c = depth[idx], d_l = depth[il], d_r = depth[ir], d_t = depth[it], d_b = depth[ib];
+    depth_out[idx] = a_c > 0.f ? d_c : dmax;
 
     float n0 = 0.f, n1 = 0.f, n2 = 0.f;
-    if (i >= 1 && i < H - 1 && j >= 1 && j < W - 1) {
+    if (inner) {
         // back-projection with pixel centres at +0.5 (camera_utils.py:92-144), c2w = identity
-        const float dl = filled_depth(depth, alphas, dmax, idx - 1), dr = filled_depth(depth, alphas, dmax, idx + 1);
-        const float dt = filled_depth(depth, alphas, dmax, idx - W), db = filled_depth(depth, alphas, dmax, idx + W);
+        const float dl = a_l > 0.f ? d_l : dmax, dr = a_r > 0.f ? d_r : dmax;
+        const float dt = a_t > 0.f ? d_t : dmax, db = a_b > 0.f ? d_b : dmax;
         // two reciprocals instead of eight divisions (the kernel is bound by them, not by its 49 MB): within 1-2 ulp of the
         // reference's (x - cx) * d / fx, against a test tolerance of 5e-6 on the [0, 1] normal image
         const float x = (float)j + 0.5f, y = (float)i + 0.5f, ifx = 1.f / fx, ify = 1.f / fy;

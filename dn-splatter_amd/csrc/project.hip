@@ -406,6 +406,20 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
     for (int vb = blockIdx.x; vb < (PHASE == 2 ? p.blocks : (int)blockIdx.x + 1); vb += gridDim.x) {
     if (PHASE == 2 && vb != (int)blockIdx.x) __syncthreads();      // the previous block's rows are still being read
     const int g = vb * blockDim.x + threadIdx.x;
+    // The lane's own parameters are requested BEFORE the coefficient rows are staged (and waited for after): one memory round trip
+    // for everything the Gaussian needs instead of three in a row (rows | camera | parameters).  A lane beyond N re-reads the last
+    // Gaussian and drops it below.
+    float mean[3], quat[4], sc_raw[3], opac_raw;
+    {
+        const int gc = min(g, p.s.N - 1);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) mean[i] = p.s.means[3 * gc + i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) quat[i] = p.s.quats[4 * gc + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sc_raw[i] = p.s.scales[3 * gc + i];
+        opac_raw = p.s.opacities[gc];
+    }
     if (L != SH_DIRECT && PHASE != 1) {
         const int g0 = vb * SH_STAGE_THREADS;
         const int nG = min(SH_STAGE_THREADS, p.s.N - g0);
@@ -426,9 +440,7 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
     if (g >= p.s.N) break;
     const Cam cam = load_cam(p.c.viewmat, p.c.K);
 
-    float mean[3], quat[4], sc_raw[3], sc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) mean[i] = p.s.means[3 * g + i];
+    float sc[3];
     if (PHASE == 2) {
         // colours only: same arithmetic, in the same order, as the one-launch kernel below
         float dx = mean[0] - cam.pos[0], dy = mean[1] - cam.pos[1], dz = mean[2] - cam.pos[2];
@@ -457,13 +469,8 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
         break;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) quat[i] = p.s.quats[4 * g + i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        sc_raw[i] = p.s.scales[3 * g + i];
-        sc[i] = p.s.scales_are_log ? expf(sc_raw[i]) : sc_raw[i];
-    }
-    float opac = p.s.opacities[g];
+    for (int i = 0; i < 3; ++i) sc[i] = p.s.scales_are_log ? expf(sc_raw[i]) : sc_raw[i];
+    float opac = opac_raw;
     if (p.s.opacities_are_logit) opac = sigmoidf(opac);
 
     Proj st;
@@ -639,6 +646,22 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int g0 = blockIdx.x * SH_STAGE_THREADS;
     const int nG = min(SH_STAGE_THREADS, p.s.N - g0);
+    // as in the forward: the lane's radius and parameters are requested before the coefficient rows are staged — one round trip
+    // instead of (rows | radius | parameters) in a row; the gradient record follows as soon as the radius says the Gaussian is
+    // visible, and travels while project_one() re-derives the projection
+    int32_t radius_g;
+    float mean[3], quat[4], sc_raw[3], opac_in;
+    {
+        const int gc = min(g, p.s.N - 1);
+        radius_g = p.g.radii[gc];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) mean[i] = p.s.means[3 * gc + i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) quat[i] = p.s.quats[4 * gc + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sc_raw[i] = p.s.scales[3 * gc + i];
+        opac_in = p.s.opacities[gc];
+    }
     if (L != SH_DIRECT) {
         const float *base = (L == SH_CAT ? p.s.sh0 : p.s.shN) + (size_t)g0 * ShRowTraits<L>::ROW;
         sh_stage_in<L>(base, nG * ShRowTraits<L>::ROW, sh_lds);
@@ -655,7 +678,13 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
     const int nbK = (p.s.sh_degree >= 0) ? (p.s.sh_degree + 1) * (p.s.sh_degree + 1) : 0;
 
     float v_mean[3] = {0.f, 0.f, 0.f}, v_quat[4] = {0.f, 0.f, 0.f, 0.f}, v_scale[3] = {0.f, 0.f, 0.f}, v_opac = 0.f;
-    const bool visible = p.g.radii[g] > 0;
+    const bool visible = radius_g > 0;
+    // the gradient record of a visible Gaussian: requested here, used after project_one()
+    float4 vrec[4];
+    if (visible) {
+        const float4 *vr4 = reinterpret_cast<const float4 *>(p.g.v_splats + (size_t)g * DNS_REC);
+        vrec[0] = vr4[0]; vrec[1] = vr4[1]; vrec[2] = vr4[2]; vrec[3] = vr4[3];
+    }
 
     // Gradient rows of culled Gaussians are zero; SH rows beyond the active degree are zero too.
     float *vsh0 = p.g.v_sh0 ? p.g.v_sh0 + (size_t)g * p.g.v_sh0_stride : nullptr;
@@ -664,19 +693,12 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
 
     Cam cam;
     Proj st;
-    float mean[3], quat[4], sc_raw[3], sc[3];
+    float sc[3];
     bool ok = false;
     if (visible) {
         cam = load_cam(p.c.viewmat, p.c.K);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) mean[i] = p.s.means[3 * g + i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) quat[i] = p.s.quats[4 * g + i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            sc_raw[i] = p.s.scales[3 * g + i];
-            sc[i] = p.s.scales_are_log ? expf(sc_raw[i]) : sc_raw[i];
-        }
+        for (int i = 0; i < 3; ++i) sc[i] = p.s.scales_are_log ? expf(sc_raw[i]) : sc_raw[i];
         ok = project_one(mean, quat, sc, cam, p.c.width, p.c.height, p.c.eps2d, p.c.near_plane, p.c.far_plane,
                          p.c.radius_clip, st);
     }
@@ -688,10 +710,9 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
         else if (vshN) for (int k = 0; k < 3 * restK; ++k) vshN[k] = 0.f;
         if (p.g.v_colors) for (int k = 0; k < p.s.n_colors; ++k) p.g.v_colors[(size_t)g * p.s.n_colors + k] = 0.f;
     } else {
-        const float4 *vr4 = reinterpret_cast<const float4 *>(p.g.v_splats + (size_t)g * DNS_REC);
         float vr[DNS_REC];
         {
-            float4 a = vr4[0], b = vr4[1], c = vr4[2], d = vr4[3];
+            const float4 a = vrec[0], b = vrec[1], c = vrec[2], d = vrec[3];
             vr[0] = a.x; vr[1] = a.y; vr[2] = a.z; vr[3] = a.w;
             vr[4] = b.x; vr[5] = b.y; vr[6] = b.z; vr[7] = b.w;
             vr[8] = c.x; vr[9] = c.y; vr[10] = c.z; vr[11] = c.w;
@@ -705,7 +726,6 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
         float v_comp = p.g.v_compensations ? p.g.v_compensations[g] : 0.f;
 
         // ---- opacity (A0 / antialiasing)
-        float opac_in = p.s.opacities[g];
         float opac_act = p.s.opacities_are_logit ? sigmoidf(opac_in) : opac_in;
         float v_o = vr[REC_OPAC];
         if (p.c.antialiased) { v_comp += v_o * opac_act; v_o *= st.compensation; }

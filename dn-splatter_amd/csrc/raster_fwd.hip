@@ -56,13 +56,14 @@ struct FwdArgs {
     long long zero_fill_vec4;
 };
 
-// The dn-splatter per-pixel post-ops (dn_model.py:526-528, 577-578) applied to one finished pixel.
-__device__ __forceinline__ float dn_epilogue(const FwdArgs &a, size_t pid, const float *raw, float al)
+// The dn-splatter per-pixel post-ops (dn_model.py:526-528, 577-578) applied to one finished pixel.  bg_rgb: the background colour,
+// loaded once by the caller (read here per pixel and channel, each read was a load followed by its own wait).
+__device__ __forceinline__ float dn_epilogue(const FwdArgs &a, size_t pid, const float *raw, float al, const float *bg_rgb)
 {
     const float one_minus = 1.f - al;   // the reference computes (1 - alpha) from the rounded alpha image
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-        a.dn_rgb[pid * 3 + c] = fminf(fmaxf(raw[c] + one_minus * a.bg_rgb[c], 0.f), 1.f);
+        a.dn_rgb[pid * 3 + c] = fminf(fmaxf(raw[c] + one_minus * bg_rgb[c], 0.f), 1.f);
     const float nx = raw[4], ny = raw[5], nz = raw[6];
     const float nrm = sqrtf(nx * nx + ny * ny + nz * nz);
     a.dn_normal[pid * 3 + 0] = (nx / nrm + 1.f) / 2.f;
@@ -307,8 +308,15 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
         __builtin_amdgcn_wave_barrier();
     }
 
-    // epilogue: background, expected-depth normalisation, stores
+    // epilogue: background, expected-depth normalisation, stores.  The (wave-uniform) background values are requested together, once
     float dmax = 0.f;
+    float bgk[D], bgc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < D; ++k) bgk[k] = a.background ? a.background[k] : 0.f;
+    if (DN) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bgc[c] = a.bg_rgb[c];
+    }
     if (in0) {
         const size_t pid = img + (size_t)py_i0 * a.width + px_i;
         const float al = 1.f - T0;
@@ -318,12 +326,12 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             float v = acc0[k];
-            if (a.background) v += T0 * a.background[k];
+            if (a.background) v += T0 * bgk[k];
             if (k == a.ed_channel) v = v / fmaxf(al, (float)DNS_ED_ALPHA_FLOOR);
             a.render[pid * D + k] = v;
             raw[k] = v;
         }
-        if (DN) dmax = fmaxf(dmax, dn_epilogue(a, pid, raw, al));
+        if (DN) dmax = fmaxf(dmax, dn_epilogue(a, pid, raw, al, bgc));
     }
     if (in1) {
         const size_t pid = img + (size_t)py_i1 * a.width + px_i;
@@ -334,12 +342,12 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             float v = acc1[k];
-            if (a.background) v += T1 * a.background[k];
+            if (a.background) v += T1 * bgk[k];
             if (k == a.ed_channel) v = v / fmaxf(al, (float)DNS_ED_ALPHA_FLOOR);
             a.render[pid * D + k] = v;
             raw[k] = v;
         }
-        if (DN) dmax = fmaxf(dmax, dn_epilogue(a, pid, raw, al));
+        if (DN) dmax = fmaxf(dmax, dn_epilogue(a, pid, raw, al, bgc));
     }
     if (DN) {
         // image-wide max of the expected depth (dn_model.py:535 `depth_im.detach().max()`): depths are >= 0,

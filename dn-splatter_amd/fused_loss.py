@@ -3,7 +3,7 @@
 ``dn_loss_fused`` computes what ``torch_losses.dn_loss`` (the PyTorch restatement of
 ``DNSplatterModel.get_loss_dict``, dn_splatter/dn_model.py:614-729) computes — same value, same gradients w.r.t. the
 rendered rgb / depth / normal images — but with the cotangents produced directly by ``dnsplat_dn_loss`` instead of by
-autograd over ~120 torch kernels.  The per-Gaussian min-scale term stays a torch expression.
+autograd over ~120 torch kernels; the per-Gaussian min-scale term is one more launch (``dnsplat_scale_reg``).
 """
 from __future__ import annotations
 
@@ -33,7 +33,7 @@ class _DnLossFn(torch.autograd.Function):
         H, W = rgb.shape[0], rgb.shape[1]
         dev = rgb.device
         f32 = dict(dtype=torch.float32, device=dev)
-        maps = torch.empty(9, H, W, **f32)
+        maps = torch.empty(9 * H * W + 512, **f32)      # dnsplat_dn_loss_args.maps: scratch
         v_rgb = torch.empty(H, W, 3, **f32)
         v_depth = torch.empty(depth.shape, **f32)
         v_normal = torch.empty(H, W, 3, **f32)
@@ -66,6 +66,25 @@ class _DnLossFn(torch.autograd.Function):
         return (v_rgb * g, v_depth * g, v_normal * g) + (None,) * 7
 
 
+class _ScaleRegFn(torch.autograd.Function):
+    """mean_g min_k exp(scales[g, k]) (regularization_strategy.py:195-199) and its gradient in one launch (dnsplat_scale_reg)."""
+
+    @staticmethod
+    def forward(ctx, scales):
+        scales = _f32c(scales, "scales")
+        N = scales.shape[0]
+        v = torch.empty_like(scales)
+        total = torch.zeros((), dtype=torch.float32, device=scales.device)
+        _lib.run("dnsplat_scale_reg", _lib.lib().dnsplat_scale_reg, N, _ptr(scales), 1.0 / max(N, 1), _ptr(v), _ptr(total), _stream())
+        ctx.save_for_backward(v)
+        return total
+
+    @staticmethod
+    def backward(ctx, g):
+        (v,) = ctx.saved_tensors
+        return v * g
+
+
 def dn_loss_fused(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], scales: Tensor, ssim_lambda: float = 0.2,
                   depth_lambda: float = 0.2, depth_tolerance: float = 0.1, counts: Optional[Tensor] = None) -> Tensor:
     """Drop-in for ``torch_losses.dn_loss`` (mono depth + mono normal supervision)."""
@@ -74,4 +93,4 @@ def dn_loss_fused(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], scales: 
         counts = depth_counts(gt_depth, depth_tolerance)
     per_pixel = _DnLossFn.apply(outputs["rgb"], outputs["depth"], outputs["normal"], batch["image"], gt_depth,
                                 batch.get("normal"), counts, ssim_lambda, depth_lambda, depth_tolerance)
-    return per_pixel + torch.min(torch.exp(scales), dim=1, keepdim=True)[0].mean()   # regularization_strategy.py:195-199
+    return per_pixel + _ScaleRegFn.apply(scales)                                      # regularization_strategy.py:195-199

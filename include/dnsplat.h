@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DNSPLAT_ABI_VERSION 10
+#define DNSPLAT_ABI_VERSION 11
 #define DNSPLAT_RECORD_FLOATS 16
 #define DNSPLAT_MAX_CHANNELS 8
 
@@ -384,12 +384,18 @@ typedef struct dnsplat_dn_loss_args {
     const float *gt_normal;    /* [H,W,3] or NULL (no normal losses) */
     const float *depth_counts; /* device [2]: number of pixels with gt_depth > tolerance in columns < W-1, in rows < H-1 */
     float ssim_lambda, depth_weight, depth_tolerance;
-    float *maps;               /* scratch [9, H, W] floats */
+    float *maps;               /* scratch, 9 H W + 512 floats (512 partial-sum words in front of three [H,W,3] maps) */
     float *v_rgb, *v_depth, *v_normal;   /* out, shapes of rgb / depth / normal */
     float *sums;               /* out device [8] */
 } dnsplat_dn_loss_args;
 
 int dnsplat_dn_loss(const dnsplat_dn_loss_args *args, dnsplat_stream_t stream);
+
+/* The per-Gaussian term of the same loss (regularization_strategy.py:195-199): mean_g min_k exp(scales[g][k]).  Adds
+ * weight * sum_g min_k exp(s_gk) to *sum (device scalar, caller zeroes it) and WRITES the gradient rows
+ * v_scales[g][k] = [k == argmin_k] * weight * exp(s_gk); weight = 1 / N gives the mean.  Replaces torch's exp / min / mean and their
+ * five backward kernels over [N,3] tensors. */
+int dnsplat_scale_reg(int32_t N, const float *scales_log, float weight, float *v_scales /* [N,3] */, float *sum, dnsplat_stream_t stream);
 
 /* ------------------------------------------------------------------ stage 5
  * Fused per-Gaussian back end: gradient record -> parameter gradients.
