@@ -321,8 +321,16 @@ __global__ __launch_bounds__(SC_THREADS) void radix_scan_kernel(uint32_t *__rest
 // GEN: the first pass of the tile sort — keys / values are the pairs the workgroup re-creates (GenArgs), nothing is read.
 // tile_end (LAST, optional): one past the last entry of every non-empty tile, so that a consumer that takes both arrays needs
 // no suffix-minimum fill of the offsets of the empty tiles.
+// DNS_TI_WAVES_PER_EU: register budget of the 512-thread tile-pass instantiations.  8 waves per SIMD = 64 VGPRs would admit a fourth
+// workgroup per CU (hipcc's own choice: 72 VGPRs = three; the LDS tables, 30 KB since round 4, no longer stand in the way), but the
+// nine values that no longer fit are spilled inside the ranking loop: measured +10 % on the binning stage at C2 and +7 % at C5.
+// 1 = leave the choice to the compiler.
+#ifndef DNS_TI_WAVES_PER_EU
+#define DNS_TI_WAVES_PER_EU 1
+#endif
+#define DNS_TI_OCCUPANCY(th, K) __attribute__((amdgpu_waves_per_eu(((th) == 512 && sizeof(K) == 2) ? DNS_TI_WAVES_PER_EU : 1, 8)))
 template <typename K, bool LAST, int DBITS, int ITEMS, bool FIRST = false, bool GEN = false, int TH = RS_THREADS>
-__global__ __launch_bounds__(TH) void radix_scatter_kernel(
+__global__ __launch_bounds__(TH) DNS_TI_OCCUPANCY(TH, K) void radix_scatter_kernel(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ n_ptr, uint32_t n_cap, int shift,
     const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nb, int32_t *__restrict__ tile_first,
@@ -334,10 +342,14 @@ __global__ __launch_bounds__(TH) void radix_scatter_kernel(
     // ranking registers sends the 64 lanes of one store instruction to up to 64 different cache lines and
     // ran at a quarter of this version's rate on the 21 M-entry tile passes.
     constexpr int NW = TH / DNS_WAVE;
-    __shared__ uint32_t wave_cnt[NW][RS_DIGITS];
-    __shared__ uint32_t wave_loc[NW][RS_DIGITS];         // chunk-local position of a (wave, digit) run
-    __shared__ uint32_t dstart[RS_DIGITS];               // chunk-local start of a digit's run
-    __shared__ uint32_t gbase[RS_DIGITS];                // global start of this chunk's run of a digit
+    constexpr int ND = 1 << DBITS;                       // digits of this pass: the LDS tables are sized for them, not for 256
+    __shared__ uint32_t wave_cnt[NW][ND];
+    // chunk-local position of a (wave, digit) run: written over the counts it is computed from (the thread of digit d reads its
+    // column of counts into registers, then writes the positions) — together with the ND sizing 43 -> 30 KB of LDS per workgroup
+    // of the tile passes (measured: +-0 at C2, -0.4 % at C5 — the register count, not LDS, holds these kernels at three workgroups per CU)
+    uint32_t (*wave_loc)[ND] = wave_cnt;
+    __shared__ uint32_t dstart[ND];                      // chunk-local start of a digit's run
+    __shared__ uint32_t gbase[ND];                       // global start of this chunk's run of a digit
     constexpr int CHUNK = TH * ITEMS;
     __shared__ K keys_s[CHUNK];
     // GEN: the owner table (dead once the pairs sit in registers) shares the memory of the value staging area
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(TH) void radix_scatter_kernel(
     const uint32_t pre_tot = is_digit ? totals[threadIdx.x] : 0u;
     const uint32_t pre_tab = is_digit ? table[(size_t)threadIdx.x * nb + blockIdx.x] : 0u;
 
-    if (threadIdx.x < RS_DIGITS) {
+    if (threadIdx.x < ND) {
 #pragma unroll
         for (int i = 0; i < NW; ++i) wave_cnt[i][threadIdx.x] = 0;
     }
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(TH) void radix_scatter_kernel(
     uint32_t n_out = n_valid;
     {
         // digit d = threadIdx.x (threads beyond the 256 digits only take part in the scans)
-        const bool has_digit = threadIdx.x < RS_DIGITS;
+        const bool has_digit = threadIdx.x < ND;
         uint32_t cw[NW];
         uint32_t cnt = 0;
 #pragma unroll
