@@ -26,6 +26,7 @@
 // caller bounds it with `isect_capacity`).
 
 #include "splat_common.h"
+#include "bin_ranges.h"
 
 namespace {
 
@@ -279,6 +280,70 @@ __global__ __launch_bounds__(TH) void radix_hist_kernel(const K *__restrict__ ke
     }
     __syncthreads();
     if (threadIdx.x <= mask) table[(size_t)threadIdx.x * nb + blockIdx.x] = hist[threadIdx.x];
+}
+
+// The GEN histogram without generating a single pair (round 4; bin_ranges.h): every record that has pairs inside the workgroup's
+// chunk adds its box rows as cyclic digit RANGES to a difference array in LDS (two or three LDS atomics per box row instead of an
+// owner search, a 16-byte record gather and an LDS atomic per pair), a prefix sum turns the differences into the counts.  One thread
+// per record: the chunk's ~200 (C2) records are one round of coalesced 16-byte loads.  Same table as radix_hist_kernel<.., GEN>.
+// DNS_GEN_HIST_RANGES = 0 keeps the pair-generating histogram (A/B).
+#ifndef DNS_GEN_HIST_RANGES
+#define DNS_GEN_HIST_RANGES 1
+#endif
+template <int ITEMS, int TH>
+__global__ __launch_bounds__(TH) void radix_hist_ranges_kernel(const uint32_t *__restrict__ n_ptr, uint32_t n_cap, int dbits,
+                                                               uint32_t *__restrict__ table, int nb, int32_t *__restrict__ tile_first,
+                                                               int n_tiles, int32_t *__restrict__ tile_end, GenArgs gen,
+                                                               uint32_t *__restrict__ status)
+{
+    __shared__ uint32_t diff[RS_DIGITS + 1];       // diff[ND] is a sink for ranges that end at the last digit
+    __shared__ uint32_t all_s;                     // what every digit receives (rows longer than 2^dbits tiles)
+    __shared__ uint32_t lds_wave[TH / DNS_WAVE];
+    static_assert(TH > RS_DIGITS, "one thread per difference slot");
+    const uint32_t n = n_ptr ? min(*n_ptr, n_cap) : n_cap;
+    // the duties of the first histogram pass of the tile sort (see radix_hist_kernel): tile offsets preset to n, tile ends to 0
+    if (tile_first)
+        for (int i = blockIdx.x * TH + threadIdx.x; i <= n_tiles; i += gridDim.x * TH) tile_first[i] = (int32_t)n;
+    if (tile_end)
+        for (int i = blockIdx.x * TH + threadIdx.x; i < n_tiles; i += gridDim.x * TH) tile_end[i] = 0;
+    if (status && blockIdx.x == 0 && threadIdx.x == 0) *status = 0u;
+    const uint32_t ND = 1u << dbits;
+    if (threadIdx.x <= ND) diff[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) all_s = 0u;
+    __syncthreads();
+    const uint32_t q0 = blockIdx.x * (uint32_t)(TH * ITEMS);
+    if (q0 < n) {
+        const uint32_t q1 = q0 + min((uint32_t)(TH * ITEMS), n - q0);
+        const uint32_t j0 = gen.chunk_first[blockIdx.x];
+        const uint32_t n_ranked = min(*gen.n_ranked, (uint32_t)gen.N);
+        uint32_t all = 0u;
+        for (uint32_t jb = j0;; jb += TH) {
+            const uint32_t jj = jb + threadIdx.x;
+            bool inside = false;       // this record starts before the end of the chunk (cum is non-decreasing: so do all before it)
+            if (jj < n_ranked) {
+                const uint32_t e = gen.cum[jj], s = jj ? gen.cum[jj - 1] : 0u;
+                inside = s < q1;
+                if (inside && e > s && e > q0) {        // records without pairs are never written (emit_prep_kernel): not read either
+                    const uint4 r = *reinterpret_cast<const uint4 *>(gen.jrec + jj);
+                    all += dns_record_digit_ranges(r.z, r.w, (uint32_t)gen.tw, max(s, q0) - s, min(e, q1) - s, dbits,
+                                                   [&](uint32_t d0, uint32_t len) {
+                                                       atomicAdd(&diff[d0], 1u);
+                                                       const uint32_t end = d0 + len;
+                                                       if (end <= ND) atomicAdd(&diff[end], 0xFFFFFFFFu);
+                                                       else { atomicAdd(&diff[0], 1u); atomicAdd(&diff[end - ND], 0xFFFFFFFFu); }
+                                                   });
+                }
+            }
+            // another round only if the last record of this one still started inside the chunk
+            if (!__syncthreads_or(inside && threadIdx.x == TH - 1)) break;
+        }
+        if (all) atomicAdd(&all_s, all);
+    }
+    __syncthreads();
+    const uint32_t v = threadIdx.x < ND ? diff[threadIdx.x] : 0u;      // differences modulo 2^32: the prefix sums are the true counts
+    uint32_t tot;
+    const uint32_t inc = block_incl_scan<TH / DNS_WAVE>(v, lds_wave, tot);
+    if (threadIdx.x < ND) table[(size_t)threadIdx.x * nb + blockIdx.x] = inc + all_s;
 }
 
 // one workgroup per digit: exclusive scan of table[d][0..nb) in place, totals[d] = row sum.  Eight consecutive
@@ -752,7 +817,10 @@ void radix_pass(hipStream_t stream, const K *ka, const uint32_t *va, K *kb, uint
         return;
     }
     const GenArgs g = gen ? *gen : GenArgs{};
-    if (gen)
+    if (gen && DNS_GEN_HIST_RANGES && shift == 0 && TH > RS_DIGITS)
+        hipLaunchKernelGGL((radix_hist_ranges_kernel<ITEMS, (TH > RS_DIGITS ? TH : 2 * RS_DIGITS)>), dim3(nb), dim3(TH), 0, stream, n_ptr, n_cap, dbits,
+                           table, nb, init_offsets, n_tiles, init_offsets ? tile_end : nullptr, g, status);
+    else if (gen)
         hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS, false, true, TH>), dim3(nb), dim3(TH), 0, stream, ka, n_ptr, n_cap, shift, mask,
                            table, nb, (const int32_t *)nullptr, (const float *)nullptr, init_offsets, n_tiles, init_offsets ? tile_end : nullptr, g, status);
     else

@@ -138,6 +138,31 @@ constexpr int TILE = 16;
 #ifndef DNS_BWD_FLUSH_ALL
 #define DNS_BWD_FLUSH_ALL 1
 #endif
+// round 4, from the ISA of the step: the magnitude sums of the mean gradient as v_fma_f32 |a|, |b|, acc (the products are no longer
+// formed twice) and the second channel group's share of d/d(alpha) as two chained packed FMAs: 42 -> 39 packed instructions per step
+// Idle slots read and write a DUMMY pixel row (row NPIX: zero cotangents, last index -1, x of column 0) instead of aliasing a live
+// one: "this lane is between two buckets" then needs no term in the pair's validity (no list index is <= -1), the state store
+// needs no narrowed exec, and the row index is a select instead of a mask — four scalar instructions per step less (s_and x 2,
+// s_and_saveexec, s_or), the vector count unchanged.  The folded arrays' pixel windows start at multiples of 16 for it (the dummy
+// row's "x of the next pixel" slot can only name one column): 48 + 48 + 16 + 16 instead of 56 + 40 + 24 + 8 pixels for a four-fold
+// bucket, which then lasts 79 instead of 71 steps.  Needs DNS_BWD_LDS_STATE, DNS_BWD_PX_SLOT, DNS_BWD_FOLD, no coordinate table.
+#ifndef DNS_BWD_DUMMY_ROW
+#define DNS_BWD_DUMMY_ROW 0
+#endif
+// the group switch requests its two list entries together and its two records together (two memory round trips instead of four)
+// dx of the next step formed at the end of the current one (see the step loop)
+#ifndef DNS_BWD_DX_CARRY
+#define DNS_BWD_DX_CARRY 0
+#endif
+#ifndef DNS_BWD_BATCHED_SWITCH
+#define DNS_BWD_BATCHED_SWITCH 0
+#endif
+#ifndef DNS_BWD_ABS_FMA
+#define DNS_BWD_ABS_FMA 1
+#endif
+#ifndef DNS_BWD_VA_CHAIN
+#define DNS_BWD_VA_CHAIN 1
+#endif
 #ifndef DNS_BWD_FOLD
 #define DNS_BWD_FOLD 1
 #endif
@@ -285,7 +310,7 @@ template <int D, int SPLIT, bool DN, bool COUNT = false, bool MASKS = false, boo
 __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT && !DET) void raster_bwd_kernel(BwdArgs a)
 {
     if (a.sat_flag && (*a.sat_flag != 0u) != CLAMP_LOOP) return;
-    __shared__ float4 pix[NPIX][3];            // [p][0..1] = v_k, [p][2] = (S_a, T, S_b, bin_final) (DNS_BWD_PAIR_STATE) or (T, S_a, S_b, bin_final)
+    __shared__ float4 pix[NPIX + (DNS_BWD_DUMMY_ROW ? 1 : 0)][3];   // [p][0..1] = v_k, [p][2] = (S_a, T, S_b, bin_final) (DNS_BWD_PAIR_STATE) or (T, S_a, S_b, bin_final)
     // compacted list indices waiting for a bucket (never more than 127 + 64) + the 1 KiB staging area of the transposed flush, which
     // ALIASES queue entries >= 64: while a pass is flushed only the < 64 left-over entries at the front of the queue are
     // live.  13.5 KiB per wave = 12 tiles in flight per CU (3 waves per SIMD, the VGPR limit) instead of 11.
@@ -418,6 +443,15 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT &
     hi = __builtin_amdgcn_readfirstlane(hi);
     hi = min(hi, range_end - 1);
     if (hi < range_start) return;
+#if DNS_BWD_DUMMY_ROW
+    static_assert(DNS_BWD_LDS_STATE && DNS_BWD_PAIR_STATE && DNS_BWD_PX_SLOT && DNS_BWD_FOLD && !DNS_BWD_COORD_TABLE && !DNS_BWD_PREVALID && GROUP == 16,
+                  "the dummy row replaces the exec-narrowed state store of the LDS hand-off");
+    if (lane == 0) {     // what a lane in an idle slot reads: nothing to add, no entry to replay, column 0 next; its state store lands here too
+        pix[NPIX][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pix[NPIX][1] = make_float4(0.f, 0.f, 0.f, (float)tile_x0 + 0.5f);
+        pix[NPIX][2] = make_float4(0.f, 1.f, 0.f, __int_as_float(-1));
+    }
+#endif
     __builtin_amdgcn_wave_barrier();
 
     const float fx0 = (float)tile_x0 + 0.5f, fy0 = (float)tile_y0 + 0.5f;
@@ -455,6 +489,10 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT &
     [[maybe_unused]] int p_first = 0, p_count = NPIX;
     [[maybe_unused]] bool folded = false;          // the bucket in the lanes is a folded (hence the last) one (wave-uniform)
     [[maybe_unused]] float T_out = 0.f, SA_out = 0.f, SB_out = 0.f;
+    [[maybe_unused]] int qs = -(1 << 24), qs_lim = 0;   // DNS_BWD_DUMMY_ROW: 16 x (position in the lane's pixel window), 16 x (its length)
+    [[maybe_unused]] float fy_arr = 0.f;          // DNS_BWD_DUMMY_ROW: y of the centre of the window's first pixel row
+    [[maybe_unused]] uint32_t row_run = 0;        // DNS_BWD_DUMMY_ROW: LDS address of the row of the lane's pixel counter
+    [[maybe_unused]] f2 dx_cur = zero2;           // DNS_BWD_DX_CARRY: sx - (x of the pixel of the coming step), formed at the end of the step before
     [[maybe_unused]] float px_cur = 0.f;          // DNS_BWD_PX_SLOT: x of the centre of the pixel the lane works on in the coming step
 
     const int col = lane & 15;
@@ -583,6 +621,21 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT &
                 const int idx_b = 2 * ll + 1 < take ? queue[2 * ll + 1] : -1;
                 float4 ra0 = make_float4(0.f, 0.f, 0.f, 0.f), ra1 = ra0, ra2 = ra0, ra3 = ra0;
                 float4 rb0 = ra0, rb1 = ra0, rb2 = ra0, rb3 = ra0;
+#if DNS_BWD_BATCHED_SWITCH
+                // Both list entries, then both records, each pair of requests in flight together and no branch around them: written as
+                // `if (idx >= 0) { gid = ids[idx]; rec = splats[gid]; }` twice, the group's lanes went through FOUR memory round trips in a
+                // row per switch (id A, record A, id B, record B; from the ISA).  An empty slot re-reads the list's first entry — a real
+                // record, so its arithmetic stays finite — and is kept out of every pair by its "no entry" index (cmp = 0x7fffffff is
+                // above every pixel's last index, and such a slot is not flushed).
+                gid_a = a.flatten_ids[max(idx_a, range_start)];
+                gid_b = a.flatten_ids[max(idx_b, range_start)];
+                {
+                    const float4 *reca = a.splats + (size_t)gid_a * 4, *recb = a.splats + (size_t)gid_b * 4;
+                    ra0 = reca[0]; ra1 = reca[1]; rb0 = recb[0]; rb1 = recb[1];
+                    if (D > 2) { ra2 = reca[2]; rb2 = recb[2]; }
+                    if (D > 6) { ra3 = reca[3]; rb3 = recb[3]; }
+                }
+#else
                 gid_a = 0; gid_b = 0;
                 if (idx_a >= 0) {
                     gid_a = a.flatten_ids[idx_a];
@@ -598,6 +651,7 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT &
                     if (D > 2) rb2 = rec[2];
                     if (D > 6) rb3 = rec[3];
                 }
+#endif
                 sx = f2{ra0.x, rb0.x}; sy = f2{ra0.y, rb0.y};
                 ca = f2{ra0.z, rb0.z}; cb = f2{ra0.w, rb0.w}; cc = f2{ra1.x, rb1.x}; opac = f2{ra1.y, rb1.y};
                 const DnsConicE qa = dns_conic_e(ra0.z, ra0.w, ra1.x), qb = dns_conic_e(rb0.z, rb0.w, rb1.x);
@@ -613,15 +667,32 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT &
 #if DNS_BWD_FOLD
                 // pixel shares: array j starts 16 j (fold 4) / 32 j (fold 2) steps after array 0 and all end together
                 const int arr = lane / fold_lanes;
+#if DNS_BWD_DUMMY_ROW
+                // windows that start at column 0 (see DNS_BWD_DUMMY_ROW): 48 | 48 | 16 | 16.  Array j starts 16 j steps after array 0 and
+                // may only start at a pixel the PREVIOUS bucket has finished with: lane 63 of the full array works on pixel p at step
+                // p - 80 of the new bucket, so p_first <= 16 j + 79 (95, 111, 127) — 64 | 48 | 16 | 0 would start array 2 at pixel
+                // 112 in the very step lane 63 still holds it (found as a wrong gradient by tests/test_gpu_determinism.py)
+                p_first = fold == 4 ? (arr == 0 ? 0 : arr == 1 ? 48 : arr == 2 ? 96 : 112) * NPIX / 128
+                        : fold == 2 ? (arr == 0 ? 0 : 80) * NPIX / 128 : 0;
+                p_count = fold == 4 ? (arr == 0 ? 48 : arr == 1 ? 48 : arr == 2 ? 16 : 16) * NPIX / 128
+                        : fold == 2 ? (arr == 0 ? 80 : 48) * NPIX / 128 : NPIX;
+#else
                 p_first = fold == 4 ? (arr == 0 ? 0 : arr == 1 ? 56 : arr == 2 ? 96 : 120) * NPIX / 128
                         : fold == 2 ? (arr == 0 ? 0 : 80) * NPIX / 128 : 0;
                 p_count = fold == 4 ? (arr == 0 ? 56 : arr == 1 ? 40 : arr == 2 ? 24 : 8) * NPIX / 128
                         : fold == 2 ? (arr == 0 ? 80 : 48) * NPIX / 128 : NPIX;
+#endif
                 p = p_first - (lane % GROUP);
 #else
                 p = -(lane % GROUP);
 #endif
                 px_cur = fx0 + (float)(p & 15);
+                if (DNS_BWD_DX_CARRY && D < 8) dx_cur = sx - px_cur;
+#if DNS_BWD_DUMMY_ROW
+                row_run = pix_base + (uint32_t)(p * 48);
+                qs = -16 * (lane % GROUP); qs_lim = 16 * p_count;
+                fy_arr = fy0 + (float)(p_first >> 4);
+#endif
 #if DNS_BWD_COORD_TABLE
                 { const float2 c = coord[p & (NPIX - 1)]; pxy = f2{c.x, c.y}; }
 #endif
@@ -629,7 +700,7 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT &
             int nsteps = grp < NGROUP - 1 ? GROUP : PERIOD - GROUP * (NGROUP - 1);
 #if DNS_BWD_FOLD
             // a folded bucket: every array ends (its start) + (its lanes - 1) + (its pixels) steps after the bucket's start
-            if (grp == NGROUP - 1 && fold > 1) nsteps = (fold == 4 ? 15 + 56 * NPIX / 128 : 31 + 80 * NPIX / 128) - GROUP * (NGROUP - 1);
+            if (grp == NGROUP - 1 && fold > 1) nsteps = (fold == 4 ? 15 + (DNS_BWD_DUMMY_ROW ? 64 : 56) * NPIX / 128 : 31 + 80 * NPIX / 128) - GROUP * (NGROUP - 1);
             if (grp == NGROUP - 1) folded = fold > 1;
             if (flush_only) continue;                                     // nothing left to stream
 #endif
@@ -655,23 +726,40 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT &
             auto step_loop = [&](auto clamp_tag) {
             constexpr bool CLAMP = decltype(clamp_tag)::value;
             for (int s = 0; s < nsteps; ++s) {
-#if DNS_BWD_FOLD
+#if DNS_BWD_DUMMY_ROW
+                // the lane's position in its pixel window, times 16 (qs): "active" is one unsigned compare, and the pixel row of the window is
+                // byte 1 of the counter, which v_cvt_f32_ubyte1 converts without a shift (the windows start at multiples of 16 pixels)
+                const bool active = (unsigned)qs < (unsigned)qs_lim;
+                v4f c0, c1, cst;
+                const uint32_t row_addr = active ? row_run : pix_base + NPIX * 48;   // an idle slot reads (and writes back) the dummy row
+                row_run += 48;                                         // LDS address of the row of the lane's pixel, carried along
+                row_issue(row_addr, c0, c1, cst, qs);                  // the counter itself is the token: no copy of it
+                [[maybe_unused]] const int pcur = qs >> 4;             // D == 8 only (no "x of the next pixel" slot): column = pcur & 15
+#elif DNS_BWD_FOLD
                 const bool active = (unsigned)(p - p_first) < (unsigned)p_count;
 #else
                 const bool active = (unsigned)p < (unsigned)NPIX;
 #endif
+#if DNS_BWD_DUMMY_ROW
+#else
                 int pcur = p & (NPIX - 1);
                 v4f c0, c1, cst;
                 const uint32_t row_addr = pix_base + pcur * 48;        // LDS byte address of the pixel's row (read now, state written back at the end)
                 row_issue(row_addr, c0, c1, cst, pcur);
+#endif
 #if DNS_BWD_COORD_TABLE
                 f2 pxy_next;
                 coord_issue(coord_base + (((p + 1) & (NPIX - 1)) << 3), pxy_next, pcur);
                 const float px = pxy.x, py = pxy.y;
 #else
+#if DNS_BWD_DUMMY_ROW
+                const float px = (DNS_BWD_PX_SLOT && D < 8) ? px_cur : fx0 + (float)(pcur & 15);
+                const float py = fy_arr + (float)(((uint32_t)qs >> 8) & 0xffu);
+#else
                 const float px = (DNS_BWD_PX_SLOT && D < 8) ? px_cur : fx0 + (float)(pcur & 15), py = fy0 + (float)(pcur >> 4);
 #endif
-                const f2 dx = sx - px, dy = sy - py;
+#endif
+                const f2 dx = (DNS_BWD_DX_CARRY && DNS_BWD_PX_SLOT && D < 8) ? dx_cur : sx - px, dy = sy - py;
                 // same fused-multiply-add sequence as dns_exponent(), two splats at a time (v_pk_*_f32)
 #if DNS_EXP_SYM
                 const f2 hu = __builtin_elementwise_fma(nb, dy, na * dx);     // -log2e/2 d sigma / d dx
@@ -718,13 +806,18 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT &
                 float SB = dpp_wave_shr1(SB_out, cst.z);
 #endif
                 const int bin_final = __float_as_int(cst.w);
+#if DNS_BWD_DX_CARRY
+                (void)px;
+#else
                 if (DNS_BWD_PX_SLOT && D < 8) px_cur = c1.w;
+#endif
 #if DNS_BWD_PREVALID
                 const bool valid_a = cmp_a <= bin_final && (COUNT || CLAMP ? pre_a : true);
                 const bool valid_b = cmp_b <= bin_final && (COUNT || CLAMP ? pre_b : true);
 #else
-                const bool valid_a = active && cmp_a <= bin_final && e.x <= 0.f && al_a >= (float)DNS_ALPHA_MIN;
-                const bool valid_b = active && cmp_b <= bin_final && e.y <= 0.f && al_b >= (float)DNS_ALPHA_MIN;
+                // DNS_BWD_DUMMY_ROW: an idle slot has read bin_final = -1, below every list index
+                const bool valid_a = (DNS_BWD_DUMMY_ROW || active) && cmp_a <= bin_final && e.x <= 0.f && al_a >= (float)DNS_ALPHA_MIN;
+                const bool valid_b = (DNS_BWD_DUMMY_ROW || active) && cmp_b <= bin_final && e.y <= 0.f && al_b >= (float)DNS_ALPHA_MIN;
 #endif
                 if (COUNT) n_pairs += __popcll(dns_ballot(valid_a)) + __popcll(dns_ballot(valid_b));
                 {   // straight-line: an idle step costs the same as a busy one, but no phi copies at a join
@@ -792,7 +885,14 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT &
 #else
                         const f2 SBv = {SB, SB1};
 #endif
+#if DNS_BWD_VA_CHAIN
+                        // the second group's share joins as two chained packed FMAs (written as a sum of two differences it was a
+                        // multiply, an FMA and an add: one packed instruction more per step)
+                        va = __builtin_elementwise_fma(Tv, cvb, va_a);
+                        va = __builtin_elementwise_fma(-ra, SBv, va);
+#else
                         va += Tv * cvb - ra * SBv;
+#endif
                         SB = __builtin_fmaf(fac.y, cvb.y, SB1);
                     }
                     const f2 vs = -ovm * va, vs_a = -ovm * va_a;
@@ -806,10 +906,23 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT &
                     const f2 gx = vs_a * (ca * dx + cb * dy);
                     const f2 gy = vs_a * (cb * dx + cc * dy);
 #endif
+#if DNS_BWD_ABS_FMA && DNS_EXP_SYM
+                    // sum and sum of magnitudes of vs_a x (hu, hw) WITHOUT forming the products as values: the plain sums are two packed
+                    // FMAs, the magnitudes four v_fma_f32 with |.| on both factors (|a b| = |a| |b|; source modifiers are free).  With
+                    // the products formed first hipcc issued them twice — a packed multiply for the |.| adds and a packed FMA for the
+                    // sums: two packed instructions more per step.
+                    (void)gx; (void)gy;
+                    g_x = __builtin_elementwise_fma(vs_a, hu, g_x); g_y = __builtin_elementwise_fma(vs_a, hw, g_y);
+                    g_ax.x = __builtin_fmaf(__builtin_fabsf(vs_a.x), __builtin_fabsf(hu.x), g_ax.x);
+                    g_ax.y = __builtin_fmaf(__builtin_fabsf(vs_a.y), __builtin_fabsf(hu.y), g_ax.y);
+                    g_ay.x = __builtin_fmaf(__builtin_fabsf(vs_a.x), __builtin_fabsf(hw.x), g_ay.x);
+                    g_ay.y = __builtin_fmaf(__builtin_fabsf(vs_a.y), __builtin_fabsf(hw.y), g_ay.y);
+#else
                     g_x += gx; g_y += gy;
                     // |.| as a source modifier of a plain add: cheaper than masking the sign bits and a packed add
                     g_ax.x += __builtin_fabsf(gx.x); g_ax.y += __builtin_fabsf(gx.y);
                     g_ay.x += __builtin_fabsf(gy.x); g_ay.y += __builtin_fabsf(gy.y);
+#endif
                     g_o = __builtin_elementwise_fma(ovm, va, g_o);             // / opacity at the flush
                     T = T2;
                 }
@@ -819,11 +932,16 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT &
                     // store sits behind a branch per step
                     // two stores of loose registers (S_a and T, then S_b) rather than one ds_write_b96: the three values end the step in
                     // the high halves of three different register pairs and a 96-bit operand would cost two copies
+#if DNS_BWD_DUMMY_ROW
+                    asm volatile("ds_write2_b32 %0, %1, %2 offset0:8 offset1:9\n\tds_write_b32 %0, %3 offset:40"
+                                 : : "v"(row_addr), "v"(SA), "v"(T), "v"(SB) : "memory");
+#else
                     const uint64_t act = dns_ballot(active);
                     uint64_t saved;
                     asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write2_b32 %2, %3, %4 offset0:8 offset1:9\n\tds_write_b32 %2, %5 offset:40\n\t"
                                  "s_or_b64 exec, exec, %0"
                                  : "=&s"(saved) : "s"(act), "v"(row_addr), "v"(SA), "v"(T), "v"(SB) : "memory", "scc");
+#endif
                 }
 #else
                 T_out = T; SA_out = SA; SB_out = SB;
@@ -841,7 +959,20 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT &
 #else
                 if (lane == DNS_WAVE - 1 && active) pix[pcur][2] = make_float4(T, SA, SB, cst.w);
 #endif
+#if DNS_BWD_DX_CARRY
+                // the NEXT step's dx straight from the row's "x of the next pixel" slot, in place of this step's (dead by now): the slot
+                // need not be copied out of the row's registers before the next row load overwrites them (one v_mov per step less)
+                if (DNS_BWD_PX_SLOT && D < 8) {
+                    // sx - (high half of the row's last register pair, broadcast): hipcc only finds low-half broadcasts and would copy the slot first
+                    const f2 tail = __builtin_shufflevector(c1, c1, 2, 3);
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dx_cur) : "v"(sx), "v"(tail));
+                }
+#endif
+#if DNS_BWD_DUMMY_ROW
+                qs += 16;
+#else
                 ++p;
+#endif
             }
             };
             if (COUNT) n_slots += (unsigned long long)nsteps * BUCKET;

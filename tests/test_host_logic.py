@@ -237,3 +237,55 @@ def test_kernel_source_hash_ignores_comments_but_not_code(tmp_path):
     assert bench.kernel_source_sha16(str(root)) != base
     f.write_text(src.replace("0.5f", "0.25f", 1))
     assert bench.kernel_source_sha16(str(root)) != base
+
+
+def test_digit_ranges_of_a_box_equal_the_pair_by_pair_count(tmp_path):
+    """csrc/bin_ranges.h (the first tile pass's histogram without generating pairs) against the definition: pair k of a record has
+    tile id base + (k / w) * tw + k % w and counts on digit (tile & (2^dbits - 1)).  The difference-array bookkeeping of
+    radix_hist_ranges_kernel (cyclic ranges, sink slot, constant share) is replayed here as the kernel does it."""
+    import subprocess
+
+    src = tmp_path / "ranges.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "bin_ranges.h"
+int main() {
+    unsigned long long seed = 12345;
+    auto rnd = [&](unsigned m) { seed = seed * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)((seed >> 33) % m); };
+    long cases = 0;
+    for (int it = 0; it < 200000; ++it) {
+        const int dbits = 1 + rnd(8);
+        const unsigned ND = 1u << dbits;
+        const unsigned tw = 1 + rnd(it % 3 == 0 ? 600 : 130);
+        const unsigned w = 1 + rnd(tw), rows = 1 + rnd(70);
+        const unsigned base = rnd(70000);
+        const unsigned total = w * rows;
+        unsigned lo = rnd(total), hi = lo + 1 + rnd(total - lo);
+        if (it % 7 == 0) { lo = 0; hi = total; }
+        std::vector<unsigned> want(ND, 0), diff(ND + 1, 0);
+        for (unsigned k = lo; k < hi; ++k) want[(base + (k / w) * tw + k % w) & (ND - 1)]++;
+        unsigned all = dns_record_digit_ranges(base, w, tw, lo, hi, dbits, [&](uint32_t d0, uint32_t len) {
+            if (d0 >= ND || len == 0 || len >= ND) { printf("bad range %u %u\n", d0, len); exit(1); }
+            diff[d0] += 1u;
+            const unsigned end = d0 + len;
+            if (end <= ND) diff[end] += 0xFFFFFFFFu;
+            else { diff[0] += 1u; diff[end - ND] += 0xFFFFFFFFu; }
+        });
+        unsigned run = 0;
+        for (unsigned d = 0; d < ND; ++d) {
+            run += diff[d];
+            if (run + all != want[d]) { printf("MISMATCH it %d dbits %d tw %u w %u rows %u base %u lo %u hi %u digit %u: %u vs %u\n", it, dbits, tw, w, rows, base, lo, hi, d, run + all, want[d]); return 1; }
+        }
+        ++cases;
+    }
+    printf("ok %ld\n", cases);
+    return 0;
+}
+''')
+    exe = tmp_path / "ranges"
+    inc = os.path.join(ROOT, "dn-splatter_amd", "csrc")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", inc, str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
