@@ -147,15 +147,15 @@ constexpr int TILE = 16;
 // row's "x of the next pixel" slot can only name one column): 48 + 48 + 16 + 16 instead of 56 + 40 + 24 + 8 pixels for a four-fold
 // bucket, which then lasts 79 instead of 71 steps.  Needs DNS_BWD_LDS_STATE, DNS_BWD_PX_SLOT, DNS_BWD_FOLD, no coordinate table.
 #ifndef DNS_BWD_DUMMY_ROW
-#define DNS_BWD_DUMMY_ROW 0
+#define DNS_BWD_DUMMY_ROW 1
 #endif
 // the group switch requests its two list entries together and its two records together (two memory round trips instead of four)
 // dx of the next step formed at the end of the current one (see the step loop)
 #ifndef DNS_BWD_DX_CARRY
-#define DNS_BWD_DX_CARRY 0
+#define DNS_BWD_DX_CARRY 1
 #endif
 #ifndef DNS_BWD_BATCHED_SWITCH
-#define DNS_BWD_BATCHED_SWITCH 0
+#define DNS_BWD_BATCHED_SWITCH 1
 #endif
 #ifndef DNS_BWD_ABS_FMA
 #define DNS_BWD_ABS_FMA 1
