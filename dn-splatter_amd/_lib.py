@@ -18,7 +18,7 @@ _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["DNSPLAT_LIB"]).resolve() if os.environ.get("DNSPLAT_LIB") else _PKG_DIR / "libdnsplat.so"
 CSRC_DIR = _PKG_DIR / "csrc"
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 RECORD_FLOATS = 16
 MAX_CHANNELS = 8
 
@@ -133,6 +133,7 @@ class ProjGrads(ctypes.Structure):
         ("v_shN", c_void_p), ("v_shN_stride", c_int32),
         ("v_colors", c_void_p),
         ("sh_grads_skip", c_int32),
+        ("sh_factors", c_void_p),
     ]
 
 

@@ -485,9 +485,14 @@ class _ProjectFn(torch.autograd.Function):
                 # factors come from their own small kernel so that their all-gather is already under way while the geometry
                 # gradients are computed below.
                 fac = ex.begin(N, dev, cfg.sh_degree, sh_K, means=means)
-                _lib.run("dnsplat_sh_factors", _lib.lib().dnsplat_sh_factors, N, _ptr(radii[c]), _ptr(viewmat[c]),
-                         _ptr(splats_fwd), _ptr(vs_c), _ptr(fac), _stream())
-                ex.launch()
+                if ex.deferred:
+                    # a captured step (graph.GraphedDpStep): the exchange only starts behind the replay, so nothing is gained by
+                    # having the slab early — dnsplat_project_bwd writes it from the values it holds anyway (one launch less)
+                    g.sh_factors = _ptr(fac)
+                else:
+                    _lib.run("dnsplat_sh_factors", _lib.lib().dnsplat_sh_factors, N, _ptr(radii[c]), _ptr(viewmat[c]),
+                             _ptr(splats_fwd), _ptr(vs_c), _ptr(fac), _stream())
+                    ex.launch()
                 g.sh_grads_skip = 1
             _lib.run("dnsplat_project_bwd", _lib.lib().dnsplat_project_bwd, ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(fwd),
                      ctypes.byref(g), _stream())

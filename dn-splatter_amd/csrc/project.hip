@@ -678,6 +678,7 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
     const int nbK = (p.s.sh_degree >= 0) ? (p.s.sh_degree + 1) * (p.s.sh_degree + 1) : 0;
 
     float v_mean[3] = {0.f, 0.f, 0.f}, v_quat[4] = {0.f, 0.f, 0.f, 0.f}, v_scale[3] = {0.f, 0.f, 0.f}, v_opac = 0.f;
+    float fac3[3] = {0.f, 0.f, 0.f};          // dnsplat_proj_grads.sh_factors: the colour gradients behind the clamp
     const bool visible = radius_g > 0;
     // the gradient record of a visible Gaussian: requested here, used after project_one()
     float4 vrec[4];
@@ -743,7 +744,6 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
             float bas[16];
             sh_basis(p.s.sh_degree, dx, dy, dz, bas);
             float vdn[3] = {0.f, 0.f, 0.f};
-            float fcol[3] = {0.f, 0.f, 0.f};
             float bx[16], by[16], bz[16];
             if (p.s.sh_degree >= 1) sh_basis_grad(p.s.sh_degree, dx, dy, dz, bx, by, bz);
             if (L == SH_DIRECT) {
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
                 float vcol[3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) vcol[i] = (col[i] + 0.5f >= 0.f) ? vr[REC_CH0 + i] : 0.f;
-                fcol[0] = vcol[0]; fcol[1] = vcol[1]; fcol[2] = vcol[2];
+                fac3[0] = vcol[0]; fac3[1] = vcol[1]; fac3[2] = vcol[2];
                 if (vsh0 && !sh_elsewhere) { vsh0[0] = bas[0] * vcol[0]; vsh0[1] = bas[0] * vcol[1]; vsh0[2] = bas[0] * vcol[2]; }
                 if (vshN && !sh_elsewhere) {
 #pragma unroll
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
                 float vcol[3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) vcol[i] = (col[i] + 0.5f >= 0.f) ? vr[REC_CH0 + i] : 0.f;
-                fcol[0] = vcol[0]; fcol[1] = vcol[1]; fcol[2] = vcol[2];
+                fac3[0] = vcol[0]; fac3[1] = vcol[1]; fac3[2] = vcol[2];
                 if (L == SH_CAT) { lrow[0] = bas[0] * vcol[0]; lrow[1] = bas[0] * vcol[1]; lrow[2] = bas[0] * vcol[2]; }
                 else if (vsh0 && !sh_elsewhere) { vsh0[0] = bas[0] * vcol[0]; vsh0[1] = bas[0] * vcol[1]; vsh0[2] = bas[0] * vcol[2]; }
 #pragma unroll
@@ -941,6 +941,16 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
     p.g.v_quats[4 * g] = v_quat[0]; p.g.v_quats[4 * g + 1] = v_quat[1]; p.g.v_quats[4 * g + 2] = v_quat[2]; p.g.v_quats[4 * g + 3] = v_quat[3];
     p.g.v_scales[3 * g] = v_scale[0]; p.g.v_scales[3 * g + 1] = v_scale[1]; p.g.v_scales[3 * g + 2] = v_scale[2];
     p.g.v_opacities[g] = v_opac;
+    if (p.g.sh_factors) {
+        // the slab of dnsplat_sh_factors, from what this lane holds anyway (one launch and two record lines per Gaussian less)
+        float *f = p.g.sh_factors + 3 * (size_t)g;
+        f[0] = fac3[0]; f[1] = fac3[1]; f[2] = fac3[2];
+        if (g == 0) {
+            const Cam cc = load_cam(p.c.viewmat, p.c.K);
+            float *tail = p.g.sh_factors + 3 * (size_t)p.s.N;
+            tail[0] = cc.pos[0]; tail[1] = cc.pos[1]; tail[2] = cc.pos[2]; tail[3] = 0.f;
+        }
+    }
     }  // g < N
     if (L != SH_DIRECT && !p.g.sh_grads_skip) {
         __syncthreads();

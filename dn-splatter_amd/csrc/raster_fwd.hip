@@ -25,9 +25,6 @@
 #ifndef DNS_FWD_PAIR_OPSEL
 #define DNS_FWD_PAIR_OPSEL 1
 #endif
-#ifndef DNS_FWD_T_SUB
-#define DNS_FWD_T_SUB 0
-#endif
 
 namespace {
 
@@ -250,17 +247,11 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
             // a skipped pair takes alpha = 0: its weight is 0 and T x (1 - 0) is T itself, so the blend and the transmittance update
             // below are unconditional.  Only a valid pair can lower T, so "T' <= 1e-4" alone says "this pair saturates the pixel".
             const float a0 = sel0(valid0, alpha0), a1 = sel0(valid1, alpha1);
-#if DNS_FWD_T_SUB
-            // T' = T - alpha T: the weight alpha T is needed anyway, so the new transmittance is one subtraction instead of (1 - alpha)
-            // and a multiply (two instructions per splat less); differs from T (1 - alpha) by one rounding of T per splat
-            v0 = a0 * T0; v1 = a1 * T1;
-            nT0 = T0 - v0; nT1 = T1 - v1;
-            const uint64_t stop0 = dns_ballot(nT0 <= (float)DNS_T_MIN), stop1 = dns_ballot(nT1 <= (float)DNS_T_MIN);
-#else
+            // (measured and not kept, round 4: T' = T - alpha T, i.e. one v_fma per pixel instead of (1 - alpha) and a multiply — two
+            // vector instructions of 39 less per splat and no faster, 0.493 vs 0.490 ms paired; the reference's T (1 - alpha) stays)
             nT0 = T0 * (1.f - a0); nT1 = T1 * (1.f - a1);
             const uint64_t stop0 = dns_ballot(nT0 <= (float)DNS_T_MIN), stop1 = dns_ballot(nT1 <= (float)DNS_T_MIN);
             v0 = a0 * T0; v1 = a1 * T1;
-#endif
             any0 |= valid0; any1 |= valid1;
             if (COUNT) {
                 n_walked += 1;

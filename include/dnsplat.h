@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DNSPLAT_ABI_VERSION 11
+#define DNSPLAT_ABI_VERSION 12
 #define DNSPLAT_RECORD_FLOATS 16
 #define DNSPLAT_MAX_CHANNELS 8
 
@@ -419,6 +419,11 @@ typedef struct dnsplat_proj_grads {
     int32_t sh_grads_skip;       /* non-zero: the SH coefficient gradients are not written — the caller took the colour gradients
                                     with dnsplat_sh_factors before this launch and rebuilds the rows from the gathered slabs
                                     (dnsplat_sh_grads_from_factors) */
+    float *sh_factors;           /* optional [3 N + 4] (ABI 12; SH scenes only): this launch ALSO writes the slab dnsplat_sh_factors
+                                    produces — per Gaussian the three colour gradients behind the clamp (zeros when culled), then the
+                                    camera centre and a pad word — from the values it holds anyway, which saves that kernel's launch
+                                    and its 128 B / Gaussian of reads.  For callers whose exchange starts after this launch (a
+                                    captured step: graph.GraphedDpStep); dnsplat_sh_factors stays for those that start it before */
 } dnsplat_proj_grads;
 
 int dnsplat_project_bwd(const dnsplat_scene *scene, const dnsplat_camera *cam,

@@ -828,11 +828,13 @@ def test_multi_camera_rasterization_equals_sequential_calls_and_oracle(dns, orc,
     assert_equal_int(info_b["isect_ids"], info_o["isect_ids"], "batch isect_ids (camera bits)")
 
 
-@pytest.mark.parametrize("layout", ["split", "cat"])
-def test_sh_factor_exchange_rebuilds_the_multi_camera_gradient(dns, layout):
+@pytest.mark.parametrize("layout,deferred", [("split", False), ("split", True), ("cat", False)])
+def test_sh_factor_exchange_rebuilds_the_multi_camera_gradient(dns, layout, deferred):
     """Data parallel: all-gathering the 3 colour gradients per Gaussian (+ each camera's position) and rebuilding the sum equals
     averaging the 192-byte coefficient gradients of the cameras (dp.ShFactorExchange, dnsplat_sh_grads_from_factors) — checked here
-    with three cameras rendered one after the other on one GPU; the geometry gradients are untouched by the mode."""
+    with three cameras rendered one after the other on one GPU; the geometry gradients are untouched by the mode.
+    ``deferred`` (what graph.GraphedDpStep sets): the slab is written by dnsplat_project_bwd itself (dnsplat_proj_grads.sh_factors)
+    instead of by dnsplat_sh_factors ahead of it — same slab, same rebuilt gradients."""
     import ctypes
 
     from dn_splatter_amd import _lib, _ops, dp, synthetic
@@ -866,6 +868,7 @@ def test_sh_factor_exchange_rebuilds_the_multi_camera_gradient(dns, layout):
 
     dense = [one(c, None) for c in cams]
     ex = dp.ShFactorExchange()
+    ex.deferred = deferred
     if layout == "cat":
         # gsplat's concatenated [N,16,3] layout: its gradient is an intermediate autograd tensor that dp.allreduce_gradients
         # cannot reach, so an active exchange must be IGNORED and the kernel must write the coefficient rows itself
