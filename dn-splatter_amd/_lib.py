@@ -18,7 +18,7 @@ _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["DNSPLAT_LIB"]).resolve() if os.environ.get("DNSPLAT_LIB") else _PKG_DIR / "libdnsplat.so"
 CSRC_DIR = _PKG_DIR / "csrc"
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 RECORD_FLOATS = 16
 MAX_CHANNELS = 8
 

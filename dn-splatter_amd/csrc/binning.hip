@@ -559,10 +559,17 @@ __global__ __launch_bounds__(TH) DNS_TI_OCCUPANCY(TH, K) void radix_scatter_kern
 // random gather through `order` (at 5 M Gaussians: 57 -> 18 us).  Gathering the tile boxes here as well, for emit_prep_kernel, was
 // measured too: this kernel 54 -> 154 us for the 73 -> 19 us it saved there — a second random line per Gaussian costs the same
 // wherever it is fetched; left where it was.
+// BOXES (round 4): the projection's tile boxes carry the count as width x height (dnsplat_proj_out.tile_boxes, ABI 13), so ONE random
+// 8-byte gather per Gaussian yields both the count and the box; the box is left behind in depth order as well (boxes_sorted) and
+// emit_prep_kernel reads it coalesced instead of gathering it a second time through `order` (its random line per Gaussian was the
+// whole cost of that kernel: 73 us at 5 M Gaussians).  Two separate arrays gathered here cost 2 x a gather; one record does not.
+template <bool BOXES>
 __global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(int N, const uint32_t *__restrict__ n_ptr,
                                                                const uint32_t *__restrict__ order,
                                                                const int32_t *__restrict__ tiles,
-                                                               uint32_t *__restrict__ sums, uint32_t *__restrict__ tiles_sorted)
+                                                               uint32_t *__restrict__ sums, uint32_t *__restrict__ tiles_sorted,
+                                                               const int2 *__restrict__ boxes = nullptr,
+                                                               int2 *__restrict__ boxes_sorted = nullptr)
 {
     __shared__ uint32_t lds_wave[4];
     const int n = (int)min(*n_ptr, (uint32_t)N);
@@ -572,15 +579,22 @@ __global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(int N, const uint
         // the eight (order -> tiles) gathers of a thread are issued together: first all ranks, then all counts (no branch around the
         // loads: a rank past the end re-reads the last valid one), instead of eight dependent round-trip pairs in a row
         uint32_t o[SC_ITEMS], t[SC_ITEMS];
+        [[maybe_unused]] int2 bx[SC_ITEMS];
 #pragma unroll
         for (int i = 0; i < SC_ITEMS; ++i) o[i] = order[min(base + i, n - 1)];
 #pragma unroll
-        for (int i = 0; i < SC_ITEMS; ++i) t[i] = (uint32_t)tiles[o[i]];
+        for (int i = 0; i < SC_ITEMS; ++i) {
+            if (BOXES) {
+                bx[i] = boxes[o[i]];
+                t[i] = ((uint32_t)bx[i].y & 0xffffu) * ((uint32_t)bx[i].y >> 16);
+            } else t[i] = (uint32_t)tiles[o[i]];
+        }
 #pragma unroll
         for (int i = 0; i < SC_ITEMS; ++i)
             if (base + i < n) {
                 s += t[i];
                 tiles_sorted[base + i] = t[i];
+                if (BOXES) boxes_sorted[base + i] = bx[i];
             }
     }
     uint32_t tot;
@@ -598,7 +612,8 @@ struct EmitPrep {
     const float *__restrict__ means2d;
     const int32_t *__restrict__ radii;
     const float4 *__restrict__ splats;   // tight tile boxes (dnsplat_bin_args.tight_tiles): the box the projection kernel counted
-    const int2 *__restrict__ boxes;      // or NULL: (first tile id within the camera's grid, width) straight from the projection
+    const int2 *__restrict__ boxes;      // or NULL: (first tile id within the camera's grid, width | height << 16) straight from the projection
+    const int2 *__restrict__ boxes_sorted;   // the same records in depth order (scan_sums_kernel<true> left them): read by rank, no gather
 };
 
 // depth rank j = entry gid owns the pairs [start, end) of the emission order, end > start
@@ -610,8 +625,8 @@ __device__ __forceinline__ void emit_record(const EmitPrep &ep, int N, uint32_t 
     // cameras' (tile id = camera * tw * th + row * tw + column)
     const uint32_t cam_tiles = (ep.n_per_cam < N) ? (gid / (uint32_t)ep.n_per_cam) * (uint32_t)(ep.tw * ep.th) : 0u;
     if (ep.boxes) {
-        const int2 b = ep.boxes[gid];
-        r.bw = (uint32_t)b.y;
+        const int2 b = ep.boxes_sorted ? ep.boxes_sorted[j] : ep.boxes[gid];
+        r.bw = (uint32_t)b.y & 0xffffu;
         r.base_tile = (uint32_t)b.x + cam_tiles;
     } else {
         int x0, y0, x1, y1;
@@ -744,6 +759,7 @@ struct BinWs {
     uint32_t *key_a, *key_b, *val_a, *val_b;  // [N]
     uint32_t *cum;                            // [N]
     uint32_t *tiles_sorted;                   // [N] tile counts in depth order
+    int2 *boxes_sorted;                       // [N] tile boxes in depth order (only written when the caller passes tile_boxes)
     EmitRec *jrec;                            // [N]
     uint32_t *chunk_first;                    // [MAX_CHUNKS]
     uint32_t *tab_n;                          // [256 * nb_n]
@@ -782,6 +798,7 @@ BinWs carve(void *ws, int N, int64_t cap)
     b.key_a = take(n); b.key_b = take(n); b.val_a = take(n); b.val_b = take(n);
     b.cum = take(n);
     b.tiles_sorted = take(n);
+    b.boxes_sorted = reinterpret_cast<int2 *>(take(2 * n));
     b.jrec = reinterpret_cast<EmitRec *>(take(4 * n));
     b.chunk_first = take(MAX_CHUNKS);
     b.tab_n = take((size_t)RS_DIGITS * b.nb_n);
@@ -1039,8 +1056,16 @@ extern "C" int dnsplat_bin_prepare(const dnsplat_bin_args *a, dnsplat_stream_t s
             t = va; va = vb; vb = t;
         }
         // after 4 passes the sorted order is back in val_a
-        hipLaunchKernelGGL(scan_sums_kernel, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.n_ranked, w.val_a, a->tiles_per_gauss,
-                           w.sums, w.tiles_sorted);
+        const int2 *boxes = reinterpret_cast<const int2 *>(a->tile_boxes);
+        // DNSPLAT_BIN_BOX_GATHER=0: the round-3 route (counts gathered here, boxes gathered again by emit_prep_kernel), for A/B runs
+        static const bool box_gather = [] { const char *e = getenv("DNSPLAT_BIN_BOX_GATHER"); return !(e && e[0] == '0'); }();
+        const bool sorted_boxes = boxes && box_gather;
+        if (sorted_boxes)
+            hipLaunchKernelGGL(scan_sums_kernel<true>, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.n_ranked, w.val_a, a->tiles_per_gauss,
+                               w.sums, w.tiles_sorted, boxes, w.boxes_sorted);
+        else
+            hipLaunchKernelGGL(scan_sums_kernel<false>, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.n_ranked, w.val_a, a->tiles_per_gauss,
+                               w.sums, w.tiles_sorted);
         EmitPrep ep;
         ep.jrec = w.jrec; ep.chunk_first = w.chunk_first; ep.nb_chunks = MAX_CHUNKS; ep.chunk = RS_THREADS * RS_ITEMS_I;
         ep.n_per_cam = N / (a->n_cameras > 1 ? a->n_cameras : 1);
@@ -1048,7 +1073,8 @@ extern "C" int dnsplat_bin_prepare(const dnsplat_bin_args *a, dnsplat_stream_t s
         ep.tw = dns_tiles_w(a->width, a->tile_size); ep.th = dns_tiles_h(a->height, a->tile_size);
         ep.means2d = a->means2d; ep.radii = a->radii;
         ep.splats = a->tight_tiles ? reinterpret_cast<const float4 *>(a->splats) : nullptr;
-        ep.boxes = reinterpret_cast<const int2 *>(a->tile_boxes);
+        ep.boxes = boxes;
+        ep.boxes_sorted = sorted_boxes ? w.boxes_sorted : nullptr;
         hipLaunchKernelGGL(scan_final_kernel, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.n_ranked, w.val_a,
                            (const int32_t *)w.tiles_sorted, w.sums, w.cum, w.total, a->n_isects, a->n_isects_max);
         hipLaunchKernelGGL(emit_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, w.n_ranked, w.val_a, w.cum, ep);

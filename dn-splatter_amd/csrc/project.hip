@@ -516,8 +516,9 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
                            x0, y0, x1, y1);
         p.o.tiles_bin[g] = (y1 - y0) * (x1 - x0);          // what the binning of the fused path walks
     }
-    // the box the binning will walk, ready-made (dnsplat_bin_args.tile_boxes): first tile id and width
-    if (p.o.tile_boxes) reinterpret_cast<int2 *>(p.o.tile_boxes)[g] = make_int2(y0 * tw + x0, x1 - x0);
+    // the box the binning will walk, ready-made (dnsplat_bin_args.tile_boxes): first tile id, then width | height << 16 — the
+    // tile count is their product, so the binning's scan needs this one 8-byte record per Gaussian and not the count array as well
+    if (p.o.tile_boxes) reinterpret_cast<int2 *>(p.o.tile_boxes)[g] = make_int2(y0 * tw + x0, (x1 - x0) | ((y1 - y0) << 16));
 
     p.o.radii[g] = (int32_t)st.radius;
     p.o.means2d[2 * g] = st.mean2d[0]; p.o.means2d[2 * g + 1] = st.mean2d[1];
@@ -1090,6 +1091,10 @@ extern "C" int dnsplat_project_fwd(const dnsplat_scene *scene, const dnsplat_cam
     int rc = check_scene(scene, cam, out);
     if (rc != DNSPLAT_OK) return rc;
     if (scene->N == 0) return DNSPLAT_OK;
+    // tile_boxes packs the box as width | height << 16: a tile grid beyond 65535 x 65535 tiles (a megapixel-wide image) does not fit
+    if (out->tile_boxes && cam->tile_size > 0 &&
+        ((cam->width + cam->tile_size - 1) / cam->tile_size > 0xffff || (cam->height + cam->tile_size - 1) / cam->tile_size > 0xffff))
+        return DNSPLAT_ERR_UNSUPPORTED;
     FwdParams p{*scene, *cam, *out, (scene->N + SH_STAGE_THREADS - 1) / SH_STAGE_THREADS};
     dim3 block(SH_STAGE_THREADS), grid((scene->N + SH_STAGE_THREADS - 1) / SH_STAGE_THREADS);
     if (out->phase < 0 || out->phase > 2 || (out->phase != 0 && scene->sh_degree < 0)) return DNSPLAT_ERR_INVALID_ARG;

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DNSPLAT_ABI_VERSION 12
+#define DNSPLAT_ABI_VERSION 13
 #define DNSPLAT_RECORD_FLOATS 16
 #define DNSPLAT_MAX_CHANNELS 8
 
@@ -119,9 +119,10 @@ typedef struct dnsplat_proj_out {
     int32_t *tiles_bin;           /* required iff camera.tight_tiles: [N] tile count over the TIGHT box (what dnsplat_bin_args.tiles_per_gauss
                                      must then be given); tiles_per_gauss itself always receives gsplat's count (A.3), which is what
                                      info["tiles_per_gauss"] / DNSplatterModel.num_tiles_hit (dn_model.py:524) report */
-    int32_t *tile_boxes;          /* optional [N,2]: (id of the first tile, width in tiles) of the box the tile count was taken over — the
-                                     tight one if camera.tight_tiles.  dnsplat_bin_args.tile_boxes takes it and saves the binning
-                                     a gather of the records and the box arithmetic per Gaussian */
+    int32_t *tile_boxes;          /* optional [N,2]: (id of the first tile, width | height << 16, in tiles; ABI 13) of the box the tile count
+                                     was taken over — the tight one if camera.tight_tiles; width x height IS that count (0 | 0 for a culled
+                                     Gaussian).  dnsplat_bin_args.tile_boxes takes it and saves the binning a gather of the records, the box
+                                     arithmetic per Gaussian and the separate gather of the count */
     int32_t phase;                /* 0: everything in one launch.  SH colours only (scene.sh_degree >= 0): 1 = all outputs except the three
                                      colour channels of the records (left 0; no coefficient is read), 2 = those three channels for the
                                      Gaussians with radii > 0 (reads radii and the records' location only).  A caller may run 2 on
@@ -174,7 +175,9 @@ typedef struct dnsplat_bin_args {
     int32_t skip_offsets_fill;       /* with tile_ends: leave tile_offsets[t] of EMPTY tiles undefined (>= the tile's end) instead of
                                         giving them gsplat's value (the offset of the next non-empty tile) — one launch less */
     const int32_t *tile_boxes;       /* optional [N,2] = dnsplat_proj_out.tile_boxes of the projection that produced tiles_per_gauss (single
-                                        camera or a batch; for camera c > 0 the kernel adds c * n_tiles to the first tile id) */
+                                        camera or a batch; for camera c > 0 the kernel adds c * n_tiles to the first tile id).  With it the
+                                        counts are taken from the boxes themselves (width x height, ABI 13): tiles_per_gauss must be the
+                                        counts of exactly these boxes */
     int64_t *n_isects_max;           /* optional device scalar the caller zeroes once: running maximum of n_isects over the frames binned
                                         since.  For a host that never waits on a single frame's count (replayed HIP graphs). */
 } dnsplat_bin_args;
