@@ -339,12 +339,15 @@ def test_render_modes(dns, orc, render_mode):
     _check_backward(o, g)
 
 
-def test_direct_colors_and_background(dns, orc):
-    """sh_degree=None path (dn_model.py:491-493) with a background, 5 feature channels."""
+@pytest.mark.parametrize("n_colors", [5, 7])
+def test_direct_colors_and_background(dns, orc, n_colors):
+    """sh_degree=None path (dn_model.py:491-493) with a background, 5 or 7 feature channels + depth.  7 + depth = 8 channels is the
+    record's capacity: the compositing backward then has no free cotangent slot for the next pixel's x and takes the column from
+    its pixel counter instead (DNS_BWD_PX_SLOT needs D < 8) — the one instantiation no other test reaches."""
     inp, viewmat, K, _ = gsplat_inputs(3000, 96, 80, focal=70.0, seed=7, anisotropic=True)
     g_ = torch.Generator().manual_seed(9)
-    inp["colors"] = torch.rand(3000, 5, generator=g_)
-    bg = torch.rand(1, 6, generator=g_)
+    inp["colors"] = torch.rand(3000, n_colors, generator=g_)
+    bg = torch.rand(1, n_colors + 1, generator=g_)
     ci = to_leaf(inp, "cpu")
     gi = to_leaf(inp, DEV)
     r_o, a_o, info_o = orc.rasterization(**ci, viewmats=viewmat, Ks=K, width=96, height=80, packed=False,
