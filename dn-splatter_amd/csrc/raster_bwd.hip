@@ -24,11 +24,13 @@
 //     row-independent arithmetic of the step;
 //   * state leaving lane 63 is parked back in the pixel's LDS row and picked up by lane 0 in the next (nearer) bucket — the
 //     arithmetic order per pixel is exactly the reference's back-to-front replay (T *= 1/(1-alpha); buffer += c*alpha*T);
+//   * a lane in an idle slot reads and writes a DUMMY row of the pixel table (zero cotangents, last index -1): no pair of it is ever
+//     valid and its state store needs no narrowed exec (round 4, DNS_BWD_DUMMY_ROW);
 //   * the stream is CONTINUOUS over the buckets of a unit: 15 idle slots separate two buckets, which lets the 16 lanes of
 //     a row change their splats at the same wave-uniform step (four staggered group switches per bucket) instead of
 //     draining and refilling the whole array — 143 steps per bucket instead of 128 + 63;
 //   * the last, partly filled bucket of a unit is FOLDED (DNS_BWD_FOLD): with <= 64 (<= 32) splats the four rows are re-cut
-//     into two (four) arrays that each hold all of its splats and stream a share of the pixels: 111 (71) steps;
+//     into two (four) arrays that each hold all of its splats and stream a share of the pixels: 111 (79) steps;
 //   * a splat's 16 partials are summed over all 128 pixels in registers: NO cross-lane reduction, and ONE atomic row per
 //     (half tile, splat).  The flush is transposed through LDS so that each global_atomic_add_f32 instruction covers whole
 //     64-byte gradient records (16 lanes per record).
@@ -108,8 +110,9 @@ constexpr int TILE = 16;
 // up from there one step later — for free, every lane reads its pixel's row (for bin_final) anyway, and the park is the
 // store lane 63 already did.  A bucket costs ~143 steps however few splats it holds, and the last bucket of a unit holds
 // 64 on average: with <= 64 (<= 32) splats the four rows are re-cut into two (four) independent arrays that each hold
-// ALL of the bucket's splats and stream a share of the pixels — 80 + 48 (56 + 40 + 24 + 8) of the 128, unequal because a
-// later row is still busy with the previous bucket for 16 more steps per row — and the bucket ends after 111 (71) steps.
+// ALL of the bucket's splats and stream a share of the pixels — 80 + 48 (48 + 48 + 16 + 16; 56 + 40 + 24 + 8 before the dummy
+// pixel row asked for windows at multiples of 16, DNS_BWD_DUMMY_ROW) of the 128, unequal because a later row is still busy with
+// the previous bucket for 16 more steps per row — and the bucket ends after 111 (79; 71) steps.
 // State slots of a pixel row ordered (S_a, T, S_b, bin_final) instead of (T, S_a, S_b, bin_final): S_a and S_b arrive in the
 // LOW halves of the two aligned register pairs of the row's third ds_read_b128, the value the step computes next for each chain
 // (S after splat A) goes into the high half once T / bin_final are consumed, and the packed operand (S before A, S before B) is
