@@ -39,8 +39,14 @@ constexpr int RS_ITEMS_I = DNS_RS_ITEMS_I;       // keys per lane in the I-sized
 #ifndef DNS_RS_ITEMS_N
 #define DNS_RS_ITEMS_N 8
 #endif
-constexpr int RS_ITEMS_N = DNS_RS_ITEMS_N;                    // ... in the N-sized depth passes: 1 M keys are only 245 chunks of 4096, less than
+constexpr int RS_ITEMS_N = DNS_RS_ITEMS_N;       // ... in the N-sized depth passes: 1 M keys are only 245 chunks of 4096, less than
                                                  // one workgroup per CU and a 16-round ranking chain each; 2048-key chunks fill the chip (measured best of 2/4/8/16)
+// ... and twice that from 4 M entries on: with 2048-key chunks a 5 M-Gaussian depth sort is 2400 chunks per pass — the chip is full
+// either way, and 4096-key chunks halve the per-chunk tables the scans walk and double the scatter's run length (paired, round 4:
+// binning 0.659 -> 0.634 ms at 5 M, +-0 at 3 M; 8 stays the better choice at 1 M)
+constexpr int RS_ITEMS_N_LARGE = 2 * DNS_RS_ITEMS_N;
+constexpr int RS_LARGE_N = 1 << 22;
+inline int rs_items_n(int N) { return N >= RS_LARGE_N ? RS_ITEMS_N_LARGE : RS_ITEMS_N; }
 // the I-sized tile passes: the same 4096-key chunk as RS_THREADS x RS_ITEMS_I, cut into TI_THREADS x TI_ITEMS.  With 512 threads
 // the ranking chain of a wave (one LDS counter round trip per 64 keys) is 8 rounds long instead of 16 and a CU holds 24 instead
 // of 16 waves of this latency-bound kernel
@@ -780,7 +786,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 BinWs carve(void *ws, int N, int64_t cap)
 {
     BinWs b{};
-    b.nb_n = (N + RS_THREADS * RS_ITEMS_N - 1) / (RS_THREADS * RS_ITEMS_N);
+    b.nb_n = (N + RS_THREADS * rs_items_n(N) - 1) / (RS_THREADS * rs_items_n(N));
     b.nb_i = (int)((cap + RS_THREADS * RS_ITEMS_I - 1) / (RS_THREADS * RS_ITEMS_I));
     b.nb_scan = (N + SC_CHUNK - 1) / SC_CHUNK;
     if (b.nb_n < 1) b.nb_n = 1;
@@ -1049,9 +1055,14 @@ extern "C" int dnsplat_bin_prepare(const dnsplat_bin_args *a, dnsplat_stream_t s
             const int shift = 8 * pass;
             // pass 0 knows its element count on the host (n_ptr = NULL), reads (radii, depths) instead of a key / value pair and drops
             // the culled Gaussians; it leaves the number it kept in w.n_ranked, which bounds every later pass and the scans
-            radix_pass<uint32_t, RS_ITEMS_N>(stream, ka, va, kb, vb, pass == 0 ? nullptr : w.n_ranked, n_u32, shift, 8, w.tab_n, w.totals,
-                                             w.nb_n, nullptr, pass == 0 ? a->radii : nullptr, pass == 0 ? a->depths : nullptr, nullptr, 0,
-                                             nullptr, nullptr, nullptr, pass == 0 ? w.n_ranked : nullptr);
+            if (rs_items_n(N) == RS_ITEMS_N_LARGE)
+                radix_pass<uint32_t, RS_ITEMS_N_LARGE>(stream, ka, va, kb, vb, pass == 0 ? nullptr : w.n_ranked, n_u32, shift, 8, w.tab_n, w.totals,
+                                                       w.nb_n, nullptr, pass == 0 ? a->radii : nullptr, pass == 0 ? a->depths : nullptr, nullptr, 0,
+                                                       nullptr, nullptr, nullptr, pass == 0 ? w.n_ranked : nullptr);
+            else
+                radix_pass<uint32_t, RS_ITEMS_N>(stream, ka, va, kb, vb, pass == 0 ? nullptr : w.n_ranked, n_u32, shift, 8, w.tab_n, w.totals,
+                                                 w.nb_n, nullptr, pass == 0 ? a->radii : nullptr, pass == 0 ? a->depths : nullptr, nullptr, 0,
+                                                 nullptr, nullptr, nullptr, pass == 0 ? w.n_ranked : nullptr);
             uint32_t *t = ka; ka = kb; kb = t;
             t = va; va = vb; vb = t;
         }
