@@ -41,6 +41,11 @@
 extern "C" {
 #endif
 
+/* Bumped whenever a struct gains a field, a field changes meaning or an entry point is added; the Python binding refuses a
+ * library of another version.  Round 4: 10 = dnsplat_raster_args.det_partials / dnsplat_det_reduce (deterministic gradient
+ * scatter), 11 = dnsplat_scale_reg, 12 = dnsplat_proj_grads.sh_factors (the colour-gradient slab written by the projection
+ * backward), 13 = dnsplat_proj_out.tile_boxes carries width | height << 16 and dnsplat_bin_args.tile_boxes takes the counts
+ * from it. */
 #define DNSPLAT_ABI_VERSION 13
 #define DNSPLAT_RECORD_FLOATS 16
 #define DNSPLAT_MAX_CHANNELS 8
