@@ -123,3 +123,26 @@ def test_hand_placed_lds_loads_are_not_touched_before_their_wait():
     import check_asm_hazards
 
     assert check_asm_hazards.check() == 0
+
+
+def test_integration_md_ctypes_stub_matches_the_binding(dns):
+    """The ctypes stub INTEGRATION.md shows a maintainer (section C) is this ABI version's dnsplat_raster_args: same fields, same
+    layout as the binding's mirror (which test_struct_layouts_match_gcc holds to the header) — a stale stub passes a short struct."""
+    import ctypes
+    import re
+
+    from dn_splatter_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    m = re.search(r"^class RasterArgs\(ctypes\.Structure\):.*?\]\s*(#[^\n]*)?\n\n", text, re.S | re.M)
+    assert m, "stub not found"
+    ns = {"ctypes": ctypes}
+    exec(m.group(0), ns)
+    stub = ns["RasterArgs"]
+    assert [f[0] for f in stub._fields_] == [f[0] for f in _lib.RasterArgs._fields_]
+    assert ctypes.sizeof(stub) == ctypes.sizeof(_lib.RasterArgs)
+    for name, *_ in stub._fields_:
+        assert getattr(stub, name).offset == getattr(_lib.RasterArgs, name).offset, name
+    v = re.search(r"dnsplat_abi_version\(\) == (\d+)", text)
+    assert v and int(v.group(1)) == _lib.ABI_VERSION
