@@ -648,8 +648,9 @@ def main():
     # (DNSPLAT_TIGHT_TILES=0) flatten_ids / isect_offsets are the reference's bit for bit — that configuration is timed here.
     strict, extras = None, None
     from dn_splatter_amd import _ops as _ops_mod2
+    # (not when the multi-GPU accounting below runs, DNSPLAT_FORCE_DIST=1: it replays the headline's graph, which this section closes)
     if (world == 1 and exchange is None and not args.two_call and not args.torch_postops and _ops_mod2.TIGHT_TILES and not args.lean
-            and not args.no_strict):
+            and not args.no_strict and os.environ.get("DNSPLAT_FORCE_DIST", "0") != "1"):
         if gstep is not None:
             gstep.close()
         K3 = max(5, min(20, args.steps))

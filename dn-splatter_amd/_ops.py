@@ -250,11 +250,13 @@ def static_overflow(device, stream=None) -> Optional[int]:
 
 
 def forget_capacity_guesses(device=None) -> None:
-    """Drops what the bin policies remember about earlier frames (capacity guesses, static capacities, running maxima) — for
-    ``device`` or for all: the Gaussian set changed size (densify.after_refinement), the next frame of a size starts in "sync"."""
-    for d in (BUFFERS.capacity_hint, BUFFERS.static_cap, BUFFERS.n_max):
-        for k in [k for k in d if device is None or k[0] == device]:
-            del d[k]
+    """Drops the capacity guesses earlier frames left behind — for ``device`` or for all: the Gaussian set changed size
+    (densify.after_refinement), the next frame of a size starts in "sync".  The "static" policy's per-stream records (running
+    maxima, static capacities) are NOT touched: the running maximum is a device word that the captured bin kernels of a live
+    graph.GraphedStep still write on every replay, and this dict holds the reference that keeps it allocated — they go
+    with their step (GraphedStep.close -> forget_static)."""
+    for k in [k for k in BUFFERS.capacity_hint if device is None or k[0] == device]:
+        del BUFFERS.capacity_hint[k]
 
 
 def forget_static(device, stream) -> None:
@@ -711,6 +713,26 @@ class LazyInfo(dict):
         for k in list(self._lazy):
             self._force(k)
         return super().values()
+
+    # dict(info), {**info}, info.copy() and pickling take CPython's dict-merge fast path for a dict subclass whose __iter__ is
+    # dict's own, which reads the stored None of an entry nobody has asked for yet.  With __iter__ overridden they go
+    # through keys() + __getitem__, i.e. through _force.
+    def __iter__(self):
+        return iter(list(super().keys()))
+
+    def keys(self):
+        return list(super().keys())
+
+    def _forced(self) -> dict:
+        for k in list(self._lazy):
+            self._force(k)
+        return {k: dict.__getitem__(self, k) for k in super().keys()}
+
+    def copy(self):
+        return self._forced()
+
+    def __reduce__(self):
+        return (dict, (self._forced(),))
 
 
 def binning_status(b: Binning, n_entries: int) -> int:

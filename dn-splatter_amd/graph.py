@@ -78,6 +78,10 @@ class GraphedStep:
             over = self._overflow()
             if over is not None:
                 raise _lib.DnsplatError(f"GraphedStep: warm-up frame with {over} intersections exceeded its capacity")
+        # the device words the captured bin kernels keep their running maxima in: held here as well, so that nothing the host
+        # forgets meanwhile can free memory a replay still writes (check() refuses to vouch for a step whose records are gone)
+        skey = (self.device, s.cuda_stream)
+        self._n_max = {k: t for k, t in _ops.BUFFERS.n_max.items() if k[:2] == skey}
         for c in range(copies):
             self._zero_grads()
             if before_capture is not None:
@@ -114,6 +118,12 @@ class GraphedStep:
         ``check()`` raises again, replaying it keeps truncating): build a new GraphedStep — the capacity guess has been raised to
         1.25 x the count that did not fit, so the new capture gets buffers that hold it."""
         self.stream.synchronize()
+        gone = [k for k in getattr(self, "_n_max", {}) if _ops.BUFFERS.n_max.get(k) is not self._n_max[k]]
+        if gone and self.graphs:
+            raise _lib.DnsplatError(
+                "GraphedStep.check(): the bin policy's running-maximum records of this step were dropped while it was alive "
+                f"({len(gone)} of {len(self._n_max)}): overflow of the replayed frames can no longer be ruled out — close() this "
+                "step and capture a new one")
         over = self._overflow()
         if over is not None:
             self.overflowed = max(self.overflowed or 0, over)
@@ -157,7 +167,15 @@ class GraphedDpStep:
                 exchange.drop()          # an eager warm-up frame leaves factors nobody rebuilds
             return fn()
 
-        self.step = GraphedStep(compute, params={k: params[k] for k in dp.GRAD_KEYS}, **kw)
+        try:
+            self.step = GraphedStep(compute, params={k: params[k] for k in dp.GRAD_KEYS}, **kw)
+        except BaseException:
+            # warm-up or capture failed (overflow, capture error): the caller falls back to the eager step with the SAME exchange
+            # object, which must start its all-gather from the backward again and must not find the warm-up's factors pending
+            if exchange is not None:
+                exchange.deferred = False
+                exchange.drop()
+            raise
         # what ShFactorExchange.begin() recorded while the backward was captured: restored before every exchange, because a replay
         # runs no Python
         self._meta = exchange.meta if exchange is not None else None

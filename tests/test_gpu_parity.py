@@ -583,15 +583,16 @@ def test_get_outputs_mirror_matches_reference_sequence(dns, orc, mode):
     # stated tolerance: (1) the product's stencil (dnsplat_dn_depth_normals) applied to the ORACLE's depth image equals the
     # reference sequence's surface_normal of that same depth to 2e-5 absolute (values in [0, 1]); (2) the product's
     # surface_normal IS that stencil of the product's own depth image (2e-5; the fused HIP post-ops produce both in one launch)
-    def hip_stencil(depth_hw1):
+    def hip_stencil(depth_hw1, alpha_hw=None, dmax=0.0, want_depth=False):
         from dn_splatter_amd import _lib, _ops
         d = depth_hw1.detach().reshape(H, W).to(DEV).float().contiguous()
-        ones, dmax = torch.ones_like(d), torch.zeros(1, device=DEV)
+        al = torch.ones_like(d) if alpha_hw is None else alpha_hw.detach().reshape(H, W).to(DEV).float().contiguous()
+        dmax = torch.full((1,), float(dmax), device=DEV)
         d_out, sn_out = torch.empty_like(d), torch.empty(H, W, 3, device=DEV)
         _lib.run("dnsplat_dn_depth_normals", _lib.lib().dnsplat_dn_depth_normals, W, H, float(cam.fx), float(cam.fy), float(cam.cx),
-                 float(cam.cy), _ops._ptr(d), _ops._ptr(ones), _ops._ptr(dmax), _ops._ptr(d_out), _ops._ptr(sn_out), _ops._stream())
+                 float(cam.cy), _ops._ptr(d), _ops._ptr(al), _ops._ptr(dmax), _ops._ptr(d_out), _ops._ptr(sn_out), _ops._stream())
         torch.cuda.synchronize()
-        return sn_out.cpu()
+        return (sn_out.cpu(), d_out.cpu()) if want_depth else sn_out.cpu()
 
     d1 = (hip_stencil(out_o["depth"]) - out_o["surface_normal"].detach()).abs().max().item()
     assert d1 <= 2e-5, f"HIP depth->normal stencil on the oracle's depth vs the reference sequence: {d1:.3e}"
@@ -599,6 +600,26 @@ def test_get_outputs_mirror_matches_reference_sequence(dns, orc, mode):
     assert d2 <= 2e-5, f"product surface_normal vs the stencil of the product's own depth: {d2:.3e}"
     sn = out_g["surface_normal"].detach().cpu()
     assert torch.equal(sn[0], torch.full_like(sn[0], 0.5)) and torch.equal(sn[:, -1], torch.full_like(sn[:, -1], 0.5))
+    # (3) the kernel's alpha <= 0 fill (dn_model.py:533-537: where(alpha > 0, depth, depth.max())) on the taps of the stencil
+    # (with alphas = 1 the fill of the neighbour taps is never taken).  The oracle's accumulation and depth with holes
+    # punched into them — a block, a single pixel, an image corner, a border run — go through the kernel with the real depth
+    # maximum and through the reference sequence's own two steps (the torch mirror of normal_from_depth_image, pinned to the
+    # reference in tests/test_reference_golden.py).
+    from dn_splatter_amd.model import normal_from_depth_image
+    al = out_o["accumulation"].detach().reshape(H, W).clone()
+    raw = torch.where(al > 0, out_o["depth"].detach().reshape(H, W), torch.zeros(()))
+    for sl in ((slice(40, 90), slice(60, 130)), (slice(100, 101), slice(200, 201)), (slice(0, 9), slice(0, 5)), (slice(H - 1, H), slice(30, 99)),
+               (slice(120, 140), slice(W - 3, W))):
+        al[sl], raw[sl] = 0.0, 0.0
+    dmax = float(raw.max())
+    filled = torch.where(al > 0, raw, torch.full((), dmax))
+    sn_ref = normal_from_depth_image(filled[..., None], float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), (W, H),
+                                     torch.eye(4)) @ torch.diag(torch.tensor([1.0, -1.0, -1.0]))
+    sn_ref = (1 + sn_ref) / 2
+    sn_k, d_k = hip_stencil(raw, al, dmax, want_depth=True)
+    assert torch.equal(d_k, filled), "depth fill where(alpha > 0, depth, max) differs from the reference sequence"
+    d3 = (sn_k - sn_ref).abs().max().item()
+    assert d3 <= 2e-5, f"HIP depth->normal stencil with alpha <= 0 holes vs the reference sequence: {d3:.3e}"
     assert_close(p_g["normals"], p_o["normals"], "gauss_params['normals'] (dn_model.py:558)", 1e-5)
 
 

@@ -289,3 +289,29 @@ int main() {
     subprocess.run(["g++", "-O2", "-std=c++17", "-I", inc, str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+
+
+def test_lazy_info_copies_force_their_lazy_entries(dns):
+    """ADVICE r04: ``info`` of the fused path is a dict subclass whose isect_ids / flatten_ids / n_isects are computed on first read;
+    dict(info), {**info}, info.copy() and pickling must hand out the computed values, not the placeholder."""
+    import pickle
+
+    from dn_splatter_amd._ops import LazyInfo
+
+    calls = []
+
+    def make():
+        calls.append(1)
+        return 42
+
+    fresh = lambda: LazyInfo({"width": 7}, {"isect_ids": make})   # noqa: E731
+    assert dict(fresh())["isect_ids"] == 42
+    assert {**fresh()}["isect_ids"] == 42
+    assert fresh().copy()["isect_ids"] == 42
+    assert pickle.loads(pickle.dumps(fresh()))["isect_ids"] == 42
+    assert dict(fresh().items())["isect_ids"] == 42 and list(fresh().values()) == [7, 42]
+    i = fresh()
+    assert "isect_ids" in i and len(i) == 2 and list(i) == ["width", "isect_ids"] and i.get("isect_ids") == 42
+    n = len(calls)
+    assert i["isect_ids"] == 42 and len(calls) == n          # computed once
+    assert isinstance(i, dict)
