@@ -42,6 +42,7 @@ int orc_get_exact_accum(void) { return orc_exact_accum; }
 #define CEIL ceilf
 #define FLOOR floorf
 #define FABS fabsf
+#define ORC_ULP_BELOW_ONE 5.9604644775390625e-8 /* 2^-24: spacing of floats in [0.5, 1) */
 #include "oracle_impl.inc"
 #undef REAL
 #undef FN
@@ -50,6 +51,7 @@ int orc_get_exact_accum(void) { return orc_exact_accum; }
 #undef CEIL
 #undef FLOOR
 #undef FABS
+#undef ORC_ULP_BELOW_ONE
 
 /* ---- fp64 instantiation ---- */
 #define REAL double
@@ -59,6 +61,7 @@ int orc_get_exact_accum(void) { return orc_exact_accum; }
 #define CEIL ceil
 #define FLOOR floor
 #define FABS fabs
+#define ORC_ULP_BELOW_ONE 1.1102230246251565e-16 /* 2^-53 */
 #include "oracle_impl.inc"
 #undef REAL
 #undef FN

@@ -255,6 +255,34 @@ def rasterize_bwd(means2d, conics, colors, opacities, background, width, height,
     return v_means2d, v_abs, v_conics, v_colors, v_opac
 
 
+def rasterize_bwd_hull(means2d, conics, colors, opacities, background, width, height, tile_size, isect_offsets, flatten_ids,
+                       mask, v_render, v_alphas, max_flags=10, combo=-1):
+    """Backward of the pixels selected by ``mask`` (bool [H,W]) under every combination of outcomes of their flagged
+    (borderline) decisions — orc_rasterize_bwd_hull: per gradient entry the smallest / largest value any admissible combination
+    gives, as float64 tensors.  Returns (lo, hi, status) with lo / hi dicts of means2d [N,2], absgrad [N,2], conics [N,3],
+    colors [N,D], opacities [N] and status = dict(max_flags_seen, pixels_over_cap, pixels_incomplete, pixels).  ``combo >= 0``:
+    that single combination only (bit j = outcome of the pixel's j-th flagged decision), lo == hi."""
+    N, D = colors.shape
+    n_tot = (8 + D) * N
+    lo = torch.zeros(n_tot, dtype=torch.float64)
+    hi = torch.zeros(n_tot, dtype=torch.float64)
+    status = torch.zeros(4, dtype=torch.int64)
+    fn = getattr(lib(), "orc_rasterize_bwd_hull_" + _suffix(colors))
+    fn(ctypes.c_int(N), ctypes.c_int(D), _p(means2d.contiguous()), _p(conics.contiguous()), _p(colors.contiguous()),
+       _p(opacities.contiguous()), _p(background.contiguous() if background is not None else None),
+       ctypes.c_int(width), ctypes.c_int(height), ctypes.c_int(tile_size),
+       _p(isect_offsets.contiguous()), _p(flatten_ids.contiguous()), ctypes.c_int64(flatten_ids.shape[0]),
+       _p(mask.to(torch.uint8).contiguous()), _p(v_render.contiguous()), _p(v_alphas.contiguous()),
+       ctypes.c_int(max_flags), ctypes.c_int(combo), _p(lo), _p(hi), _p(status))
+
+    def split(t):
+        return {"means2d": t[:2 * N].view(N, 2), "absgrad": t[2 * N:4 * N].view(N, 2), "conics": t[4 * N:7 * N].view(N, 3),
+                "colors": t[7 * N:(7 + D) * N].view(N, D), "opacities": t[(7 + D) * N:]}
+
+    st = dict(max_flags_seen=int(status[0]), pixels_over_cap=int(status[1]), pixels_incomplete=int(status[2]), pixels=int(status[3]))
+    return split(lo), split(hi), st
+
+
 # --------------------------------------------------------------------------- autograd wiring
 
 

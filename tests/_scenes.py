@@ -274,3 +274,141 @@ def to_leaf(inp, device):
 def cotangents(shapes, seed=1):
     g = torch.Generator().manual_seed(seed)
     return [torch.rand(s, generator=g) * 2 - 1 for s in shapes]
+
+
+# ---- row-relative statistics ("1e-4 rel" held per Gaussian / per pixel, not only against the tensor's maximum) -----
+# For a gradient tensor with one row per Gaussian: r_g = ||a_g - b_g||_2 / ||b_g||_2 over the rows whose reference norm is at
+# least ROW_FLOOR x the largest row norm (rows below that are dominated by what cancels in them; they stay covered by the
+# scale-relative comparison of assert_close).  Asserted where BOTH sides sum order-independently (HIP deterministic mode, oracle
+# scatter accumulated in double), so that what is measured is the arithmetic, not the arrival order of atomics:
+#   p99 <= ROW_P99 and max <= ROW_MAX of  max(0, ||d_g|| - FP32_ENVELOPE x ||oracle32_g - oracle64_g||) / ||ref_g||,
+# i.e. outside the row's fp64 envelope.  The envelope is needed per row for the same reason as per entry (assert_close): the
+# reference algorithm's OWN fp32 evaluation is that far from exact arithmetic — measured on the C1 scenes, oracle fp32 against oracle
+# fp64, per Gaussian: p50 6e-6 / p99 2e-4 / max 2e-3 isotropic, p50 1.3e-4 / p99 2e-3 / max 8e-3 anisotropic (the backward starts
+# from T_final = 1 - alpha image, a multiple of 2^-24: 6e-4 relative at a saturated pixel; 1 / (1 - alpha) at opacities near the
+# cap) — so no second fp32 implementation can be held to 1e-4 per row against it, only to 1e-4 beyond that envelope.  The raw
+# statistics are printed and logged beside the asserted ones.
+# In the default (atomics) mode the statistics are logged only.  DNSPLAT_ROWREL_LOG=<file> appends one line per comparison.
+ROW_FLOOR = 1e-3
+ROW_P99 = 1e-4
+ROW_MAX = 1e-3
+
+
+def row_rel_stats(a, b, b64=None, floor=ROW_FLOOR):
+    """(p50, p99, max, max outside the fp64 envelope, rows counted, rows total) of the row-relative L2 error; rows = all leading
+    dimensions but the last (a 1-D tensor is one entry per row)."""
+    a_ = a.detach().double().cpu()
+    b_ = b.detach().double().cpu()
+    assert a_.shape == b_.shape, (a_.shape, b_.shape)
+    if b_.dim() == 1:
+        a_, b_ = a_[:, None], b_[:, None]
+    a_, b_ = a_.reshape(-1, b_.shape[-1]), b_.reshape(-1, b_.shape[-1])
+    nb = b_.norm(dim=1)
+    if nb.numel() == 0 or float(nb.max()) == 0.0:
+        return None
+    sel = nb >= floor * nb.max()
+    err = (a_ - b_).norm(dim=1)[sel]
+    r = err / nb[sel]
+    r_out = r
+    if b64 is not None:
+        e64 = b64.detach().double().cpu()
+        e64 = (e64[:, None] if e64.dim() == 1 else e64).reshape(-1, b_.shape[-1])
+        env = FP32_ENVELOPE * (b_ - e64).norm(dim=1)[sel]
+        r_out = (err - env).clamp_min(0) / nb[sel]
+
+    def q(t, f):
+        if not t.numel():
+            return 0.0
+        k = min(t.numel() - 1, int(f * t.numel()))
+        return float(torch.sort(t).values[k])       # torch.quantile refuses more than 16 M entries
+    return q(r, 0.5), q(r, 0.99), float(r.max()), float(r_out.max()), int(sel.sum()), int(nb.numel()), q(r_out, 0.99)
+
+
+ROWREL_ENFORCE = os.environ.get("DNSPLAT_ROWREL_ENFORCE", "1") != "0"      # 0: log the statistics, assert nothing (exploration runs)
+
+
+def both_sides_order_independent(orc) -> bool:
+    """True when the HIP path runs its deterministic gradient mode AND the oracle accumulates its scatter in double: the only
+    configuration in which a row-relative bound on gradients measures arithmetic rather than the arrival order of atomics."""
+    from dn_splatter_amd import _ops
+    return bool(_ops.DETERMINISTIC["on"]) and bool(orc.lib().orc_get_exact_accum())
+
+
+def check_rows(a, b, what, b64=None, enforce=False, p99=ROW_P99, rmax=ROW_MAX, n_rows=None):
+    """``n_rows``: reshape to [n_rows, -1] first (one row per Gaussian whatever the trailing shape)."""
+    enforce = enforce and ROWREL_ENFORCE
+    if n_rows is not None:
+        a, b = a.detach().reshape(n_rows, -1), b.detach().reshape(n_rows, -1)
+        b64 = None if b64 is None else b64.detach().reshape(n_rows, -1)
+    st = row_rel_stats(a, b, b64)
+    if st is None:
+        return None
+    p50, p99_, mx, mx_out, n, tot, p99_out = st
+    print(f"[parity] {what}: row-relative error over {n} of {tot} rows: p50 {p50:.2e}  p99 {p99_:.2e}  max {mx:.2e}"
+          + (f"  (outside the fp64 envelope: p99 {p99_out:.2e}  max {mx_out:.2e})" if b64 is not None else ""))
+    log = os.environ.get("DNSPLAT_ROWREL_LOG")
+    if log:
+        with open(log, "a") as f:
+            f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]}\t{what}\t{n}\t{tot}\t{p50:.3e}\t{p99_:.3e}\t{mx:.3e}\t{p99_out:.3e}\t"
+                    f"{mx_out:.3e}\t{'asserted' if enforce else 'logged'}\n")
+    if enforce:
+        assert p99_out <= p99, f"{what}: p99 of the row-relative error{' outside the fp64 envelope' if b64 is not None else ''} {p99_out:.3e} > {p99:.1e}"
+        assert mx_out <= rmax, f"{what}: largest row-relative error{' outside the fp64 envelope' if b64 is not None else ''} {mx_out:.3e} > {rmax:.1e}"
+    return st
+
+
+def check_pixels(a, b, what, keep=None, enforce=False, p99=ROW_P99, rmax=ROW_MAX):
+    """The same statistic per PIXEL of an image [.., H, W, C] (over its C channels), borderline pixels left to their flip bound."""
+    a_, b_ = a.detach().cpu(), b.detach().cpu()
+    if keep is not None:
+        a_, b_ = image_pixels(a_, keep), image_pixels(b_, keep)
+    return check_rows(a_, b_, what, enforce=enforce, p99=p99, rmax=rmax)
+
+
+# ---- raster-level scene for the backward of borderline pixels (tests/test_borderline_bounds.py, tests/test_gpu_parity.py) ---------
+
+
+def raster_level_scene(orc, seed, N=10_000, W=256, H=256, focal=160.0, D=4, anisotropic=True, view=0):
+    """Projected Gaussians (the oracle's own projection), their sorted tile lists, random per-Gaussian channels and a background:
+    everything gsplat's rasterize_to_pixels takes, as CPU tensors, plus the oracle's forward with its borderline mask."""
+    inp, viewmat, K, _ = gsplat_inputs(N, W, H, focal=focal, seed=seed, anisotropic=anisotropic, view=view)
+    radii, xys, depths, conics, _comp, tiles = orc.project_fwd(inp["means"], inp["quats"], inp["scales"], viewmat[0], K[0], W, H)
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    _t, ids, fid = orc.isect_tiles(xys, radii, depths, 16, tw, th)
+    offs = orc.isect_offset_encode(ids, tw, th)
+    g = torch.Generator().manual_seed(seed + 77)
+    cols = torch.rand(N, D, generator=g)
+    bg = torch.rand(D, generator=g)
+    border = torch.zeros(H, W, dtype=torch.uint8)
+    flip = torch.zeros(H, W, dtype=torch.float32)
+    render, alphas, last = orc.rasterize_fwd(xys, conics, cols, inp["opacities"], bg, W, H, 16, offs, fid, border, flip)
+    return dict(W=W, H=H, D=D, N=N, xys=xys, conics=conics, colors=cols, opacities=inp["opacities"], background=bg, radii=radii,
+                depths=depths, tiles=tiles, offsets=offs, flatten_ids=fid, render=render, alphas=alphas, last_ids=last,
+                borderline=border.bool(), gen=g)
+
+
+HULL_KEYS = ("means2d", "absgrad", "conics", "colors", "opacities")
+
+
+def assert_in_hull(grads, lo, hi, what, tol=REL_TOL, scales=None):
+    """lo - tol * scale <= g <= hi + tol * scale at every entry of every tensor of HULL_KEYS; ``scales``: per-key scale (default: the
+    largest |lo|, |hi| of that tensor).  Returns the worst violation in units of tol * scale."""
+    worst = 0.0
+    for k in HULL_KEYS:
+        g = grads[k].detach().double().cpu().reshape(lo[k].shape)
+        scale = float(scales[k]) if scales is not None else float(torch.maximum(lo[k].abs(), hi[k].abs()).max())
+        if scale == 0.0:
+            assert float(g.abs().max()) == 0.0, f"{what} {k}: non-zero gradient where every admissible evaluation gives zero"
+            continue
+        viol = torch.maximum(lo[k] - g, g - hi[k]).clamp_min(0)
+        w = float(viol.max()) / (tol * scale)
+        width = float((hi[k] - lo[k]).max()) / scale
+        print(f"[parity] {what} {k}: worst distance from the hull of admissible decisions = {w:.3f} x (1e-4 x scale {scale:.3e}); "
+              f"{int((hi[k] > lo[k]).sum())} entries with a non-degenerate interval, widest {width:.2e} of scale")
+        log = os.environ.get("DNSPLAT_MARGIN_LOG")
+        if log:
+            with open(log, "a") as f:
+                f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]}\t{what} {k} (hull)\t{w:.3f}\t{w:.3f}\n")
+        worst = max(worst, w)
+        assert w <= 1.0, f"{what} {k}: {int((viol > tol * scale).sum())} entries outside the hull by more than 1e-4 x scale, worst {w:.2f}"
+    return worst

@@ -10,7 +10,7 @@ import os
 import pytest
 import torch
 
-from _scenes import (REL_TOL, assert_close, assert_close_groups, sh_band_groups, fp64_envelope, assert_equal_int, cotangents, gsplat_inputs,
+from _scenes import (both_sides_order_independent, check_pixels, check_rows, REL_TOL, assert_close, assert_close_groups, sh_band_groups, fp64_envelope, assert_equal_int, cotangents, gsplat_inputs,
                      keep_mask, rel_err, to_leaf, zero_borderline, render_bounds, flip_bound_linear, flip_bound_alpha, flip_bound_ratio,
                      flip_bound_unit)
 
@@ -78,6 +78,11 @@ def _check_forward(o, g, tol=REL_TOL, what="scene"):
     rb, ab = render_bounds(info_o, r_o, a_o, mode)
     assert_close_groups(r_g, r_o, "render", groups, tol=tol, bound=rb)
     assert_close(a_g, a_o, "alpha", tol, bound=ab)
+    # and per PIXEL, relative to that pixel's own value (borderline pixels stay with their flip bound above)
+    keep = _keep(o, what)
+    for name, lo, hi in groups:
+        check_pixels(r_g[..., lo:hi], r_o[..., lo:hi], f"{what} render[{name}] per pixel", keep=keep, enforce=True)
+    check_pixels(a_g, a_o, f"{what} alpha per pixel", keep=keep, enforce=True)
 
 
 def _check_backward(o, g, tol=REL_TOL, seed=1, absgrad=True, quat_atol=0.0, what="scene"):
@@ -111,6 +116,19 @@ def _check_backward(o, g, tol=REL_TOL, seed=1, absgrad=True, quat_atol=0.0, what
     if absgrad:
         assert_close(info_g["means2d"].absgrad, info_o["means2d"].absgrad, "means2d.absgrad", tol,
                      envelope=env("means2d.absgrad", info_o["means2d"].absgrad))
+    # per GAUSSIAN, relative to that Gaussian's own gradient norm (_scenes.check_rows): asserted when neither side's sums depend on
+    # the arrival order of atomics (HIP deterministic mode + oracle scatter in double), logged otherwise
+    det = both_sides_order_independent(info_o["_call"][0]) if "_call" in info_o else False
+    N_ = ci["means"].shape[0]
+    for k in ci:
+        if ci[k].grad is None or (k == "quats" and quat_atol > 0):
+            continue
+        check_rows(gi[k].grad, ci[k].grad, f"{what} grad {k} per Gaussian", b64=None if g64 is None else g64.get(k), enforce=det, n_rows=N_)
+    check_rows(info_g["means2d"].grad, info_o["means2d"].grad, f"{what} means2d.grad per Gaussian",
+               b64=None if g64 is None else g64.get("means2d"), enforce=det, n_rows=N_)
+    if absgrad:
+        check_rows(info_g["means2d"].absgrad, info_o["means2d"].absgrad, f"{what} means2d.absgrad per Gaussian",
+                   b64=None if g64 is None else g64.get("means2d.absgrad"), enforce=det, n_rows=N_)
 
 
 GRAD_NAMES = ("means", "scales", "quats", "features_dc", "features_rest", "opacities")
@@ -289,6 +307,22 @@ def _check_mirror(hip, ora, keep, what="mirror", quat_atol=0.0, ints=True):
         assert_close(p_g[k].grad, p_o[k].grad, what + " grad " + k, atol=quat_atol if k == "quats" else 0.0, envelope=env(k, p_o[k].grad))
     assert_close(m_g.xys.grad, m_o.xys.grad, what + " xys.grad (dn_model.py:517-519)", envelope=env("xys", m_o.xys.grad))
     assert_close(m_g.xys.absgrad, m_o.xys.absgrad, what + " xys.absgrad", envelope=env("xys.absgrad", m_o.xys.absgrad))
+    # row-relative statistics: per pixel for the images (always asserted), per Gaussian for the gradients (asserted when both sides
+    # sum order-independently, logged otherwise) — _scenes.check_rows
+    from oracle import oracle as _orc
+    det = both_sides_order_independent(_orc)
+    for k in OUT_KEYS:
+        if k == "normal" and not out_o[k].requires_grad and float(out_o[k].abs().max()) == 0.0:
+            continue
+        check_pixels(out_g[k], out_o[k], f"{what} {k} per pixel", keep=keep, enforce=True)
+    N_ = p_o["means"].shape[0]
+    for k in GRAD_NAMES:
+        if p_o[k].grad is None or (k == "quats" and quat_atol > 0) or p_o[k].grad.numel() == 0:
+            continue
+        check_rows(p_g[k].grad, p_o[k].grad, f"{what} grad {k} per Gaussian", b64=None if g64 is None else g64.get(k), enforce=det, n_rows=N_)
+    check_rows(m_g.xys.grad, m_o.xys.grad, f"{what} xys.grad per Gaussian", b64=None if g64 is None else g64.get("xys"), enforce=det, n_rows=N_)
+    check_rows(m_g.xys.absgrad, m_o.xys.absgrad, f"{what} xys.absgrad per Gaussian", b64=None if g64 is None else g64.get("xys.absgrad"),
+               enforce=det, n_rows=N_)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1625,3 +1659,87 @@ def test_graphed_step_overflow_is_reported_and_a_recapture_fits(dns):
     finally:
         dns.set_bin_policy("sync")
         _ops.BUFFERS.capacity_hint.pop(hkey, None)
+
+
+# ------------------------------------------------------------------------------------------------
+# The backward of the BORDERLINE pixels.  Everywhere else in this file their cotangents are zero on both
+# sides; here they are the ONLY pixels with a cotangent, and the kernels' gradients are held to what the rule set admits there.
+
+
+def _hip_raster_level_grads(s, v_r, v_a, deterministic=False):
+    """rasterize_to_pixels of the raster-level scene ``s`` (tests/_scenes.raster_level_scene) through the product: records packed by
+    dnsplat_pack_splats, binned by dnsplat_bin_*, composited forward and backward by dnsplat_raster_fwd / _bwd.  Returns the five
+    raster-level gradients as CPU tensors."""
+    from dn_splatter_amd import _ops
+
+    prev = _ops.DETERMINISTIC["on"]
+    _ops.set_deterministic(deterministic)
+    try:
+        leaf = {k: s[k].to(DEV).clone().requires_grad_(True) for k in ("xys", "conics", "colors", "opacities")}
+        splats = _ops._PackFn.apply(leaf["xys"], leaf["conics"], leaf["opacities"], leaf["colors"])
+        # the tensor the caller reads .grad / .absgrad on (gsplat's info["means2d"]); the kernels take xy from the records
+        m2d = leaf["xys"].detach()[None].clone().requires_grad_(True)
+        render, alphas = _ops.rasterize(m2d, splats, s["depths"].to(DEV), s["radii"].to(DEV), s["tiles"].to(DEV),
+                                        background=s["background"].to(DEV), width=s["W"], height=s["H"], tile_size=16, D=s["D"],
+                                        absgrad=True)
+        torch.autograd.backward([render, alphas], [v_r.to(DEV)[None], v_a.to(DEV)[None]])
+        torch.cuda.synchronize()
+        # the screen-space gradient arrives through means2d; what is left in the records' xy columns (nothing) goes back to xys
+        return {"means2d": (m2d.grad[0] + leaf["xys"].grad).cpu(), "absgrad": m2d.absgrad.reshape(-1, 2).cpu(), "conics": leaf["conics"].grad.cpu(),
+                "colors": leaf["colors"].grad.cpu(), "opacities": leaf["opacities"].grad.reshape(-1).cpu()}, render[0].detach().cpu()
+    finally:
+        _ops.set_deterministic(prev)
+
+
+@pytest.mark.parametrize("seed,D,aniso", [(1, 4, True), (2, 7, True), (0, 4, False)])
+def test_backward_of_borderline_pixels_lies_in_the_hull_of_admissible_decisions(dns, orc, seed, D, aniso):
+    """C1 sizes, cotangents on the oracle-flagged borderline pixels only.  A decision taken the other way changes WHICH (pixel, splat)
+    pairs exist, so there is no tolerance around one reference gradient; what the rule set admits is the set of gradients under
+    every combination of outcomes of the flagged decisions (orc_rasterize_bwd_hull evaluates them all).  Checked: (1) every entry of
+    the kernels' five raster-level gradients lies between the smallest and the largest admissible value, up to 1e-4 of the tensor's
+    scale; (2) for single pixels, the kernels' gradient equals ONE admissible combination in all entries at once."""
+    from _scenes import assert_in_hull, raster_level_scene
+
+    s = raster_level_scene(orc, seed, D=D, anisotropic=aniso, view=seed)
+    m = s["borderline"]
+    n_b = int(m.sum())
+    print(f"[parity] {n_b} of {m.numel()} pixels borderline; they alone carry cotangents")
+    assert 0 < n_b <= 0.01 * m.numel()
+    g = s["gen"]
+    v_r = (torch.rand(s["H"], s["W"], D, generator=g) * 2 - 1) * m[..., None]
+    v_a = (torch.rand(s["H"], s["W"], generator=g) * 2 - 1) * m
+    args = (s["xys"], s["conics"], s["colors"], s["opacities"], s["background"], s["W"], s["H"], 16, s["offsets"], s["flatten_ids"])
+    lo, hi, st = orc.rasterize_bwd_hull(*args, m, v_r, v_a)
+    assert st["pixels"] == n_b and st["pixels_over_cap"] == 0 and st["pixels_incomplete"] == 0, st
+    hip, _ = _hip_raster_level_grads(s, v_r, v_a)
+    assert_in_hull(hip, lo, hi, f"borderline-only backward (seed {seed}, {D} channels)")
+    hip_d, _ = _hip_raster_level_grads(s, v_r, v_a, deterministic=True)
+    assert_in_hull(hip_d, lo, hi, f"borderline-only backward, deterministic mode (seed {seed}, {D} channels)")
+
+    # (2) one pixel at a time
+    ys, xs = torch.nonzero(m, as_tuple=True)
+    other = 0
+    for y, x in list(zip(ys.tolist(), xs.tolist()))[:: max(1, n_b // 16)][:16]:
+        one_px = torch.zeros_like(m)
+        one_px[y, x] = True
+        vr1, va1 = v_r * one_px[..., None], v_a * one_px
+        h1, _ = _hip_raster_level_grads(s, vr1, va1)
+        _l, _h, st1 = orc.rasterize_bwd_hull(*args, one_px, vr1, va1)
+        k = st1["max_flags_seen"]
+        assert 1 <= k <= 10
+        t_fin = max(1.0 - float(s["alphas"][y, x]), 1e-30)
+        dlt = min(1.0, 2.0 * 2.0 ** -24 / t_fin)        # T_final = 1 - alpha image, 2 ulp of the image value (orc_rasterize_bwd_hull)
+        best, best_c = None, None
+        for c in range(1 << k):
+            one, _same, _ = orc.rasterize_bwd_hull(*args, one_px, vr1, va1, combo=c)
+            w = max(float(((h1[n].double().reshape(one[n].shape) - one[n]).abs()
+                           / (REL_TOL * max(float(one[n].abs().max()), float(h1[n].abs().max()), 1e-30) + dlt * one[n].abs())).max()) for n in one)
+            if best is None or w < best:
+                best, best_c = w, c
+        assert best <= 1.0, f"pixel ({y}, {x}): the kernels' gradient matches none of the {1 << k} admissible combinations (closest {best:.2f})"
+        base = orc.rasterize_bwd(*args, s["alphas"], s["last_ids"], vr1, va1, absgrad=True)
+        nat, _s2, _ = orc.rasterize_bwd_hull(*args, one_px, vr1, va1, combo=best_c)
+        if any(float((b.double().reshape(nat[n].shape) - nat[n]).abs().max()) > REL_TOL * max(float(nat[n].abs().max()), 1e-30)
+               for n, b in zip(("means2d", "absgrad", "conics", "colors", "opacities"), base)):
+            other += 1
+    print(f"[parity] single-pixel check: {other} of the sampled borderline pixels were decided the other way by the kernels — and match that combination")

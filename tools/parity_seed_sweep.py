@@ -15,7 +15,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 import dn_splatter_amd as dns  # noqa: E402
-from _scenes import FP32_ENVELOPE, assert_borderline_bounded, cotangents, gsplat_inputs, image_pixels, to_leaf, zero_borderline  # noqa: E402
+from _scenes import (FP32_ENVELOPE, ROW_MAX, ROW_P99, assert_borderline_bounded, cotangents, gsplat_inputs, image_pixels, row_rel_stats,  # noqa: E402
+                     to_leaf, zero_borderline)
 from dn_splatter_amd import _ops  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
@@ -27,6 +28,8 @@ if _ops.DETERMINISTIC["on"]:
 print(f"deterministic gradient mode: {_ops.DETERMINISTIC['on']} (oracle scatter accumulated in double: {_ops.DETERMINISTIC['on']}); "
       f"repeats per scene: {repeats}")
 worst_all, n_fail, n_vary = 0.0, 0, 0
+row_p99_out_all = 0.0
+row_p99_all, row_max_all, row_max_out_all = 0.0, 0.0, 0.0      # per-Gaussian relative error over the sweep (tests/_scenes.row_rel_stats)
 for seed in range(first, first + count):
     for aniso in (False, True):
         inp, viewmat, K, _ = gsplat_inputs(10_000, 256, 256, focal=160.0, seed=seed, anisotropic=aniso, view=seed % 8)
@@ -70,11 +73,28 @@ for seed in range(first, first + count):
                 if e > worst:
                     worst, where = e, name
         worst_all = max(worst_all, worst)
-        bad = worst > 1.0 or not ints
+        # per Gaussian: ||d_g|| / ||ref_g|| over the rows with ||ref_g|| >= 1e-3 max; asserted (p99 <= 1e-4, max outside the fp64
+        # envelope <= 1e-3) in deterministic mode, where neither side's sums depend on the order of atomics
+        rp99, rmax, rout, rwhere, rp99o = 0.0, 0.0, 0.0, "", 0.0
+        for k in ci:
+            if k == "quats" and not aniso:
+                continue
+            st = row_rel_stats(first_run[k].reshape(10_000, -1), ci[k].grad.reshape(10_000, -1), c64[k].grad.reshape(10_000, -1))
+            if st is not None:
+                if st[3] > rout:
+                    rwhere = k
+                rp99, rmax, rout, rp99o = max(rp99, st[1]), max(rmax, st[2]), max(rout, st[3]), max(rp99o, st[6])
+        row_p99_all, row_max_all, row_max_out_all = max(row_p99_all, rp99), max(row_max_all, rmax), max(row_max_out_all, rout)
+        row_p99_out_all = max(row_p99_out_all, rp99o)
+        row_bad = _ops.DETERMINISTIC["on"] and (rp99o > ROW_P99 or rout > ROW_MAX)
+        bad = worst > 1.0 or not ints or row_bad
         n_fail += int(bad)
         n_vary += int(not same)
         print(f"seed {seed} aniso {int(aniso)}: ints {'bit-exact' if ints else 'DIFFER'}, borderline {int((~keep).sum())} px, "
-              f"worst error / allowance = {worst:.3f} ({where}) [{worst_plain:.3f} without the fp64 envelope]"
+              f"worst error / allowance = {worst:.3f} ({where}) [{worst_plain:.3f} without the fp64 envelope]; per Gaussian: p99 {rp99:.1e} "
+              f"max {rmax:.1e} (outside the fp64 envelope: p99 {rp99o:.1e} max {rout:.1e}, {rwhere})"
               + (f", {repeats} runs {'bit-identical' if same else 'VARY'}" if repeats > 1 else "")
               + ("   <-- FAIL" if bad else ""), flush=True)
 print(f"worst over the sweep: {worst_all:.3f} of the allowance; {n_fail} scenes FAIL; {n_vary} scenes vary between repeats")
+print(f"per-Gaussian relative error over the sweep: worst p99 {row_p99_all:.2e}, worst max {row_max_all:.2e}, outside the fp64 "
+      f"envelope: worst p99 {row_p99_out_all:.2e}, worst max {row_max_out_all:.2e} ({'asserted outside the envelope: p99 <= 1e-4, max <= 1e-3' if _ops.DETERMINISTIC['on'] else 'logged only: default (atomics) mode'})")
