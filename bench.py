@@ -281,7 +281,161 @@ def side_section(workload, steps, losses=None, tight=True, shared=None, rank=0):
         torch.cuda.empty_cache()
 
 
-def child_workload(workload, losses, steps):
+def make_scene(N, dev, scene="reference_init", seed=0):
+    """The benchmark scene.  "reference_init": the reference's own random initialisation (isotropic 3-NN scales, opacity 0.1,
+    BASELINE.md section 4).  "anisotropic": the parity suite's harder scene at full size (tests/_scenes.gsplat_inputs(anisotropic=
+    True)): log-scales + N(0, 0.6) per axis, opacity logits + N(0, 2) — long thin footprints, opacities from ~0 to beyond the 0.999
+    cap (the clamping twin of the compositing backward runs), shorter useful runs per half tile."""
+    from dn_splatter_amd import synthetic
+
+    gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=seed, device=dev)
+    if scene == "anisotropic":
+        g = torch.Generator(device=dev).manual_seed(1000 + seed)
+        with torch.no_grad():
+            gp["scales"] += torch.randn(N, 3, device=dev, generator=g) * 0.6
+            gp["opacities"] += torch.randn(N, 1, device=dev, generator=g) * 2.0
+    elif scene != "reference_init":
+        raise ValueError(scene)
+    return gp
+
+
+def train_loop_section(workload, steps, rank=0):
+    """A train-like timed section (the reference loop: dn_model.py:271-386 refinement, :938-950 callbacks,
+    dn_datamanager.py:90-96 sequential cameras): the whole step — get_outputs, the fused dn-splatter loss stack, backward,
+    DensifyStats.after_train — captured ONCE into a HIP graph and replayed with a NEW POSE each step (8 orbit poses cycled by
+    camera_to_worlds.copy_), check() every 10 steps, and in the middle one refinement_after + after_refinement + re-capture on the
+    refined Gaussian set.  Prints one JSON line after the first half and one at the end (a crash in the re-capture leaves the first)."""
+    import dn_splatter_amd as dns
+    from dn_splatter_amd import _ops, densify, dp, fused_loss, synthetic, torch_losses
+    from dn_splatter_amd.graph import GraphedStep
+
+    N, W, H, focal = WORKLOADS[workload]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    gp = make_scene(N, dev)
+    poses = [synthetic.orbit_camera(i, n_views=8, width=W, height=H, focal=focal).camera_to_worlds.to(dev) for i in range(8)]
+    cam = synthetic.orbit_camera(0, n_views=8, width=W, height=H, focal=focal).to(dev)      # its pose tensor is what the graph reads
+    batch = torch_losses.synthetic_batch(W, H, dev, seed=rank)
+    counts = fused_loss.depth_counts(batch["mono_depth"])
+    half = max(steps // 2, 10)
+    res = {"workload": workload, "what": "8 orbit poses cycled under one captured step (fused loss, densify statistics in the step), "
+           "check() every 10 steps, one refinement + re-capture in the middle", "unit": "frames/s", "steps": 2 * half, "phases": []}
+
+    def build(gp):
+        renderer = dns.DNSplatterRenderer(gp, fused=True)
+        arena = dp.GradArena(gp)
+        dns.set_grad_arena(arena)
+        stats = densify.DensifyStats(gp["means"].shape[0], dev)
+
+        def compute():
+            for k in dp.GRAD_KEYS:
+                gp[k].grad = None
+            out = renderer.get_outputs(cam)
+            fused_loss.dn_loss_fused(out, batch, gp["scales"], counts=counts).backward()
+            stats.after_train(renderer, W, H)
+
+        # every pose once, eagerly: the capacity guess becomes 1.25 x the largest count any pose of the cycle produces
+        dns.set_bin_policy("capacity")
+        isects = []
+        for p in poses:
+            cam.camera_to_worlds.copy_(p)
+            compute()
+            isects.append(int(renderer.last_info["n_isects"]))
+        torch.cuda.synchronize()
+
+        def reset_stats():      # IN PLACE: the captured dnsplat_densify_stats launch writes into these very tensors
+            stats.xys_grad_norm.zero_(); stats.vis_counts.fill_(1.0); stats.max_2Dsize.zero_()
+
+        renderer.forget()
+        gc.collect()
+        t0 = time.perf_counter()
+        step = GraphedStep(compute, params={k: gp[k] for k in dp.GRAD_KEYS})
+        torch.cuda.synchronize()
+        capture_ms = 1e3 * (time.perf_counter() - t0)
+        cap = min([v for k, v in _ops.BUFFERS.static_cap.items() if k[:2] == (dev, step.stream.cuda_stream)] or [0])
+        reset_stats()
+        return renderer, stats, step, isects, capture_ms, cap
+
+    def run_phase(step, n, first):
+        for i in range(PREROLL_STEPS):
+            cam.camera_to_worlds.copy_(poses[i % 8])
+            step()
+        torch.cuda.synchronize()
+        checks = 0
+        t0 = time.perf_counter()
+        for i in range(n):
+            cam.camera_to_worlds.copy_(poses[(first + i) % 8])
+            step()
+            if (i + 1) % 10 == 0:
+                step.check()                    # synchronises: part of what a training loop pays
+                checks += 1
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, checks
+
+    renderer, stats, step, isects, capture_ms, cap = build(gp)
+    dt1, checks1 = run_phase(step, half, 0)
+    ph = {"N": int(gp["means"].shape[0]), "steps": half, "value": round(half / dt1, 3), "ms_per_step": round(1e3 * dt1 / half, 4),
+          "capture_ms": round(capture_ms, 1), "n_isects_per_pose": isects, "n_isects_max_over_mean": round(max(isects) / (sum(isects) / 8), 4),
+          "capacity": cap, "checks": checks1, "overflows": 0}
+    res["phases"].append(ph)
+    res.update(value=ph["value"], ms_per_step=ph["ms_per_step"], note="first half only (the line after the refinement replaces this one)")
+    print(json.dumps(res), flush=True)
+
+    # ---- the refinement step (dn_model.py:271-386) on the statistics the replays accumulated, then a new capture
+    t0 = time.perf_counter()
+    step.close()
+    cfg = densify.RefineConfig()
+    params = {k: v.detach() for k, v in gp.items()}
+    new, _adam, report = densify.refinement_after(params, stats, cfg, 3500, 8, (H, W), adam_state=None, seed=5)
+    gp2 = {k: (v.clone().requires_grad_(True) if k != "normals" else v.clone()) for k, v in new.items()}
+    del gp, params, new, renderer, stats, step
+    densify.after_refinement(gp2)
+    gc.collect()
+    torch.cuda.synchronize()
+    refine_ms = 1e3 * (time.perf_counter() - t0)
+    launch = "one HIP graph replay per step"
+    try:
+        renderer, stats, step, isects2, capture_ms2, cap2 = build(gp2)
+    except Exception as e:      # the eager path is always there
+        res["recapture_error"] = repr(e)
+        raise
+    dt2, checks2 = run_phase(step, half, half)
+    step.check()
+    ph2 = {"N": int(gp2["means"].shape[0]), "steps": half, "value": round(half / dt2, 3), "ms_per_step": round(1e3 * dt2 / half, 4),
+           "capture_ms": round(capture_ms2, 1), "n_isects_per_pose": isects2,
+           "n_isects_max_over_mean": round(max(isects2) / (sum(isects2) / 8), 4), "capacity": cap2, "checks": checks2, "overflows": 0}
+    res["phases"].append(ph2)
+    total = dt1 + dt2 + (refine_ms + capture_ms2) * 1e-3
+    res.update(value=round(2 * half / total, 3), ms_per_step=round(1e3 * total / (2 * half), 4), launch=launch,
+               refinement={"ms": round(refine_ms, 1), "recapture_ms": round(capture_ms2, 1), **{k: report[k] for k in
+                           ("n_before", "n_after", "n_split", "n_dup", "n_culled")}},
+               note="value = all steps / (both phases + refinement + the re-capture incl. its eager warm-up frames over the 8 poses); "
+                    "phases[i].value = replays of one capture alone")
+    print(json.dumps(res), flush=True)
+
+
+def child_section(section, steps, timeout=420):
+    """Runs ``bench.py --section <section>`` in a process of its own (a second capture with other buffer sizes inside one process has
+    crashed the HIP runtime before, see child_workload) and returns the LAST JSON line it printed."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--section", section, "--steps", str(steps)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "DNSPLAT_FORCE_DIST")}
+    out = ""
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        out = r.stdout
+        lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+        d = json.loads(lines[-1])
+        if r.returncode != 0:
+            d["child_exit_code"] = r.returncode
+            d["child_stderr_tail"] = r.stderr[-400:]
+        return d
+    except Exception as e:
+        return {"section": section, "value": None, "error": repr(e), "stdout_tail": out[-300:]}
+
+
+def child_workload(workload, losses, steps, scene=None):
     """Another BASELINE workload measured by THIS script in a process of its own (same method as the headline: graph replay,
     pre-roll, device stamps around the dominant stage, counting step), started after the headline's timed region; returns the
     fields of its JSON line that BASELINE.md section 2 asks for.  A process of its own, because a second and third HIP-graph
@@ -291,6 +445,8 @@ def child_workload(workload, losses, steps):
 
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps), "--warmup", "3",
            "--no-cpu-baseline", "--no-strict", "--no-extra-workloads"] + (["--losses", losses] if losses else [])
+    if scene:
+        cmd += ["--scene", scene]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
                                                             "DNSPLAT_FORCE_DIST")}
     try:
@@ -308,6 +464,8 @@ def child_workload(workload, losses, steps):
             "roofline": {k: (d.get("roofline") or {}).get(k) for k in ("kernel", "achieved", "frac", "ms_per_launch")},
             "frame_roofline_frac": (d.get("frame_roofline") or {}).get("frac"),
             "useful_pair_fraction": {k: v.get("useful_pair_fraction") for k, v in rv.items() if isinstance(v, dict) and "useful_pair_fraction" in v},
+            "scene": cfg.get("scene"), "alpha_clamp_twin_active": cfg.get("alpha_clamp_twin_active"),
+            "eager_drop_in": d.get("eager_drop_in"),
             "measured": "a child process running this script on that workload, after the headline's timed region"}
 
 
@@ -324,6 +482,9 @@ def main():
                          "waits for it in the steady state (verified as soon as it has arrived, an overflow raises)")
     ap.add_argument("--dense-allreduce", action="store_true",
                     help="all-reduce the full 236 B/Gaussian bucket instead of exchanging the SH gradients as factors")
+    ap.add_argument("--slices", type=int, default=4,
+                    help="N > 1 ranks (or DNSPLAT_FORCE_DIST=1): the projection backward as this many slices of Gaussians, slice k's "
+                         "colour-gradient slab all-gathered while slices k+1.. compute (dp.SlicedShExchange); 1 = one launch, one slab")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step (get_outputs + backward) as a captured HIP graph (dn-splatter_amd/graph.py): 'auto' = when the "
                          "step has no collective in it (one rank) and runs the fused path; falls back to eager launches if the capture fails")
@@ -338,6 +499,11 @@ def main():
     ap.add_argument("--no-strict", action="store_true", help="skip the index-exact (gsplat tile boxes) section after the timed region")
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="skip the short C3 / C5 / C5-with-fused-losses sections a default C2 run appends (extra_workloads in the JSON line)")
+    ap.add_argument("--scene", default="reference_init", choices=["reference_init", "anisotropic"],
+                    help="reference_init: the reference's random initialisation (BASELINE.md); anisotropic: the parity suite's "
+                         "anisotropic / spread-opacity scene at the workload's size (make_scene)")
+    ap.add_argument("--section", default=None, choices=["train_loop"],
+                    help="run one of the side sections a default C2 run starts as child processes, print its JSON line(s) and exit")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, count them with one all-reduce and print {n_gpus, ranks_seen} without rendering (works "
                          "without a GPU over gloo: the CPU test of the --gpus N self-launch)")
@@ -375,12 +541,15 @@ def main():
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return
+    if args.section == "train_loop":
+        train_loop_section(args.workload, args.steps, rank)
+        return
     N, W, H, focal = WORKLOADS[args.workload]
     P = W * H
     T = ((W + 15) // 16) * ((H + 15) // 16)
 
     # identical parameters on every rank (seed 0), one camera per rank (8-view orbit)
-    gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=0, device=dev)
+    gp = make_scene(N, dev, args.scene, seed=0)
     cam = synthetic.orbit_camera(rank % 8, n_views=8, width=W, height=H, focal=focal).to(dev)
     renderer = dns.DNSplatterRenderer(gp, fused=not args.two_call, fused_postops=not args.torch_postops)
     dns.set_bin_policy(args.bin_policy)
@@ -388,7 +557,7 @@ def main():
     dns.set_grad_arena(arena)
     exchange = None
     if (world > 1 or os.environ.get("DNSPLAT_FORCE_DIST", "0") == "1") and not args.dense_allreduce and not args.two_call:
-        exchange = dp.ShFactorExchange()
+        exchange = dp.SlicedShExchange(args.slices) if args.slices > 1 else dp.ShFactorExchange()
         dns.set_sh_exchange(exchange)
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
     shapes = {"rgb": (H, W, 3), "depth": (H, W, 1), "normal": (H, W, 3), "accumulation": (H, W, 1)}
@@ -438,6 +607,29 @@ def main():
         return st[name][1] if name in st else None
 
     probe_ms = {name: stage_ms(pstats, name, PROBE_STEPS) for name in STAGE_NAMES}
+    # ---- the EAGER drop-in figure (VERDICT r04 missing 4): what a maintainer gets who applies INTEGRATION.md under nerfstudio's
+    # trainer — the same fused step launched kernel by kernel from Python through ctypes and autograd (~35 launches), no graph,
+    # bin policy as given (default "deferred": the host never waits for the intersection count).  Pre-rolled like everything else.
+    eager_drop_in = None
+    if world == 1 and not args.lean and not args.two_call and not args.torch_postops:
+        from dn_splatter_amd import _ops as _ops_e
+        for _ in range(PREROLL_STEPS):
+            step()
+        torch.cuda.synchronize()
+        gc.collect(); gc.disable()
+        te, host_e = time.perf_counter(), 0.0
+        for _ in range(args.steps):
+            h0 = time.perf_counter()
+            step()
+            host_e += time.perf_counter() - h0
+        torch.cuda.synchronize()
+        _ops_e.verify_pending_counts(dev, block=True)
+        dte = time.perf_counter() - te
+        gc.enable()
+        eager_drop_in = {"value": round(args.steps / dte, 3), "unit": "frames/s", "ms_per_step": round(1e3 * dte / args.steps, 4),
+                         "host_enqueue_ms_per_step": round(1e3 * host_e / args.steps, 4), "steps": args.steps,
+                         "launch": f"eager launches from Python (fused path, bin policy '{args.bin_policy}', no HIP graph)",
+                         "host_cpu_count": os.cpu_count()}
     # one step through the COUNTING instantiation of the compositing kernels (outside the timed region)
     counts = None
     if not args.two_call and not args.torch_postops and not args.lean:
@@ -602,6 +794,13 @@ def main():
     for name, t in stage_traffic.items():
         if name in stages:
             stages[name]["hbm_traffic"] = t
+            if stages[name]["ms"] > 0:      # what the memory system actually moved per second, beside the algorithmic figure (GBps)
+                stages[name]["hbm_traffic_GBps"] = round(t / (stages[name]["ms"] * 1e-3) / 1e9, 1)
+                stages[name]["hbm_traffic_frac"] = round(t / (stages[name]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                stages[name]["traffic_over_alg_bytes"] = round(t / max(stages[name]["alg_bytes"], 1), 3)
+    for name in stages:
+        if stages[name].get("GBps") is not None:
+            stages[name]["alg_frac"] = round(stages[name]["GBps"] / HBM_PEAK_GBS, 4)
     if "dnsplat_project_fwd_colours" in pstats and "dnsplat_project_fwd" in stages:
         # the SH colour half of the projection runs on a side stream beside the binning kernels (ProjCfg.split_colours)
         stages["dnsplat_project_fwd"]["colour_phase_on_side_stream_ms"] = round(pstats["dnsplat_project_fwd_colours"][1], 4)
@@ -660,8 +859,12 @@ def main():
         # ---- the other BASELINE configurations, so that the driver's record carries them
         if args.workload == "c2" and not args.no_extra_workloads and not args.losses:
             extras = {}
-            for name, wl, ls in (("c3", "c3", None), ("c5", "c5", None), ("c5_fused_loss", "c5", "fused")):
+            for name, wl, ls in (("c3", "c3", None), ("c5", "c5", None), ("c5_fused_loss", "c5", "fused"), ("c5_torch_loss", "c5", "torch")):
                 extras[name] = child_workload(wl, ls, max(5, min(10, args.steps)))
+            # the north star's C5 ("depth + mono-normal loss enabled", losses in PyTorch-ROCm: regularization_strategy.py:146-199,
+            # losses.py:187-224) is c5_torch_loss; c5_fused_loss is the same loss stack as two HIP launches (N2)
+            extras["c2_anisotropic"] = child_workload("c2", None, max(5, min(10, args.steps)), scene="anisotropic")
+            extras["c2_train_loop"] = child_section("train_loop", 200)
 
     # ---- multi-GPU accounting, all outside the timed region ----------------------------------------
     multi = None
@@ -705,10 +908,35 @@ def main():
             t_step = timed(step, K2)
             t_comm = timed(exchange_only, K2)
         exposed = max(0.0, t_step - t_compute)
+        # one rank through RCCL (development boxes): the same step captured WITHOUT any exchange — what a single-GPU run replays,
+        # dnsplat_project_bwd writing the coefficient rows itself — so that the cost of the whole exchange machinery (slab, rebuild
+        # kernel, stream hand-overs, RCCL's one-rank kernels) is a number.  Not on real multi-rank runs: a third capture beside
+        # two live graphs is not something to try for the first time on the driver's 8-GPU node.
+        t_single = None
+        if world == 1 and gdp is not None:
+            g1 = None
+            try:
+                dns.set_sh_exchange(None)
+                renderer.forget(); gc.collect()
+                g1 = GraphedStep(compute, params={k: gp[k] for k in dp.GRAD_KEYS})
+                t_single = timed(g1, K2)
+            except Exception as e:
+                t_single = None
+                graph_note = (graph_note or "") + f" single-GPU comparison capture failed: {e!r}"
+            finally:
+                if g1 is not None:
+                    g1.close()
+                dns.set_sh_exchange(exchange)
         per_rank_I = dp.gather_over_ranks(float(I), dev)
         multi = {"step_ms": round(t_step, 4), "compute_only_ms": round(t_compute, 4), "exchange_alone_ms": round(t_comm, 4),
                  "exchange_exposed_ms": round(exposed, 4), "exchange_hidden_ms": round(max(0.0, t_comm - exposed), 4),
-                 "launch": ("compute = one HIP graph replay per step, the collectives issued eagerly behind it (graph.GraphedDpStep)"
+                 "single_gpu_graphed_step_ms": (round(t_single, 4) if t_single is not None else None),
+                 "exchange_exposed_vs_single_gpu_step_ms": (round(t_step - t_single, 4) if t_single is not None else None),
+                 "exchange_slices": getattr(exchange, "slices", 1) if exchange is not None else None,
+                 "launch": (("everything up to the projection backward = one HIP graph replay per step; its K slice launches, each "
+                             "followed by the all-gather of its slab, the geometry all-reduce and the rebuilds issued eagerly behind it "
+                             "(graph.GraphedDpStep + dp.SlicedShExchange)") if (gdp is not None and gdp.sliced)
+                            else "compute = one HIP graph replay per step, the collectives issued eagerly behind it (graph.GraphedDpStep)"
                             if gdp is not None else "eager launches from Python"),
                  "bytes_exchanged_per_gpu_per_step": int(wire),
                  "bytes_per_xgmi_link_per_step": int(wire / (world - 1)) if world > 1 else None,
@@ -736,7 +964,10 @@ def main():
             "config": {"workload": f"{args.workload}: {N} random-init Gaussians, 1 camera/GPU {W}x{H}, SH degree 3 + "
                                    f"expected depth + per-Gaussian normals ({D_CH} channels, "
                                    f"{'two-call' if args.two_call else 'fused one-pass'}, post-ops in {'torch' if (args.torch_postops or args.two_call) else 'HIP'}), fx=fy={focal}, orbit r=8, "
-                                   f"closed-form 3-NN scale init, {('dn-splatter loss stack (' + args.losses + ')') if args.losses else 'random dense cotangents'}",
+                                   f"closed-form 3-NN scale init{'' if args.scene == 'reference_init' else ' perturbed: log-scales + N(0, 0.6), opacity logits + N(0, 2)'}, "
+                                   f"{('dn-splatter loss stack (' + args.losses + ')') if args.losses else 'random dense cotangents'}",
+                       "scene": args.scene,
+                       "alpha_clamp_twin_active": (bool(int(info["_saturation_flag"].item())) if info.get("_saturation_flag") is not None else None),
                        "N": N, "Nv": Nv, "n_isects": I, "n_isects_sorted": I_sorted, "mean_isects_per_rank": i_all / world,
                        "mean_tile_list_len": round(I / T, 1), "pixels": P, "bin_policy": args.bin_policy,
                        # every result row reports Nv, I and the mean number of Gaussians blended per pixel
@@ -750,6 +981,7 @@ def main():
             "roofline_valu": roofline_valu,
             "frame_roofline": frame_roofline,
             "strict_index_parity": strict,
+            "eager_drop_in": eager_drop_in,
             "extra_workloads": extras,
             "multi_gpu": multi,
             "stages": stages,

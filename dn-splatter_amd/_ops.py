@@ -482,6 +482,40 @@ class _ProjectFn(torch.autograd.Function):
             # Only the model's own split layout (features_dc / features_rest are the leaf parameters dp.allreduce_gradients
             # rebuilds into), one camera per rank.  With the concatenated gsplat layout the coefficient gradient is an
             # intermediate autograd tensor that nobody could fill in afterwards, so the kernel writes the rows itself.
+            if ex is not None and ctx.layout == "split" and sh_K == 16 and C == 1 and getattr(ex, "slices", 1) > 1:
+                # dp.SlicedShExchange: the same entry point on K slices of the Gaussians (every row pointer advanced by g0, N = n_k),
+                # each with its own mini slab.  Under capture (record_only) nothing is launched here: the argument structs stay with
+                # the exchange, graph.GraphedDpStep issues launch k + all-gather k behind each replay; the geometry gradients are
+                # then NOT handed to autograd (None): the launches write the bucket slices, which GraphedDpStep installs as .grad.
+                slabs = ex.begin(N, dev, cfg.sh_degree, sh_K, means=means)
+                g_all = dict(v_means=v_means, v_quats=v_quats, v_scales=v_scales, v_opac=v_opac, v_sh0=v_sh0, v_shN=v_shN)
+                launches, keep = [], [means, quats, scales, opacities, sh0, shN, viewmat, K, normal_frame, radii, vs_c, v_m2d, v_dep, v_con,
+                                      slabs, g_all]
+                for k, (g0, g1) in enumerate(ex.bounds):
+                    sc_k = _scene_struct(g1 - g0, means[g0:g1], quats[g0:g1], scales[g0:g1], opacities[g0:g1], cfg, sh0[g0:g1], 3,
+                                         shN[g0:g1], 3 * (sh_K - 1), sh_K, None)
+                    g_k = ProjGrads()
+                    g_k.radii, g_k.v_splats = _ptr(radii[c][g0:g1]), _ptr(vs_c[g0:g1])
+                    g_k.v_means2d = _ptr(v_m2d[c][g0:g1]) if v_m2d is not None else None
+                    g_k.v_depths = _ptr(v_dep[c][g0:g1]) if v_dep is not None else None
+                    g_k.v_conics = _ptr(v_con[c][g0:g1]) if v_con is not None else None
+                    g_k.v_means, g_k.v_quats = _ptr(v_means[g0:g1]), _ptr(v_quats[g0:g1])
+                    g_k.v_scales, g_k.v_opacities = _ptr(v_scales[g0:g1]), _ptr(v_opac[g0:g1])
+                    g_k.v_sh0, g_k.v_sh0_stride = _ptr(v_sh0[g0:g1]), 3
+                    g_k.v_shN, g_k.v_shN_stride = _ptr(v_shN[g0:g1]), 3 * (sh_K - 1)
+                    g_k.sh_factors, g_k.sh_grads_skip = _ptr(slabs[k]), 1
+                    launches.append((ctypes.byref(sc_k), ctypes.byref(cam), ctypes.byref(fwd), ctypes.byref(g_k)))
+                    keep += [sc_k, g_k]
+                keep += [cam, fwd, scene]
+                if ex.record_only:
+                    ex.record(launches, keep)
+                    v_means = v_quats = v_scales = v_opac = None
+                else:
+                    for args in launches:
+                        _lib.run("dnsplat_project_bwd", _lib.lib().dnsplat_project_bwd, *args, _stream())
+                outs = [v_means, v_quats, v_scales, v_opac, v_coeffs, v_sh0, v_shN, v_colors]
+                total = outs
+                continue
             if ex is not None and ctx.layout == "split" and sh_K == 16 and C == 1:
                 # The coefficient-gradient tensors are handed to autograd unwritten; dp.allreduce_gradients fills them.  The
                 # factors come from their own small kernel so that their all-gather is already under way while the geometry

@@ -172,6 +172,142 @@ class ShFactorExchange:
         return (w - 1) * self.slab_floats(N) * 4
 
 
+class SlicedShExchange(ShFactorExchange):
+    """The exchange step cut into K slices of Gaussians, so that xGMI starts carrying gradients a quarter of the way into the
+    projection backward instead of behind it ("bucketed ... overlapped with backward").
+
+    ``dnsplat_project_bwd`` needs no change for this: a slice [g0, g1) is the same entry point called on a smaller scene — every
+    pointer of ``dnsplat_scene`` / ``dnsplat_proj_grads`` advanced by g0 rows, N = g1 - g0 — and each slice writes its own mini slab
+    ``[3 n_k colour gradients | camera position | pad]``.  As soon as slice k has been launched its slab's all-gather is queued on
+    the communication stream (it waits for that launch only) and travels while slices k+1 ... compute; the geometry gradients
+    (44 B per Gaussian, one contiguous prefix of the bucket) are all-reduced in ONE collective behind the last slice — the links are
+    busy with the slabs until then anyway (K x 7 x 12 n_k bytes take longer than the K launches at every BASELINE size) — and the
+    coefficient rows of slice k are rebuilt (``dnsplat_sh_grads_from_factors`` on the slice) as soon as its slab has arrived.
+
+    Two ways of running it:
+      * eager: the projection backward launches the K slices itself; ``dp.allreduce_gradients`` runs the collectives;
+      * recorded (``record_only``, used by ``graph.GraphedDpStep``): the projection backward that is being CAPTURED launches
+        nothing and leaves the argument structs of the K launches here; ``run_recorded`` issues launch k + gather k for every
+        slice right behind each graph replay.  No collective is ever part of a HIP graph (see GraphedDpStep).
+    Slice bounds are multiples of 256 Gaussians (16-byte alignment of every row pointer, whole staging workgroups)."""
+
+    ALIGN = 256
+
+    def __init__(self, slices: int = 4):
+        super().__init__()
+        self.slices = max(1, int(slices))
+        self.record_only = False
+        self.records = None            # [(entry point args..., keep-alive tensors)] of the captured backward
+        self.bounds = None
+        self.total = 0
+        self.works = None
+
+    def plan(self, N: int):
+        K = max(1, min(self.slices, N // self.ALIGN))
+        step = -(-N // K)
+        step = -(-step // self.ALIGN) * self.ALIGN
+        return [(g0, min(N, g0 + step)) for g0 in range(0, max(N, 1), step)] if N > 0 else [(0, 0)]
+
+    def _slab_offset(self, k: int) -> int:
+        return 3 * self.bounds[k][0] + 4 * k
+
+    def begin(self, N, device, sh_degree, sh_K, means: Optional[Tensor] = None):
+        """-> the K mini slabs (views of one buffer of 3 N + 4 K floats), slab k = 3 n_k + 4 floats."""
+        if self.meta is not None:
+            raise RuntimeError("SlicedShExchange: the factors of the previous backward were never rebuilt — every backward must be "
+                               "followed by dp.allreduce_gradients(..., exchange=...) (or run_recorded / finish)")
+        self.bounds = self.plan(N)
+        self.total = 3 * N + 4 * len(self.bounds)
+        if self.mine is None or self.mine.shape[0] != self.total or self.mine.device != device:
+            self.mine = torch.empty(self.total, dtype=torch.float32, device=device)
+        self.meta = (N, sh_degree, sh_K)
+        if means is not None:
+            self.means = means.detach()
+        self.works = None
+        return [self.slab(k) for k in range(len(self.bounds))]
+
+    def slab(self, k: int) -> Tensor:
+        g0, g1 = self.bounds[k]
+        o = self._slab_offset(k)
+        return self.mine[o:o + 3 * (g1 - g0) + 4]
+
+    def _gathered(self, k: int, w: int) -> Tensor:
+        """[w, 3 n_k + 4] view of slice k's receive buffer (one buffer of w x (3 N + 4 K) floats, slice-major)."""
+        if self.gathered is None or self.gathered.numel() != w * self.total or self.gathered.device != self.mine.device:
+            self.gathered = torch.empty(w * self.total, dtype=torch.float32, device=self.mine.device)
+        g0, g1 = self.bounds[k]
+        n = 3 * (g1 - g0) + 4
+        o = w * self._slab_offset(k)
+        return self.gathered[o:o + w * n].view(w, n)
+
+    def launch(self, group=None) -> None:      # the unsliced early all-gather does not apply
+        return
+
+    def gather_slice(self, k: int, group=None):
+        """Queues the all-gather of slab k behind whatever filled it on the current stream; returns the handle (or None)."""
+        w = world_size(group)
+        buf = self._gathered(k, w)
+        if w > 1 or _collectives_on(group):
+            return dist.all_gather_into_tensor(buf.view(-1), self.slab(k), group=group, async_op=True)
+        buf.copy_(self.slab(k)[None])
+        return None
+
+    def rebuild_slice(self, k: int, w: int, v_sh0: Tensor, v_shN: Tensor) -> None:
+        N, sh_degree, sh_K = self.meta
+        g0, g1 = self.bounds[k]
+        if g1 > g0:
+            self._rebuild(self._gathered(k, w), self.means[g0:g1], g1 - g0, w, sh_degree, sh_K, None, v_sh0[g0:g1], v_shN[g0:g1])
+
+    def finish(self, group=None, v_coeffs: Optional[Tensor] = None, v_sh0: Optional[Tensor] = None,
+               v_shN: Optional[Tensor] = None) -> int:
+        """All slices: gathers not yet in flight are queued now (all of them before the first wait), then each slice is rebuilt as
+        its slab arrives.  Returns the bytes received."""
+        if self.meta is None:
+            return 0
+        if v_coeffs is not None:
+            raise RuntimeError("SlicedShExchange rebuilds into the split features_dc / features_rest gradients only")
+        N = self.meta[0]
+        w = world_size(group)
+        K = len(self.bounds)
+        works = self.works if self.works is not None else [self.gather_slice(k, group) for k in range(K)]
+        self.works = None
+        for k in range(K):
+            if works[k] is not None:
+                works[k].wait()
+            self.rebuild_slice(k, w, v_sh0, v_shN)
+        self.meta = None
+        return (w - 1) * self.total * 4
+
+    # ---- recorded mode (graph.GraphedDpStep) -----------------------------------------------------------------------------
+    def record(self, launches, keep) -> None:
+        self.records = (launches, keep)
+
+    def run_recorded(self, params: Dict[str, Tensor], arena: "GradArena", group=None, collectives: bool = True,
+                     direct: Optional[Dict[str, Tensor]] = None) -> int:
+        """Behind a replay of the captured step: launch k (dnsplat_project_bwd on slice k) + all-gather k for every slice, ONE
+        all-reduce of the geometry prefix, the rebuilds.  ``direct``: gradients that reach a geometry tensor NOT through the
+        renderer (a scale regulariser): the captured step leaves them in tensors of its own, they are added to the bucket slice
+        before it is reduced.  ``collectives=False``: the launches only (what the step costs when nothing travels; the coefficient
+        rows stay unwritten).  Returns the bytes exchanged."""
+        launches, _keep = self.records
+        works = []
+        for k, args in enumerate(launches):
+            self._launch(args)
+            if collectives:
+                works.append(self.gather_slice(k, group))
+        if direct:
+            for name, t in direct.items():
+                arena.view(name).add_(t.view(arena.view(name).shape))
+        if not collectives:
+            return 0
+        n_geo = sum(arena.slices[k][1] for k in GEOMETRY_KEYS)
+        geo = allreduce_mean_(arena.flat[:n_geo], group, async_op=True)
+        self.works = works
+        got = self.finish(group, v_sh0=arena.view("features_dc"), v_shN=arena.view("features_rest"))
+        geo.wait()
+        return n_geo * 4 + got
+
+
 def _rebuild_hip(gathered: Tensor, means: Tensor, N: int, w: int, sh_degree: int, sh_K: int, v_coeffs, v_sh0, v_shN) -> None:
     from . import _lib
     from ._ops import _ptr, _stream
@@ -185,6 +321,17 @@ def _rebuild_hip(gathered: Tensor, means: Tensor, N: int, w: int, sh_degree: int
 
 
 ShFactorExchange._rebuild = staticmethod(_rebuild_hip)   # the CPU gloo test swaps in a torch reference
+SlicedShExchange._rebuild = staticmethod(_rebuild_hip)
+
+
+def _launch_project_bwd(args) -> None:
+    from . import _lib
+    from ._ops import _stream
+
+    _lib.run("dnsplat_project_bwd", _lib.lib().dnsplat_project_bwd, *args, _stream())
+
+
+SlicedShExchange._launch = staticmethod(_launch_project_bwd)   # the CPU gloo test swaps in a stand-in that fills slab + bucket slice
 
 
 def init_from_env(device_type: Optional[str] = None):
@@ -264,6 +411,8 @@ def allreduce_gradients(params: Dict[str, Tensor], arena: Optional[GradArena] = 
         if arena is None or not all(arena.holds(params[k].grad) for k in GEOMETRY_KEYS):
             raise RuntimeError("the SH factor exchange needs the gradients in a GradArena (dp.GradArena + set_grad_arena)")
         n_geo = sum(arena.slices[k][1] for k in GEOMETRY_KEYS)
+        if isinstance(exchange, SlicedShExchange) and exchange.works is None:
+            exchange.works = [exchange.gather_slice(k, group) for k in range(len(exchange.bounds))]      # the slabs first
         # the geometry all-reduce is queued behind the factor all-gather on the communication stream and runs while the
         # SH rows are rebuilt from the gathered factors on the compute stream
         geo = allreduce_mean_(arena.flat[:n_geo], group, async_op=True)

@@ -159,8 +159,14 @@ class GraphedDpStep:
         self._dp = dp
         self.params, self.arena, self.exchange, self.group = params, arena, exchange, group
         self.wire = 0
+        # dp.SlicedShExchange: the captured step ends in front of dnsplat_project_bwd; its K slice launches are issued behind each
+        # replay, each followed by the all-gather of its slab (the exchange overlaps the projection backward again)
+        self.sliced = exchange is not None and getattr(exchange, "slices", 1) > 1
+        self.direct: Dict[str, Tensor] = {}
         if exchange is not None:
             exchange.deferred = True
+            if self.sliced:
+                exchange.record_only = True
 
         def compute():
             if exchange is not None:
@@ -174,20 +180,46 @@ class GraphedDpStep:
             # object, which must start its all-gather from the backward again and must not find the warm-up's factors pending
             if exchange is not None:
                 exchange.deferred = False
+                if self.sliced:
+                    exchange.record_only = False
                 exchange.drop()
             raise
+        if self.sliced:
+            if exchange.records is None:
+                raise _lib.DnsplatError("GraphedDpStep: the captured step never reached the projection backward (no slices recorded)")
+            # What autograd left in .grad of a geometry tensor during the capture did not come from the renderer (the recorded
+            # launches hand autograd nothing): a loss term that feeds the parameter directly, e.g. the scale regulariser.  The
+            # graph rewrites that tensor on every replay; it is added to the bucket slice before the all-reduce, and the bucket
+            # slice — which the recorded launches write — becomes .grad.
+            for k in dp.GEOMETRY_KEYS:
+                g = params[k].grad
+                if g is not None and not arena.holds(g):
+                    self.direct[k] = g
+                params[k].grad = arena.view(k)
+            for k in ("features_dc", "features_rest"):
+                if not arena.holds(params[k].grad):
+                    raise _lib.DnsplatError(f"GraphedDpStep: {k}.grad is not a slice of the gradient bucket — a loss term that feeds "
+                                            "the SH coefficients directly cannot be combined with the factor exchange")
         # what ShFactorExchange.begin() recorded while the backward was captured: restored before every exchange, because a replay
         # runs no Python
         self._meta = exchange.meta if exchange is not None else None
 
     def compute_only(self):
         """Replay without the exchange (bench.py: what the step costs when nothing travels)."""
-        return self.step()
+        out = self.step()
+        if self.sliced:
+            self.exchange.meta = self._meta
+            self.exchange.run_recorded(self.params, self.arena, self.group, collectives=False, direct=self.direct)
+            self.exchange.meta = None
+        return out
 
     def exchange_only(self) -> int:
         if self.exchange is not None:
             self.exchange.meta = self._meta
-        self.wire = self._dp.allreduce_gradients(self.params, self.arena, self.group, exchange=self.exchange)
+        if self.sliced:
+            self.wire = self.exchange.run_recorded(self.params, self.arena, self.group, direct=self.direct)
+        else:
+            self.wire = self._dp.allreduce_gradients(self.params, self.arena, self.group, exchange=self.exchange)
         return self.wire
 
     def __call__(self):
@@ -202,4 +234,7 @@ class GraphedDpStep:
         self.step.close()
         if self.exchange is not None:
             self.exchange.deferred = False
+            if self.sliced:
+                self.exchange.record_only = False
+                self.exchange.records = None
             self.exchange.drop()

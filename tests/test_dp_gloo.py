@@ -165,6 +165,82 @@ def _worker(rank, world, port, ret):
         assert torch.equal(fpar["features_dc"].grad, want_dc) and torch.equal(fpar["features_rest"].grad, want_rest)
     ex.deferred = False
 
+    # ---- the SLICED exchange (dp.SlicedShExchange): K slices of Gaussians, one mini slab + one all-gather +
+    # one rebuild per slice, one all-reduce of the geometry prefix — must give what the unsliced exchange gives on the same data.
+    n2 = 1300
+    fp2 = {k: torch.nn.Parameter(torch.zeros(s)) for k, s in (("means", (n2, 3)), ("scales", (n2, 3)), ("quats", (n2, 4)),
+                                                             ("opacities", (n2, 1)), ("features_dc", (n2, 3)),
+                                                             ("features_rest", (n2, 15, 3)))}
+    far2 = dp.GradArena(fp2)
+    for k in KEYS:
+        fp2[k].grad = far2.take(fp2[k])
+    means2 = torch.randn(n2, 3, generator=torch.Generator().manual_seed(98)) * 2
+    gen2 = torch.Generator().manual_seed(17 + rank)
+    cols2, geo2 = torch.randn(n2, 3, generator=gen2), torch.randn(11 * n2, generator=gen2)
+    n_geo2 = 11 * n2
+
+    def fill_geometry():
+        far2.flat[:n_geo2].copy_(geo2)
+        fp2["features_dc"].grad.zero_(); fp2["features_rest"].grad.zero_()
+
+    ex1 = dp.ShFactorExchange()
+    ex1._rebuild = rebuild_ref
+    fill_geometry()
+    ex1.begin(n2, torch.device("cpu"), 3, 16, means=means2).copy_(torch.cat([cols2.reshape(-1), campos, torch.zeros(1)]))
+    bytes1 = dp.allreduce_gradients(fp2, far2, exchange=ex1)
+    want = far2.flat.clone()
+    exs = dp.SlicedShExchange(4)
+    exs._rebuild = rebuild_ref
+    assert exs.plan(n2) == [(0, 512), (512, 1024), (1024, 1300)] and exs.plan(100) == [(0, 100)] and exs.plan(0) == [(0, 0)]
+    assert exs.plan(5_000_000)[-1][1] == 5_000_000 and all(a % 256 == 0 for a, _ in exs.plan(5_000_000)) and len(exs.plan(5_000_000)) == 4
+
+    def fill_slab(k):          # what dnsplat_project_bwd on slice k leaves behind: its colour gradients, the camera position, a pad word
+        g0, g1 = exs.bounds[k]
+        exs.slab(k).copy_(torch.cat([cols2[g0:g1].reshape(-1), campos, torch.zeros(1)]))
+
+    # (a) eager form: the backward launched the K slices itself, allreduce_gradients runs the collectives
+    fill_geometry()
+    slabs = exs.begin(n2, torch.device("cpu"), 3, 16, means=means2)
+    assert len(slabs) == 3 and [t.numel() for t in slabs] == [3 * 512 + 4, 3 * 512 + 4, 3 * 276 + 4]
+    for k in range(3):
+        fill_slab(k)
+    bytes_s = dp.allreduce_gradients(fp2, far2, exchange=exs)
+    assert bytes_s == n_geo2 * 4 + (world - 1) * (3 * n2 + 4 * 3) * 4 and bytes1 == n_geo2 * 4 + (world - 1) * (3 * n2 + 4) * 4
+    assert torch.allclose(far2.flat, want, atol=1e-6), float((far2.flat - want).abs().max())
+    # (b) recorded form (graph.GraphedDpStep): "replays" leave the inputs of the K launches behind; run_recorded issues launch k +
+    # all-gather k, adds the gradient a loss term fed to a geometry tensor directly, reduces the geometry prefix, rebuilds
+    exs.begin(n2, torch.device("cpu"), 3, 16, means=means2)
+    meta = exs.meta
+    exs.drop()
+    launched = []
+
+    def launch_stand_in(args):
+        (k,) = args
+        g0, g1 = exs.bounds[k]
+        for name in dp.GEOMETRY_KEYS:          # the slice's rows of the four geometry gradients (a launch OVERWRITES them)
+            off, n, shape = far2.slices[name]
+            wd = n // n2
+            far2.flat[off + g0 * wd:off + g1 * wd].copy_(geo2[off + g0 * wd:off + g1 * wd])
+        fill_slab(k)
+        launched.append(k)
+
+    exs._launch = launch_stand_in
+    exs.record([(k,) for k in range(3)], [])
+    direct = {"scales": torch.full((n2, 3), 0.25 * (rank + 1))}
+    for rep in range(2):
+        far2.flat.fill_(123.0)                  # whatever the previous step left
+        exs.meta = meta
+        assert exs.run_recorded(fp2, far2, direct=direct) == bytes_s and exs.meta is None
+        got2 = far2.flat.clone()
+        off, n, _shape = far2.slices["scales"]
+        got2[off:off + n] -= 0.25 * (1 + world) / 2       # the mean of the direct term
+        assert torch.allclose(got2, want, atol=1e-6), float((got2 - want).abs().max())
+    assert launched == [0, 1, 2, 0, 1, 2]
+    far2.flat.fill_(5.0)
+    exs.meta = meta
+    assert exs.run_recorded(fp2, far2, collectives=False) == 0 and float(far2.flat[n_geo2:].min()) == 5.0     # launches only
+    exs.meta = None
+
     # densification statistics: sums over the step's increments, max over ranks (densify.py)
     from dn_splatter_amd.densify import DensifyStats
     prev = DensifyStats(8, "cpu")

@@ -85,8 +85,49 @@ def _worker(rank, world, port, path):
             worst = max(worst, float((gp[k].grad - eager[k]).abs().max()) / scale)
     gdp.check()
     gdp.close()
+
+    # ---- the SLICED exchange (dp.SlicedShExchange): the projection backward as 4 slice launches, slab k all-gathered behind launch
+    # k.  Eager form first (the backward launches the slices itself), then recorded under graph.GraphedDpStep — there with a loss
+    # term that feeds `scales` directly (a scale regulariser), which the captured step leaves in a tensor of its own and
+    # run_recorded adds to the bucket slice before the all-reduce.  Both must give the unsliced step's averaged gradients.
+    sliced = dp.SlicedShExchange(4)
+    dns.set_sh_exchange(sliced)
+    for k in KEYS:
+        gp[k].grad = None
+    _render_and_backward(dns, synthetic, gp, rank, dev)
+    assert len(sliced.bounds) == 4 and sliced.bounds[0] == (0, 5120) and sliced.bounds[-1][1] == N
+    wire_s = dp.allreduce_gradients(gp, arena, exchange=sliced)
+    torch.cuda.synchronize()
+    assert wire_s == wire + (world - 1) * 4 * 3 * 4 and all(arena.holds(gp[k].grad) for k in KEYS)
+    worst_s = max(float((gp[k].grad - eager[k]).abs().max()) / (float(eager[k].abs().max()) + 1e-30) for k in KEYS)
+
+    reg_w = 0.37 * (rank + 1)
+
+    def compute_reg():
+        out = renderer.get_outputs(cam)
+        torch.autograd.backward([out[k] for k in OUT] + [(gp["scales"] * reg_w).sum()], cots + [None])
+
+    for k in KEYS:
+        gp[k].grad = None
+    renderer.forget()
+    gdp = GraphedDpStep(compute_reg, gp, arena, exchange=sliced)
+    assert gdp.sliced and list(gdp.direct) == ["scales"]
+    worst_r = 0.0
+    for it in range(3):
+        gdp()
+        torch.cuda.synchronize()
+        assert all(arena.holds(gp[k].grad) for k in KEYS) and gdp.wire == wire_s
+        for k in KEYS:
+            want = eager[k] + (0.37 * (1 + world) / 2 if k == "scales" else 0.0)     # the mean over ranks of the direct term
+            worst_r = max(worst_r, float((gp[k].grad - want).abs().max()) / (float(want.abs().max()) + 1e-30))
+    # compute_only: the launches without the exchange leave this rank's own geometry gradients (+ its direct term) in the bucket
+    gdp.compute_only()
+    torch.cuda.synchronize()
+    gdp.check()
+    gdp.close()
     if rank == 0:
-        torch.save({"grads": {k: eager[k].cpu() for k in KEYS}, "wire": int(wire), "graph_vs_eager": worst}, path)
+        torch.save({"grads": {k: eager[k].cpu() for k in KEYS}, "wire": int(wire), "graph_vs_eager": worst, "sliced_vs_eager": worst_s,
+                    "sliced_graph_with_direct_term_vs_eager": worst_r}, path)
     dns.set_grad_arena(None)
     dns.set_sh_exchange(None)
     torch.distributed.barrier()
@@ -116,3 +157,6 @@ def test_two_ranks_on_one_gpu_average_like_one_process(tmp_path):
     assert got["wire"] > 0
     # graph replay + eager exchange gave the gradients of the fully eager step (same kernels; the atomics' order differs)
     assert got["graph_vs_eager"] <= 2e-5, got["graph_vs_eager"]
+    # the sliced exchange (4 slice launches + 4 slab all-gathers), eager and recorded behind a graph replay with a direct term
+    assert got["sliced_vs_eager"] <= 2e-5, got["sliced_vs_eager"]
+    assert got["sliced_graph_with_direct_term_vs_eager"] <= 2e-5, got["sliced_graph_with_direct_term_vs_eager"]
