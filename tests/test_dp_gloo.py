@@ -81,7 +81,9 @@ def _worker(rank, world, port, ret):
         tot = torch.zeros(n, K, 3)
         for v in range(w):
             co = torch.zeros(n, K, 3, requires_grad=True)
-            cols_v, pos_v = gathered[v, :3 * n].reshape(n, 3), gathered[v, 3 * n:3 * n + 3]
+            # copies: the sliced exchange keeps all slices' receive buffers in ONE tensor, and an all-gather of another slice that
+            # is still in flight bumps the version counter autograd checks on views of it
+            cols_v, pos_v = gathered[v, :3 * n].reshape(n, 3).clone(), gathered[v, 3 * n:3 * n + 3].clone()
             dirs_v = torch.nn.functional.normalize(means_ - pos_v, dim=-1)
             (dense_ref.sh_colors(deg, dirs_v, co) * cols_v).sum().backward()
             tot += co.grad
