@@ -488,9 +488,14 @@ class _ProjectFn(torch.autograd.Function):
                 # the exchange, graph.GraphedDpStep issues launch k + all-gather k behind each replay; the geometry gradients are
                 # then NOT handed to autograd (None): the launches write the bucket slices, which GraphedDpStep installs as .grad.
                 slabs = ex.begin(N, dev, cfg.sh_degree, sh_K, means=means)
-                g_all = dict(v_means=v_means, v_quats=v_quats, v_scales=v_scales, v_opac=v_opac, v_sh0=v_sh0, v_shN=v_shN)
+                # what the recorded launches read must stay allocated (graph-pool tensors of the captured backward).  NOT the gradient
+                # tensors: they are slices of the bucket, which outlives the step — and autograd adopts a returned gradient as .grad
+                # only while nobody else holds it (a second reference here made it clone v_sh0 / v_shN out of the bucket)
                 launches, keep = [], [means, quats, scales, opacities, sh0, shN, viewmat, K, normal_frame, radii, vs_c, v_m2d, v_dep, v_con,
-                                      slabs, g_all]
+                                      slabs]
+                if ex.record_only and (GRAD_ARENA is None or not all(GRAD_ARENA.holds(t) for t in (v_means, v_quats, v_scales, v_opac, v_sh0, v_shN))):
+                    raise _lib.DnsplatError("the sliced exchange in recorded mode needs the gradients in a dp.GradArena (set_grad_arena) "
+                                            "and .grad = None when the captured backward starts")
                 for k, (g0, g1) in enumerate(ex.bounds):
                     sc_k = _scene_struct(g1 - g0, means[g0:g1], quats[g0:g1], scales[g0:g1], opacities[g0:g1], cfg, sh0[g0:g1], 3,
                                          shN[g0:g1], 3 * (sh_K - 1), sh_K, None)

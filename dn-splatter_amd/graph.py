@@ -175,6 +175,7 @@ class GraphedDpStep:
 
         try:
             self.step = GraphedStep(compute, params={k: params[k] for k in dp.GRAD_KEYS}, **kw)
+            self._adopt_recorded(dp)
         except BaseException:
             # warm-up or capture failed (overflow, capture error): the caller falls back to the eager step with the SAME exchange
             # object, which must start its all-gather from the backward again and must not find the warm-up's factors pending
@@ -182,8 +183,17 @@ class GraphedDpStep:
                 exchange.deferred = False
                 if self.sliced:
                     exchange.record_only = False
+                    exchange.records = None
                 exchange.drop()
+                if getattr(self, "step", None) is not None:
+                    self.step.close()
             raise
+        # what ShFactorExchange.begin() recorded while the backward was captured: restored before every exchange, because a replay
+        # runs no Python
+        self._meta = exchange.meta if exchange is not None else None
+
+    def _adopt_recorded(self, dp) -> None:
+        exchange, params, arena = self.exchange, self.params, self.arena
         if self.sliced:
             if exchange.records is None:
                 raise _lib.DnsplatError("GraphedDpStep: the captured step never reached the projection backward (no slices recorded)")
@@ -200,9 +210,6 @@ class GraphedDpStep:
                 if not arena.holds(params[k].grad):
                     raise _lib.DnsplatError(f"GraphedDpStep: {k}.grad is not a slice of the gradient bucket — a loss term that feeds "
                                             "the SH coefficients directly cannot be combined with the factor exchange")
-        # what ShFactorExchange.begin() recorded while the backward was captured: restored before every exchange, because a replay
-        # runs no Python
-        self._meta = exchange.meta if exchange is not None else None
 
     def compute_only(self):
         """Replay without the exchange (bench.py: what the step costs when nothing travels)."""
