@@ -203,7 +203,7 @@ def side_section(workload, steps, losses=None, tight=True, shared=None, rank=0):
             if batch is not None and losses == "fused":
                 fused_loss.dn_loss_fused(out, batch, gp["scales"], counts=loss_counts).backward()
             elif batch is not None:
-                torch_losses.dn_loss(out, batch, gp["scales"]).backward()
+                torch_losses.dn_loss(out, batch, gp["scales"], capturable=(losses == "torch_capturable")).backward()
             else:
                 torch.autograd.backward([out[k] for k in OUT_KEYS], [cot[k] for k in OUT_KEYS])
 
@@ -490,9 +490,11 @@ def main():
                          "step has no collective in it (one rank) and runs the fused path; falls back to eager launches if the capture fails")
     ap.add_argument("--two-call", action="store_true", help="reference's two-pass sequence instead of the fused pass")
     ap.add_argument("--torch-postops", action="store_true", help="keep dn_model.py:526-603 in torch instead of the HIP epilogue")
-    ap.add_argument("--losses", nargs="?", const="torch", default=None, choices=["torch", "fused"],
+    ap.add_argument("--losses", nargs="?", const="torch", default=None, choices=["torch", "torch_capturable", "fused"],
                     help="time dn-splatter's loss stack (L1+SSIM, EdgeAwareLogL1 depth, normal L1+TV, scale) instead of feeding "
-                         "random cotangents (BASELINE config C5): 'torch' = as the reference does, 'fused' = dnsplat_dn_loss")
+                         "random cotangents (BASELINE config C5): 'torch' = as the reference does (its boolean-mask gathers need the "
+                         "host: no graph capture, eager launches), 'torch_capturable' = the same PyTorch stack with the masked means as "
+                         "sum / count (capturable), 'fused' = dnsplat_dn_loss")
     ap.add_argument("--lean", action="store_true",
                     help="profiling runs (rocprofv3 --kernel-trace / --pmc serialise every launch): eager launches, no pre-roll, no "
                          "counting step, no strict-index-parity section")
@@ -578,7 +580,7 @@ def main():
         if batch is not None and args.losses == "fused":
             fused_loss.dn_loss_fused(out, batch, gp["scales"], counts=loss_counts).backward()
         elif batch is not None:
-            torch_losses.dn_loss(out, batch, gp["scales"]).backward()
+            torch_losses.dn_loss(out, batch, gp["scales"], capturable=(args.losses == "torch_capturable")).backward()
         else:
             # the losses stay in PyTorch (north star); their result is a dense cotangent per output image
             torch.autograd.backward([out[k] for k in OUT_KEYS], [cot[k] for k in OUT_KEYS])
@@ -663,7 +665,7 @@ def main():
             if batch is not None and args.losses == "fused":
                 fused_loss.dn_loss_fused(out, batch, gp["scales"], counts=loss_counts).backward()
             elif batch is not None:
-                torch_losses.dn_loss(out, batch, gp["scales"]).backward()
+                torch_losses.dn_loss(out, batch, gp["scales"], capturable=(args.losses == "torch_capturable")).backward()
             else:
                 torch.autograd.backward([out[k] for k in OUT_KEYS], [cot[k] for k in OUT_KEYS])
 
@@ -859,7 +861,8 @@ def main():
         # ---- the other BASELINE configurations, so that the driver's record carries them
         if args.workload == "c2" and not args.no_extra_workloads and not args.losses:
             extras = {}
-            for name, wl, ls in (("c3", "c3", None), ("c5", "c5", None), ("c5_fused_loss", "c5", "fused"), ("c5_torch_loss", "c5", "torch")):
+            for name, wl, ls in (("c3", "c3", None), ("c5", "c5", None), ("c5_fused_loss", "c5", "fused"), ("c5_torch_loss", "c5", "torch"),
+                                 ("c5_torch_loss_capturable", "c5", "torch_capturable")):
                 extras[name] = child_workload(wl, ls, max(5, min(10, args.steps)))
             # the north star's C5 ("depth + mono-normal loss enabled", losses in PyTorch-ROCm: regularization_strategy.py:146-199,
             # losses.py:187-224) is c5_torch_loss; c5_fused_loss is the same loss stack as two HIP launches (N2)

@@ -59,15 +59,21 @@ def _drow(t: Tensor) -> Tensor:
     return t[:-1] - t[1:]
 
 
-def edge_aware_log_l1(pred: Tensor, gt: Tensor, rgb: Tensor, mask: Optional[Tensor]) -> Tensor:
+def edge_aware_log_l1(pred: Tensor, gt: Tensor, rgb: Tensor, mask: Optional[Tensor], capturable: bool = False) -> Tensor:
     """Scalar EdgeAwareLogL1 (losses.py:187-224): log(1 + |pred - gt|), down-weighted across image edges by
     exp(-mean_c |colour difference to the right / lower neighbour|), averaged over the masked pixels separately for the
-    horizontal and the vertical term."""
+    horizontal and the vertical term.
+    ``capturable``: the masked means as sum(term x mask) / sum(mask) instead of the reference's boolean-mask gather
+    ``term[mask].mean()`` — the gather's output size is data dependent (a host synchronisation: the step cannot be captured into
+    a HIP graph); same value and gradients up to the order of the fp32 sums."""
     err = torch.log(1 + (pred - gt).abs())
     edge_x = torch.exp(-_dcol(rgb).abs().mean(dim=-1, keepdim=True))
     edge_y = torch.exp(-_drow(rgb).abs().mean(dim=-1, keepdim=True))
     term_x = edge_x * err[:, :-1]
     term_y = edge_y * err[:-1]
+    if mask is not None and capturable:
+        mx, my = mask[:, :-1].to(term_x.dtype), mask[:-1].to(term_y.dtype)
+        return (term_x * mx).sum() / mx.sum() + (term_y * my).sum() / my.sum()
     if mask is not None:
         term_x = term_x[mask[:, :-1]]
         term_y = term_y[mask[:-1]]
@@ -89,7 +95,8 @@ def rgb_term(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], ssim_lambda: 
 
 
 def regularization_term(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], scales: Tensor, depth_lambda: float = 0.2,
-                        depth_tolerance: float = 0.1, use_depth_loss: bool = True, use_normal_loss: bool = True) -> Tensor:
+                        depth_tolerance: float = 0.1, use_depth_loss: bool = True, use_normal_loss: bool = True,
+                        capturable: bool = False) -> Tensor:
     """What dn-splatter itself adds in get_loss_dict (dn_model.py:629-727) for regularization_strategy == "dn-splatter" with mono
     depth / mono normal supervision: ``DNRegularization.get_loss`` (regularization_strategy.py:146-199) on the ground truths the
     method picks — the image clamped at 10/255 for the edge weights (:633), depth, both normals and their ground truths multiplied
@@ -106,7 +113,7 @@ def regularization_term(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], sc
     loss = torch.min(torch.exp(scales), dim=1, keepdim=True)[0].mean()              # regularization_strategy.py:195-199
     if use_depth_loss and gt_depth is not None:
         valid = gt_depth > depth_tolerance                                          # :162
-        d = edge_aware_log_l1(depth_out, gt_depth.float(), gt_img, valid)
+        d = edge_aware_log_l1(depth_out, gt_depth.float(), gt_img, valid, capturable)
         loss = loss + (d + depth_lambda * d)                                        # :184
     if use_normal_loss and gt_normal is not None:
         loss = loss + torch.abs(pred_normal - gt_normal).mean() + tv_loss(pred_normal)   # :188-193
@@ -115,11 +122,11 @@ def regularization_term(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], sc
 
 def dn_loss(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], scales: Tensor, ssim_lambda: float = 0.2,
             depth_lambda: float = 0.2, depth_tolerance: float = 0.1, use_depth_loss: bool = True,
-            use_normal_loss: bool = True) -> Tensor:
+            use_normal_loss: bool = True, capturable: bool = False) -> Tensor:
     """main_loss of ``DNSplatterModel.get_loss_dict`` for regularization_strategy == "dn-splatter" with mono depth
     and mono normal supervision (dn_model.py:614-729): rgb_loss + regularization_strategy_loss (:727)."""
     return rgb_term(outputs, batch, ssim_lambda) + regularization_term(outputs, batch, scales, depth_lambda, depth_tolerance,
-                                                                       use_depth_loss, use_normal_loss)
+                                                                       use_depth_loss, use_normal_loss, capturable)
 
 
 def synthetic_batch(width: int, height: int, device, seed: int = 0) -> Dict[str, Tensor]:

@@ -315,3 +315,25 @@ def test_lazy_info_copies_force_their_lazy_entries(dns):
     n = len(calls)
     assert i["isect_ids"] == 42 and len(calls) == n          # computed once
     assert isinstance(i, dict)
+
+
+def test_capturable_torch_losses_equal_the_reference_form():
+    """torch_losses.dn_loss(capturable=True) — masked means as sum / count, so that the step can be replayed as a HIP graph —
+    against the reference's boolean-mask gathers (losses.py:216-222): same value, same gradients."""
+    from dn_splatter_amd import torch_losses
+
+    W, H, N = 40, 28, 50
+    g = torch.Generator().manual_seed(3)
+    batch = torch_losses.synthetic_batch(W, H, "cpu", seed=2)
+    batch["mono_depth"][::3, ::2] = 0.05                     # below the depth tolerance: masked out
+    res = []
+    for cap in (False, True):
+        out = {"rgb": torch.rand(H, W, 3, generator=torch.Generator().manual_seed(4)).requires_grad_(True),
+               "depth": (torch.rand(H, W, 1, generator=torch.Generator().manual_seed(5)) * 8 + 0.3).requires_grad_(True),
+               "normal": torch.rand(H, W, 3, generator=torch.Generator().manual_seed(6)).requires_grad_(True)}
+        scales = torch.randn(N, 3, generator=torch.Generator().manual_seed(7)).requires_grad_(True)
+        loss = torch_losses.dn_loss(out, batch, scales, capturable=cap)
+        loss.backward()
+        res.append((loss.detach(), out["rgb"].grad, out["depth"].grad, out["normal"].grad, scales.grad))
+    for a, b in zip(*res):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-8), float((a - b).abs().max())
