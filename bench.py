@@ -63,6 +63,7 @@ WORKLOADS = {
 OUT_KEYS = ("rgb", "depth", "normal", "accumulation")
 STAGE_NAMES = ("dnsplat_project_fwd", "binning", "dnsplat_raster_fwd", "dnsplat_raster_bwd", "dnsplat_project_bwd")
 PROBE_STEPS = 3
+CPU_BASELINE_THREADS = 64     # team size of the cpu_baseline leg (set from the scaling run in profiles/, see cpu_baseline())
 FIRST_TOUCH_STEPS = 2
 # The chip clocks down within milliseconds of idling and needs ~30 ms of load to come back (first steps after an idle gap:
 # 2.9, 3.06, 2.84, 2.79 ... ms against 2.53 ms from the twelfth on).  Everything untimed that makes the GPU wait for the host
@@ -124,9 +125,10 @@ def cpu_baseline(workload, crop=None):
     from oracle import oracle as orc
 
     N, W, H, focal = WORKLOADS[workload]
-    # the crop has a few thousand tiles (the oracle parallelises over tiles) and its gradient scatter uses omp atomics:
-    # beyond ~32 threads it only gets slower (measured: 49 s on 256 threads vs 14 s on 8), so cap the team there
-    cores = min(os.cpu_count() or 1, 32)
+    # the oracle parallelises over tiles (8160 at C2); since round 5 its gradient scatter adds up a (tile, splat) row locally and
+    # issues ONE atomic row per (tile, splat) instead of one atomic per (pixel, splat, component), which had capped the useful team
+    # at ~32 threads (49 s on 256 threads vs 14 s on 8).  DNSPLAT_CPU_THREADS overrides the team size (scaling runs).
+    cores = int(os.environ.get("DNSPLAT_CPU_THREADS", "0")) or min(os.cpu_count() or 1, CPU_BASELINE_THREADS)
     torch.set_num_threads(cores)     # torch and the oracle share the process' OpenMP runtime (libgomp)
     gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=0)
     cam = synthetic.orbit_camera(0, width=W, height=H, focal=focal)
@@ -154,7 +156,7 @@ def cpu_baseline(workload, crop=None):
         "sample": (f"oracle fwd+bwd of {'one full ' + str(cw) + 'x' + str(ch) + ' frame' if scale == 1.0 else 'a ' + str(cw) + 'x' + str(ch) + ' centre crop'} "
                    f"of the {workload} scene (all {N} Gaussians projected, "
                    f"{int(m.last_info['flatten_ids'].shape[0])} intersections) took {dt:.2f} s on {cores} of the host's "
-                   f"{os.cpu_count()} hardware threads (the oracle's gradient scatter uses omp atomics and gets slower beyond ~32)"
+                   f"{os.cpu_count()} hardware threads (one process, OpenMP over tiles; team size from the scaling run in profiles/)"
                    + ("" if scale == 1.0 else f"; value = 1/(t x {scale:.1f} pixel ratio)")),
     }
 
