@@ -63,7 +63,10 @@ WORKLOADS = {
 OUT_KEYS = ("rgb", "depth", "normal", "accumulation")
 STAGE_NAMES = ("dnsplat_project_fwd", "binning", "dnsplat_raster_fwd", "dnsplat_raster_bwd", "dnsplat_project_bwd")
 PROBE_STEPS = 3
-CPU_BASELINE_THREADS = 64     # team size of the cpu_baseline leg (set from the scaling run in profiles/, see cpu_baseline())
+# team size of the cpu_baseline leg, from profiles/r05b_cpu_baseline_scaling.txt: one C2 frame takes 5.4 / 5.6 / 6.1 / 9.0 / 60 s on
+# 16 / 32 / 64 / 128 / 256 threads of the GPU box's host (the tile-parallel compositing no longer limits it: what is left is the
+# single-threaded 64-bit sort of the 21 M pairs and torch's own ops; 256 threads oversubscribe the cores torch's pool also uses)
+CPU_BASELINE_THREADS = 32
 FIRST_TOUCH_STEPS = 2
 # The chip clocks down within milliseconds of idling and needs ~30 ms of load to come back (first steps after an idle gap:
 # 2.9, 3.06, 2.84, 2.79 ... ms against 2.53 ms from the twelfth on).  Everything untimed that makes the GPU wait for the host
@@ -156,7 +159,7 @@ def cpu_baseline(workload, crop=None):
         "sample": (f"oracle fwd+bwd of {'one full ' + str(cw) + 'x' + str(ch) + ' frame' if scale == 1.0 else 'a ' + str(cw) + 'x' + str(ch) + ' centre crop'} "
                    f"of the {workload} scene (all {N} Gaussians projected, "
                    f"{int(m.last_info['flatten_ids'].shape[0])} intersections) took {dt:.2f} s on {cores} of the host's "
-                   f"{os.cpu_count()} hardware threads (one process, OpenMP over tiles; team size from the scaling run in profiles/)"
+                   f"{os.cpu_count()} hardware threads (one process, OpenMP over tiles; team size from profiles/r05b_cpu_baseline_scaling.txt)"
                    + ("" if scale == 1.0 else f"; value = 1/(t x {scale:.1f} pixel ratio)")),
     }
 
@@ -484,9 +487,11 @@ def main():
                          "waits for it in the steady state (verified as soon as it has arrived, an overflow raises)")
     ap.add_argument("--dense-allreduce", action="store_true",
                     help="all-reduce the full 236 B/Gaussian bucket instead of exchanging the SH gradients as factors")
-    ap.add_argument("--slices", type=int, default=4,
+    ap.add_argument("--slices", type=int, default=1,
                     help="N > 1 ranks (or DNSPLAT_FORCE_DIST=1): the projection backward as this many slices of Gaussians, slice k's "
-                         "colour-gradient slab all-gathered while slices k+1.. compute (dp.SlicedShExchange); 1 = one launch, one slab")
+                         "colour-gradient slab all-gathered while slices k+1.. compute (dp.SlicedShExchange); 1 (default) = one launch, "
+                         "one slab: measured on one rank through RCCL every extra slice costs ~0.05 ms of launches and stream "
+                         "hand-overs (profiles/r05b_*rccl*), more than the earlier start of the links buys at 1 M Gaussians")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step (get_outputs + backward) as a captured HIP graph (dn-splatter_amd/graph.py): 'auto' = when the "
                          "step has no collective in it (one rank) and runs the fused path; falls back to eager launches if the capture fails")

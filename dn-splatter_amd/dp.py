@@ -411,8 +411,14 @@ def allreduce_gradients(params: Dict[str, Tensor], arena: Optional[GradArena] = 
         if arena is None or not all(arena.holds(params[k].grad) for k in GEOMETRY_KEYS):
             raise RuntimeError("the SH factor exchange needs the gradients in a GradArena (dp.GradArena + set_grad_arena)")
         n_geo = sum(arena.slices[k][1] for k in GEOMETRY_KEYS)
-        if isinstance(exchange, SlicedShExchange) and exchange.works is None:
-            exchange.works = [exchange.gather_slice(k, group) for k in range(len(exchange.bounds))]      # the slabs first
+        # the slabs first: their all-gather is what the rebuild waits for, and the rebuild (on the compute stream) then runs
+        # while the geometry all-reduce, queued behind the gather on the communication stream, is still travelling
+        if isinstance(exchange, SlicedShExchange):
+            if exchange.works is None:
+                exchange.works = [exchange.gather_slice(k, group) for k in range(len(exchange.bounds))]
+        elif exchange.work is None and _collectives_on(group):
+            buf = exchange._gather_buffer(world_size(group))
+            exchange.work = dist.all_gather_into_tensor(buf.view(-1), exchange.mine.view(-1), group=group, async_op=True)
         # the geometry all-reduce is queued behind the factor all-gather on the communication stream and runs while the
         # SH rows are rebuilt from the gathered factors on the compute stream
         geo = allreduce_mean_(arena.flat[:n_geo], group, async_op=True)
