@@ -949,6 +949,10 @@ def main():
                             else "compute = one HIP graph replay per step, the collectives issued eagerly behind it (graph.GraphedDpStep)"
                             if gdp is not None else "eager launches from Python"),
                  "bytes_exchanged_per_gpu_per_step": int(wire),
+                 # what the collectives sustained when nothing else ran (bytes received + sent per direction / exchange_alone_ms);
+                 # DESIGN.md 6 prices the 8-GPU step on an ASSUMED 400 GB/s per GPU and direction: this is the number to compare
+                 "exchange_alone_GBps_per_gpu": (round(wire / (t_comm * 1e-3) / 1e9, 1) if (world > 1 and t_comm > 0) else None),
+                 "exchange_alone_includes_project_bwd_slices": bool(gdp is not None and gdp.sliced),
                  "bytes_per_xgmi_link_per_step": int(wire / (world - 1)) if world > 1 else None,
                  "link_note": ("per-GPU bytes spread evenly over the W-1 direct xGMI links of the fully connected node" if world > 1
                                else "one rank: the collectives ran through RCCL but nothing crossed a link"),

@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# (Round 4 used tools/r04_set.sh: same parts, PMC traffic BEFORE the bench line that reads it, a 40-step profiled run, frame timeline.)
+# (Round 5 used tools/r05_set.sh; round 4 tools/r04_set.sh: same parts, PMC traffic BEFORE the bench line that reads it, a 40-step profiled run, frame timeline.)
 # Everything a round's profiles/ entry is made of, in one GPU call (about 12 minutes):
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/round_end.sh'   ->  gpurun_out/round_end/
 # then copy: bench_*.json -> profiles/rNNx_*_bench.json, kernel_stats.csv, pmc_traffic.merged.json -> profiles/pmc_traffic.json
