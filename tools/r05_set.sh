@@ -43,6 +43,17 @@ python - $O/bench_c2_single_rank_rccl.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print("rccl", d["value"], d["ms_per_step"], json.dumps(d.get("multi_gpu"))[:700])
 PY
+echo "== the whole --gpus 2 flow of bench.py with two REAL ranks sharing this GPU (gloo carries the collectives: RCCL refuses two ranks"
+echo "   per device) — not a performance figure: the N > 1 code path of the driver's scaling run, end to end, for the first time"
+DNSPLAT_DIST_BACKEND=gloo DNSPLAT_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 6 --warmup 2 > $O/bench_c2_two_ranks_one_gpu_gloo.json 2> $O/two_ranks.err; echo "rc=$?"
+python - $O/bench_c2_two_ranks_one_gpu_gloo.json <<'PY'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]).read().strip().splitlines() if l.startswith("{")][-1])
+    print("two ranks / one GPU / gloo:", d["value"], "fps (2 cameras)", d["ms_per_step"], "ms |", d["launch"][:80]); print(json.dumps(d.get("multi_gpu"))[:900])
+except Exception as e: print("unreadable", e)
+PY
+grep -v "amdgpu.ids\|socket.cpp\|UserWarning\|run_backward\|^\[W\|OMP_NUM_THREADS\|^\*\*\*" $O/two_ranks.err | tail -5 | cut -c1-300
 if [ -z "${SKIP_SWEEP:-}" ]; then
 echo "== parity seed sweeps (60 unseen scenes): deterministic mode x3 runs, default mode"
 DNSPLAT_DETERMINISTIC=1 timeout 900 python tools/parity_seed_sweep.py 100 30 3 2>&1 | grep -v amdgpu > $O/parity_seed_sweep_deterministic.txt; tail -2 $O/parity_seed_sweep_deterministic.txt
