@@ -251,5 +251,6 @@ def after_refinement(new_params: Dict[str, Tensor], stats=None, report: Optional
         arena = dp.GradArena({k: new_params[k] for k in dp.GRAD_KEYS})
         _ops.set_grad_arena(arena)
     if _ops.SH_EXCHANGE is not None:
-        _ops.set_sh_exchange(dp.ShFactorExchange())
+        old = _ops.SH_EXCHANGE       # the same kind of exchange (dp.SlicedShExchange keeps its slice count)
+        _ops.set_sh_exchange(dp.SlicedShExchange(old.slices) if isinstance(old, dp.SlicedShExchange) else dp.ShFactorExchange())
     return arena
