@@ -259,6 +259,20 @@ def forget_capacity_guesses(device=None) -> None:
         del BUFFERS.capacity_hint[k]
 
 
+def carry_capacity_guesses(device, n_old: int, n_new: int, slack: float = 1.1) -> int:
+    """The Gaussian set changed size (densify.after_refinement): instead of forgetting what the frames of the old size needed —
+    which costs the next capture a round of eager frames over every pose just to size its buffers again — scale each guess by
+    n_new / n_old x ``slack`` and file it under the new size.  A guess is a capacity, not a promise: a frame that outgrows it is
+    reported by the bin policy in force (``GraphedStep.check()`` raises and enlarges it).  Returns the number of guesses carried."""
+    carried = 0
+    for k in [k for k in BUFFERS.capacity_hint if (device is None or k[0] == device) and k[1] == n_old]:
+        hint = BUFFERS.capacity_hint.pop(k)
+        nk = (k[0], n_new) + tuple(k[2:])
+        BUFFERS.capacity_hint[nk] = max(BUFFERS.capacity_hint.get(nk, 0), int(hint * (n_new / max(n_old, 1)) * slack) + 4096)
+        carried += 1
+    return carried
+
+
 def forget_static(device, stream) -> None:
     """Drops the "static" policy's per-stream records (running maxima, capacities) of ``stream``: called when the GraphedStep that
     owned the stream is discarded, so that they do not accumulate across re-captures."""

@@ -245,7 +245,13 @@ def after_refinement(new_params: Dict[str, Tensor], stats=None, report: Optional
     # the capacity guesses / static capacities / running maxima are keyed by the number of Gaussians: those of the old size would
     # only accumulate (the scratch buffers themselves are grow-only and stay)
     dev = new_params["means"].device
-    _ops.forget_capacity_guesses(dev if dev.type == "cuda" else None)
+    n_new, n_old = int(new_params["means"].shape[0]), (report or {}).get("n_before")
+    if n_old and n_old != n_new:
+        # ... carried over to the new size in proportion (a capture right after the refinement then needs no eager frames over the
+        # poses to size its buffers again: _ops.carry_capacity_guesses); without the report they are dropped
+        _ops.carry_capacity_guesses(dev if dev.type == "cuda" else None, int(n_old), n_new)
+    elif not n_old:
+        _ops.forget_capacity_guesses(dev if dev.type == "cuda" else None)
     arena = None
     if _ops.GRAD_ARENA is not None:
         arena = dp.GradArena({k: new_params[k] for k in dp.GRAD_KEYS})

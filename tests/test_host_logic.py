@@ -337,3 +337,30 @@ def test_capturable_torch_losses_equal_the_reference_form():
         res.append((loss.detach(), out["rgb"].grad, out["depth"].grad, out["normal"].grad, scales.grad))
     for a, b in zip(*res):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-8), float((a - b).abs().max())
+
+
+def test_capacity_guesses_are_carried_over_a_refinement(dns):
+    """densify.after_refinement(report=...) files the binning's capacity guesses of the old Gaussian count under the new one, scaled
+    by n_new / n_old (x 1.1), instead of dropping them: the capture that follows needs no eager frames to size its buffers again.
+    Without a report (or on another device) nothing is guessed."""
+    from dn_splatter_amd import _ops, densify
+
+    dev = torch.device("cpu")
+    hints = _ops.BUFFERS.capacity_hint
+    saved = dict(hints)
+    try:
+        hints.clear()
+        hints[(dev, 1000, 640, 480)] = 50_000
+        hints[(dev, 1000, 320, 240)] = 20_000
+        hints[(dev, 777, 640, 480)] = 9_000                       # another Gaussian set: untouched
+        new = {"means": torch.zeros(1500, 3)}
+        densify.after_refinement(new, report={"n_before": 1000})
+        assert hints[(dev, 1500, 640, 480)] == int(50_000 * 1.5 * 1.1) + 4096 and hints[(dev, 1500, 320, 240)] == int(20_000 * 1.5 * 1.1) + 4096
+        assert (dev, 1000, 640, 480) not in hints and hints[(dev, 777, 640, 480)] == 9_000
+        densify.after_refinement({"means": torch.zeros(1500, 3)}, report={"n_before": 1500})     # size unchanged: guesses stay
+        assert hints[(dev, 1500, 640, 480)] == int(50_000 * 1.5 * 1.1) + 4096
+        densify.after_refinement({"means": torch.zeros(900, 3)})                                  # no report: dropped (all of the device)
+        assert not any(k[0] == dev for k in hints)
+    finally:
+        hints.clear()
+        hints.update(saved)
