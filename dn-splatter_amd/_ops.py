@@ -774,7 +774,7 @@ class LazyInfo(dict):
         return iter(list(super().keys()))
 
     def keys(self):
-        return list(super().keys())
+        return super().keys()          # a view, as for any dict (set operations on it keep working)
 
     def _forced(self) -> dict:
         for k in list(self._lazy):
