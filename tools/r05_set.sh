@@ -25,6 +25,12 @@ print("eager", d.get("eager_drop_in"))
 for k, v in (d.get("extra_workloads") or {}).items(): print(k, v.get("value"), v.get("ms_per_step"), str(v.get("launch"))[:70], v.get("error"))
 print("valu", {k: v for k, v in (d.get("roofline_valu") or {}).items() if k.startswith("dnsplat")}); print("cpu", d.get("cpu_baseline"))
 PY
+echo "== the other ways in (INTEGRATION.md A / B): two drop-in calls inside the reference's op sequence; fused pass with torch post-ops"
+for m in --two-call --torch-postops; do
+  python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-strict --no-extra-workloads $m 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$m', d['value'], 'frames/s', d['ms_per_step'], 'ms |', d['launch'][:50])" | tee -a $O/bench_modes.txt
+done
 echo "== kernel stats"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof" -o trace -- python "$R/bench.py" --steps 40 --warmup 5 --no-cpu-baseline --lean > "$R/$O/prof_bench.json" 2> "$R/$O/prof.err"); echo "rocprof rc=$?"
 cp $(find $O/prof -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv 2>/dev/null; rm -rf $O/prof
