@@ -299,6 +299,12 @@ ROW_P99 = 1e-4
 ROW_MAX = 2e-3
 PIX_P99 = 1e-5
 PIX_MAX = 1e-4
+# Default (atomics) mode, where the arrival order of ~30 atomic rows per Gaussian adds its own noise: measured over the suite
+# (profiles/r05c_rowrel.tsv) outside the envelope p99 <= 9.0e-5, max <= 1.3e-3; where a test computes no fp64 run (no envelope) the
+# raw statistics are p99 <= 5.0e-4, max <= 8.0e-3 (C5 frame, opacities).  Asserted with a factor ~2-4 of room — a guard against a
+# kernel that corrupts whole rows which the tensor-scale comparison would not see, not a statement about rounding.
+ROW_P99_DEFAULT, ROW_MAX_DEFAULT = 2e-4, 5e-3
+ROW_P99_RAW, ROW_MAX_RAW = 1e-3, 2e-2
 
 
 def row_rel_stats(a, b, b64=None, floor=ROW_FLOOR):
@@ -341,9 +347,15 @@ def both_sides_order_independent(orc) -> bool:
     return bool(_ops.DETERMINISTIC["on"]) and bool(orc.lib().orc_get_exact_accum())
 
 
-def check_rows(a, b, what, b64=None, enforce=False, p99=ROW_P99, rmax=ROW_MAX, n_rows=None):
-    """``n_rows``: reshape to [n_rows, -1] first (one row per Gaussian whatever the trailing shape)."""
+def check_rows(a, b, what, b64=None, enforce=False, p99=None, rmax=None, n_rows=None, strict=True):
+    """``n_rows``: reshape to [n_rows, -1] first (one row per Gaussian whatever the trailing shape).  ``strict``: both sides sum
+    order-independently (the deterministic-mode bounds ROW_P99 / ROW_MAX); otherwise the default-mode guards (with / without an fp64
+    envelope)."""
     enforce = enforce and ROWREL_ENFORCE
+    if p99 is None:
+        p99 = ROW_P99 if strict else (ROW_P99_DEFAULT if b64 is not None else ROW_P99_RAW)
+    if rmax is None:
+        rmax = ROW_MAX if strict else (ROW_MAX_DEFAULT if b64 is not None else ROW_MAX_RAW)
     if n_rows is not None:
         a, b = a.detach().reshape(n_rows, -1), b.detach().reshape(n_rows, -1)
         b64 = None if b64 is None else b64.detach().reshape(n_rows, -1)
@@ -357,7 +369,7 @@ def check_rows(a, b, what, b64=None, enforce=False, p99=ROW_P99, rmax=ROW_MAX, n
     if log:
         with open(log, "a") as f:
             f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]}\t{what}\t{n}\t{tot}\t{p50:.3e}\t{p99_:.3e}\t{mx:.3e}\t{p99_out:.3e}\t"
-                    f"{mx_out:.3e}\t{'asserted' if enforce else 'logged'}\n")
+                    f"{mx_out:.3e}\t{('asserted <= %.0e / %.0e' % (p99, rmax)) if enforce else 'logged'}\n")
     if enforce:
         if p99_out > p99 or mx_out > rmax:
             print(f"[parity] {what}: ROW-RELATIVE BOUND EXCEEDED (p99 {p99_out:.3e} vs {p99:.1e}, max {mx_out:.3e} vs {rmax:.1e})")

@@ -123,12 +123,12 @@ def _check_backward(o, g, tol=REL_TOL, seed=1, absgrad=True, quat_atol=0.0, what
     for k in ci:
         if ci[k].grad is None or (k == "quats" and quat_atol > 0):
             continue
-        check_rows(gi[k].grad, ci[k].grad, f"{what} grad {k} per Gaussian", b64=None if g64 is None else g64.get(k), enforce=det, n_rows=N_)
+        check_rows(gi[k].grad, ci[k].grad, f"{what} grad {k} per Gaussian", b64=None if g64 is None else g64.get(k), enforce=True, strict=det, n_rows=N_)
     check_rows(info_g["means2d"].grad, info_o["means2d"].grad, f"{what} means2d.grad per Gaussian",
-               b64=None if g64 is None else g64.get("means2d"), enforce=det, n_rows=N_)
+               b64=None if g64 is None else g64.get("means2d"), enforce=True, strict=det, n_rows=N_)
     if absgrad:
         check_rows(info_g["means2d"].absgrad, info_o["means2d"].absgrad, f"{what} means2d.absgrad per Gaussian",
-                   b64=None if g64 is None else g64.get("means2d.absgrad"), enforce=det, n_rows=N_)
+                   b64=None if g64 is None else g64.get("means2d.absgrad"), enforce=True, strict=det, n_rows=N_)
 
 
 GRAD_NAMES = ("means", "scales", "quats", "features_dc", "features_rest", "opacities")
@@ -319,10 +319,10 @@ def _check_mirror(hip, ora, keep, what="mirror", quat_atol=0.0, ints=True):
     for k in GRAD_NAMES:
         if p_o[k].grad is None or (k == "quats" and quat_atol > 0) or p_o[k].grad.numel() == 0:
             continue
-        check_rows(p_g[k].grad, p_o[k].grad, f"{what} grad {k} per Gaussian", b64=None if g64 is None else g64.get(k), enforce=det, n_rows=N_)
-    check_rows(m_g.xys.grad, m_o.xys.grad, f"{what} xys.grad per Gaussian", b64=None if g64 is None else g64.get("xys"), enforce=det, n_rows=N_)
+        check_rows(p_g[k].grad, p_o[k].grad, f"{what} grad {k} per Gaussian", b64=None if g64 is None else g64.get(k), enforce=True, strict=det, n_rows=N_)
+    check_rows(m_g.xys.grad, m_o.xys.grad, f"{what} xys.grad per Gaussian", b64=None if g64 is None else g64.get("xys"), enforce=True, strict=det, n_rows=N_)
     check_rows(m_g.xys.absgrad, m_o.xys.absgrad, f"{what} xys.absgrad per Gaussian", b64=None if g64 is None else g64.get("xys.absgrad"),
-               enforce=det, n_rows=N_)
+               enforce=True, strict=det, n_rows=N_)
 
 
 # ------------------------------------------------------------------------------------------------
