@@ -41,3 +41,18 @@ def dns():
     import dn_splatter_amd as _dns
 
     return _dns
+
+
+@pytest.fixture
+def hip_deterministic(dns):
+    """The HIP path in its deterministic gradient mode for the duration of a test (dnsplat_det_reduce: every Gaussian's rows added in
+    list order in double).  For tests that compare TWO GPU runs of the same frame — batched vs sequential, exchange on vs off, tight
+    vs gsplat tile boxes: in the default mode the two differ by the arrival order of fp32 atomics, up to ~1e-4 of the tensor's scale
+    on ill-conditioned entries (an anisotropic scene's quaternion gradient drew 0.01 ... 0.9 of its allowance over the round's
+    runs); in this mode they must agree to the last bit or two, whatever the tolerance written in the test."""
+    from dn_splatter_amd import _ops
+
+    prev = _ops.DETERMINISTIC["on"]
+    dns.set_deterministic(True)
+    yield
+    dns.set_deterministic(prev)

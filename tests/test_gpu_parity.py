@@ -838,6 +838,7 @@ def test_batched_render_loop_equals_sequential(dns):
 
 
 @pytest.mark.parametrize("W,H", [(160, 128), (200, 120)])
+@pytest.mark.usefixtures("hip_deterministic")
 def test_multi_camera_rasterization_equals_sequential_calls_and_oracle(dns, orc, W, H):
     """gsplat.rasterization with viewmats [C,4,4] (N4): the C = 4 result equals 4 single-camera calls bit for bit (images,
     projections, per-camera tile lists), its integer outputs — flatten_ids = camera * N + g, isect_offsets [C,th,tw],
@@ -887,6 +888,7 @@ def test_multi_camera_rasterization_equals_sequential_calls_and_oracle(dns, orc,
 
 
 @pytest.mark.parametrize("layout,deferred", [("split", False), ("split", True), ("cat", False)])
+@pytest.mark.usefixtures("hip_deterministic")
 def test_sh_factor_exchange_rebuilds_the_multi_camera_gradient(dns, layout, deferred):
     """Data parallel: all-gathering the 3 colour gradients per Gaussian (+ each camera's position) and rebuilding the sum equals
     averaging the 192-byte coefficient gradients of the cameras (dp.ShFactorExchange, dnsplat_sh_grads_from_factors) — checked here
@@ -1372,6 +1374,7 @@ def test_full_size_image_properties_and_linearity(dns, full_scene):
             assert float(c[hidden].abs().max()) == 0.0, name
 
 
+@pytest.mark.usefixtures("hip_deterministic")
 def test_tight_tile_boxes_change_the_lists_not_the_images(dns):
     """dnsplat_camera.tight_tiles (the fused path's default): fewer (tile, Gaussian) pairs, the same composited numbers —
     forward images bit for bit (the pairs left out were skipped at every pixel anyway, the others are blended in the same
@@ -1427,6 +1430,7 @@ def test_tight_tile_boxes_change_the_lists_not_the_images(dns):
         assert_close(g1[k], g0[k], "tight vs gsplat boxes: grad " + k, tol=1e-5)
 
 
+@pytest.mark.usefixtures("hip_deterministic")
 def test_extra_terms_on_means2d_add_to_the_compositing_gradient(dns, orc):
     """info["means2d"] is an autograd tensor like any other: a loss term hung on it directly must ADD to the screen-space
     gradient the compositing backward leaves in the records (which reaches `.grad` without autograd's clone, _ops.py)."""
