@@ -67,6 +67,9 @@ PROBE_STEPS = 3
 # 16 / 32 / 64 / 128 / 256 threads of the GPU box's host (the tile-parallel compositing no longer limits it: what is left is the
 # single-threaded 64-bit sort of the 21 M pairs and torch's own ops; 256 threads oversubscribe the cores torch's pool also uses)
 CPU_BASELINE_THREADS = 32
+# a side section (another workload / the train loop, in a process of its own) normally takes 5-10 s on the GPU box, a fresh box's
+# first torch import up to two minutes: a child that exceeds this is reported as an error in its entry, the headline line is not held up
+CHILD_TIMEOUT_S = 240
 FIRST_TOUCH_STEPS = 2
 # The chip clocks down within milliseconds of idling and needs ~30 ms of load to come back (first steps after an idle gap:
 # 2.9, 3.06, 2.84, 2.79 ... ms against 2.53 ms from the twelfth on).  Everything untimed that makes the GPU wait for the host
@@ -447,7 +450,7 @@ def train_loop_section(workload, steps, rank=0):
     print(json.dumps(res), flush=True)
 
 
-def child_section(section, steps, timeout=420):
+def child_section(section, steps, timeout=None):
     """Runs ``bench.py --section <section>`` in a process of its own (a second capture with other buffer sizes inside one process has
     crashed the HIP runtime before, see child_workload) and returns the LAST JSON line it printed."""
     import subprocess
@@ -457,7 +460,7 @@ def child_section(section, steps, timeout=420):
                                                             "DNSPLAT_FORCE_DIST")}
     out = ""
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout or CHILD_TIMEOUT_S, env=env)
         out = r.stdout
         lines = [l for l in out.strip().splitlines() if l.startswith("{")]
         d = json.loads(lines[-1])
@@ -484,7 +487,7 @@ def child_workload(workload, losses, steps, scene=None):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
                                                             "DNSPLAT_FORCE_DIST")}
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=CHILD_TIMEOUT_S, env=env)
         d = json.loads(r.stdout.strip().splitlines()[-1])
     except Exception as e:
         return {"workload": workload, "value": None, "error": repr(e)}
