@@ -1747,3 +1747,84 @@ def test_backward_of_borderline_pixels_lies_in_the_hull_of_admissible_decisions(
                for n, b in zip(("means2d", "absgrad", "conics", "colors", "opacities"), base)):
             other += 1
     print(f"[parity] single-pixel check: {other} of the sampled borderline pixels were decided the other way by the kernels — and match that combination")
+
+
+def test_fused_pass_backward_of_borderline_pixels_lies_in_the_hull(dns, orc, monkeypatch):
+    """The same statement as above for the BENCHMARK instantiation — the fused 7-channel pass with the dn epilogue / prologue, keep
+    masks and tight tile boxes (raster_bwd_kernel<7,4,DN,.,MASKS>): image cotangents on the borderline pixels only; the kernels'
+    gradient records (v_xy | v_conic | v_opacity | v_channels | |v_xy|) against the hull the oracle builds for the reference's two
+    passes — rgb + depth with the screen-space gradient, normals without it (dn_model.py:562 feeds xys.detach()) — from the
+    composite-level cotangents autograd hands its own backward calls.  The two passes share every decision; their hulls are added
+    (a superset of the admissible set: a necessary condition)."""
+    from _scenes import assert_in_hull
+    from dn_splatter_amd import _ops, fused, synthetic
+
+    N, W, H = 10_000, 256, 256
+    gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=0)
+    g_ = torch.Generator().manual_seed(21)
+    gp["scales"] = (gp["scales"].detach() + torch.randn(N, 3, generator=g_) * 0.5).requires_grad_(True)
+    gp["opacities"] = (gp["opacities"].detach() + torch.randn(N, 1, generator=g_) * 1.5).requires_grad_(True)
+    cam = synthetic.orbit_camera(3, width=W, height=H, focal=160.0)
+
+    # ---- the reference sequence on the oracle, its raster-level calls recorded
+    fwd_calls, bwd_calls = [], []
+    real_fwd, real_bwd = orc.rasterize_fwd, orc.rasterize_bwd
+
+    def spy_fwd(*a, **kw):
+        fwd_calls.append(a[:10])
+        return real_fwd(*a, **kw)
+
+    def spy_bwd(*a, **kw):
+        bwd_calls.append((a[12], a[13]))                     # v_render, v_alphas
+        return real_bwd(*a, **kw)
+
+    monkeypatch.setattr(orc, "rasterize_fwd", spy_fwd)
+    monkeypatch.setattr(orc, "rasterize_bwd", spy_bwd)
+    p_o = {k: v.detach().clone().requires_grad_(k != "normals") for k, v in gp.items()}
+    m_o = dns.DNSplatterRenderer(p_o, fused=False, rasterization_fn=orc.rasterization, rasterize_gaussians_fn=orc.rasterize_gaussians)
+    out_o = m_o.get_outputs(cam)
+    border = m_o.last_info["borderline"].reshape(H, W) | orc.last_borderline
+    pre = out_o["rgb"].detach()
+    assert len(fwd_calls) == 2 and fwd_calls[0][2].shape[1] == 4 and fwd_calls[1][2].shape[1] == 3
+    n_b = int(border.sum())
+    print(f"[parity] fused pass: {n_b} of {border.numel()} pixels borderline; they alone carry cotangents")
+    assert 0 < n_b <= 0.01 * border.numel()
+    # pixels whose rgb sits on a clamp(0, 1) corner have an undefined gate for the rgb cotangent: none of them may be selected
+    border &= ~(((pre - 0.0).abs() < 4e-6) | ((pre - 1.0).abs() < 4e-6)).any(-1)
+    gen = torch.Generator().manual_seed(5)
+    cot = {k: (torch.rand(out_o[k].shape, generator=gen) * 2 - 1) * border[..., None] for k in OUT_KEYS}
+    torch.autograd.backward([out_o[k] for k in OUT_KEYS], [cot[k] for k in OUT_KEYS])
+    assert len(bwd_calls) == 2
+    monkeypatch.undo()
+    # autograd runs the two backward calls in reverse order of the forward calls
+    (vr2, va2), (vr1, va1) = bwd_calls
+    assert vr1.shape[-1] == 4 and vr2.shape[-1] == 3
+    lo1, hi1, st1 = orc.rasterize_bwd_hull(*fwd_calls[0], border, vr1, va1)
+    lo2, hi2, st2 = orc.rasterize_bwd_hull(*fwd_calls[1], border, vr2, va2)
+    for st in (st1, st2):
+        assert st["pixels_over_cap"] == 0 and st["pixels_incomplete"] == 0, st
+    lo = {"means2d": lo1["means2d"], "absgrad": lo1["absgrad"], "conics": lo1["conics"] + lo2["conics"],
+          "opacities": lo1["opacities"] + lo2["opacities"], "colors": torch.cat([lo1["colors"], lo2["colors"]], 1)}
+    hi = {"means2d": hi1["means2d"], "absgrad": hi1["absgrad"], "conics": hi1["conics"] + hi2["conics"],
+          "opacities": hi1["opacities"] + hi2["opacities"], "colors": torch.cat([hi1["colors"], hi2["colors"]], 1)}
+
+    # ---- the product: the fused path's own launch sequence, with the gradient records kept
+    p_g = {k: v.detach().to(DEV).clone().requires_grad_(k != "normals") for k, v in gp.items()}
+    bg = torch.tensor(dns.RendererConfig().background_color, device=DEV)
+    camg = cam.to(DEV)
+    viewmat, K, nf, flag = _ops.camera_prepare(camg.camera_to_worlds[0], camg.fx, camg.fy, camg.cx, camg.cy, with_flag=True, n_depth_max=1)
+    cfg = _ops.ProjCfg(width=W, height=H, scales_are_log=True, opacities_are_logit=True, sh_degree=3, with_depth=True, with_normals=True,
+                       want_normals_world=True, tight_tiles=_ops.TIGHT_TILES)
+    pr = _ops.project(p_g["means"], p_g["quats"], p_g["scales"], p_g["opacities"].reshape(N), sh0=p_g["features_dc"], shN=p_g["features_rest"],
+                      viewmat=viewmat[None], K=K[None], normal_frame=nf[None], cfg=cfg, saturation_flag=flag)
+    pr["splats"].retain_grad()
+    pr["means2d"].retain_grad()
+    rgb, depth, normal, acc, _sn = _ops.rasterize_dn(pr["means2d"], pr["splats"], pr["depths"], pr["radii"], pr["tiles_bin"], background_rgb=bg,
+                                                    width=W, height=H, intrinsics=[(camg.fx, camg.fy, camg.cx, camg.cy)], absgrad=True,
+                                                    holder={"saturation_flag": flag}, tight=pr["tight_tiles"], tile_boxes=pr["tile_boxes"])
+    outs = {"rgb": rgb[0], "depth": depth[0], "normal": normal[0], "accumulation": acc[0]}
+    torch.autograd.backward([outs[k] for k in OUT_KEYS], [cot[k].to(DEV) for k in OUT_KEYS])
+    torch.cuda.synchronize()
+    rec = pr["splats"].grad.cpu()
+    hip = {"means2d": rec[:, 0:2], "absgrad": rec[:, 14:16], "conics": rec[:, 2:5], "opacities": rec[:, 5], "colors": rec[:, 6:13]}
+    assert_in_hull(hip, lo, hi, "fused pass, borderline-only backward (gradient records)")
