@@ -1749,7 +1749,7 @@ def test_backward_of_borderline_pixels_lies_in_the_hull_of_admissible_decisions(
     print(f"[parity] single-pixel check: {other} of the sampled borderline pixels were decided the other way by the kernels — and match that combination")
 
 
-def test_fused_pass_backward_of_borderline_pixels_lies_in_the_hull(dns, orc, monkeypatch):
+def _fused_hull_case(dns, orc, monkeypatch, gp, cam, what, max_share=0.01):
     """The same statement as above for the BENCHMARK instantiation — the fused 7-channel pass with the dn epilogue / prologue, keep
     masks and tight tile boxes (raster_bwd_kernel<7,4,DN,.,MASKS>): image cotangents on the borderline pixels only; the kernels'
     gradient records (v_xy | v_conic | v_opacity | v_channels | |v_xy|) against the hull the oracle builds for the reference's two
@@ -1757,14 +1757,9 @@ def test_fused_pass_backward_of_borderline_pixels_lies_in_the_hull(dns, orc, mon
     composite-level cotangents autograd hands its own backward calls.  The two passes share every decision; their hulls are added
     (a superset of the admissible set: a necessary condition)."""
     from _scenes import assert_in_hull
-    from dn_splatter_amd import _ops, fused, synthetic
+    from dn_splatter_amd import _ops
 
-    N, W, H = 10_000, 256, 256
-    gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=0)
-    g_ = torch.Generator().manual_seed(21)
-    gp["scales"] = (gp["scales"].detach() + torch.randn(N, 3, generator=g_) * 0.5).requires_grad_(True)
-    gp["opacities"] = (gp["opacities"].detach() + torch.randn(N, 1, generator=g_) * 1.5).requires_grad_(True)
-    cam = synthetic.orbit_camera(3, width=W, height=H, focal=160.0)
+    N, W, H = gp["means"].shape[0], int(cam.width), int(cam.height)
 
     # ---- the reference sequence on the oracle, its raster-level calls recorded
     fwd_calls, bwd_calls = [], []
@@ -1787,8 +1782,8 @@ def test_fused_pass_backward_of_borderline_pixels_lies_in_the_hull(dns, orc, mon
     pre = out_o["rgb"].detach()
     assert len(fwd_calls) == 2 and fwd_calls[0][2].shape[1] == 4 and fwd_calls[1][2].shape[1] == 3
     n_b = int(border.sum())
-    print(f"[parity] fused pass: {n_b} of {border.numel()} pixels borderline; they alone carry cotangents")
-    assert 0 < n_b <= 0.01 * border.numel()
+    print(f"[parity] {what}: {n_b} of {border.numel()} pixels borderline; they alone carry cotangents")
+    assert 0 < n_b <= max_share * border.numel()
     # pixels whose rgb sits on a clamp(0, 1) corner have an undefined gate for the rgb cotangent: none of them may be selected
     border &= ~(((pre - 0.0).abs() < 4e-6) | ((pre - 1.0).abs() < 4e-6)).any(-1)
     gen = torch.Generator().manual_seed(5)
@@ -1827,4 +1822,27 @@ def test_fused_pass_backward_of_borderline_pixels_lies_in_the_hull(dns, orc, mon
     torch.cuda.synchronize()
     rec = pr["splats"].grad.cpu()
     hip = {"means2d": rec[:, 0:2], "absgrad": rec[:, 14:16], "conics": rec[:, 2:5], "opacities": rec[:, 5], "colors": rec[:, 6:13]}
-    assert_in_hull(hip, lo, hi, "fused pass, borderline-only backward (gradient records)")
+    assert_in_hull(hip, lo, hi, what + ", borderline-only backward (gradient records)")
+
+
+def test_fused_pass_backward_of_borderline_pixels_lies_in_the_hull(dns, orc, monkeypatch):
+    """C1 size, anisotropic scales and spread opacities."""
+    from dn_splatter_amd import synthetic
+
+    N = 10_000
+    gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=0)
+    g_ = torch.Generator().manual_seed(21)
+    gp["scales"] = (gp["scales"].detach() + torch.randn(N, 3, generator=g_) * 0.5).requires_grad_(True)
+    gp["opacities"] = (gp["opacities"].detach() + torch.randn(N, 1, generator=g_) * 1.5).requires_grad_(True)
+    _fused_hull_case(dns, orc, monkeypatch, gp, synthetic.orbit_camera(3, width=256, height=256, focal=160.0), "fused pass")
+
+
+def test_c2_full_frame_backward_of_borderline_pixels_lies_in_the_hull(dns, orc, monkeypatch):
+    """The benchmark frame (1 M Gaussians, 1920 x 1080, the reference's initialisation): its ~10 000 borderline pixels — the ones every
+    other backward comparison of that frame leaves without a cotangent — carry the only cotangents here."""
+    from dn_splatter_amd import synthetic
+
+    _oracle_threads()
+    N, W, H = FULL["c2"]
+    gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=0)
+    _fused_hull_case(dns, orc, monkeypatch, gp, synthetic.orbit_camera(0, width=W, height=H), "C2 full frame, fused pass")
