@@ -138,6 +138,15 @@ class GraphedStep:
         self.graphs, self.results = [], []
         _ops.forget_static(self.device, self.stream)
 
+    def recapture(self, **kw) -> "GraphedStep":
+        """close() + a new capture of the same function over the same parameters — what follows a check() that reported an overflow
+        (the capacity guess has been raised by then), a refinement that kept the tensors, or a change of image size.  Returns the new
+        step; this one is finished."""
+        n = max(len(self.done), 1)
+        self.close()
+        self._zero_grads()
+        return GraphedStep(self.fn, self.params, copies=kw.pop("copies", n), **kw)
+
 
 class GraphedDpStep:
     """The data-parallel step with the host out of the way: ``fn`` (get_outputs + loss + backward of THIS rank's camera) is

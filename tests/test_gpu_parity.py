@@ -1651,10 +1651,8 @@ def test_graphed_step_overflow_is_reported_and_a_recapture_fits(dns):
         with pytest.raises(_lib.DnsplatError, match="more than the captured buffers hold"):
             step.check()
         assert _ops.BUFFERS.capacity_hint[hkey] >= n_near
-        step.close()
-        for v in gp.values():
-            v.grad = None
-        step2 = GraphedStep(compute, params={k: gp[k] for k in dp.GRAD_KEYS})        # warm-up at the near pose, enlarged buffers
+        step2 = step.recapture()                                                     # warm-up at the near pose, enlarged buffers
+        assert step.graphs == [] and step2.graphs
         out = step2()
         step2.check()
         torch.cuda.synchronize()
