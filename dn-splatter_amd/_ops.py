@@ -268,7 +268,10 @@ def carry_capacity_guesses(device, n_old: int, n_new: int, slack: float = 1.1) -
     for k in [k for k in BUFFERS.capacity_hint if (device is None or k[0] == device) and k[1] == n_old]:
         hint = BUFFERS.capacity_hint.pop(k)
         nk = (k[0], n_new) + tuple(k[2:])
-        BUFFERS.capacity_hint[nk] = max(BUFFERS.capacity_hint.get(nk, 0), int(hint * (n_new / max(n_old, 1)) * slack) + 4096)
+        # never scaled DOWN: culling removes low-opacity, small-footprint Gaussians, so the intersections fall less than N does, and
+        # an under-estimate would make the next capture's warm-up frame overflow instead of sizing itself
+        ratio = max(1.0, n_new / max(n_old, 1))
+        BUFFERS.capacity_hint[nk] = max(BUFFERS.capacity_hint.get(nk, 0), int(hint * ratio * slack) + 4096)
         carried += 1
     return carried
 
@@ -506,7 +509,7 @@ class _ProjectFn(torch.autograd.Function):
                 # tensors: they are slices of the bucket, which outlives the step — and autograd adopts a returned gradient as .grad
                 # only while nobody else holds it (a second reference here made it clone v_sh0 / v_shN out of the bucket)
                 launches, keep = [], [means, quats, scales, opacities, sh0, shN, viewmat, K, normal_frame, radii, vs_c, v_m2d, v_dep, v_con,
-                                      slabs]
+                                      v_cmp, slabs]
                 if ex.record_only and (GRAD_ARENA is None or not all(GRAD_ARENA.holds(t) for t in (v_means, v_quats, v_scales, v_opac, v_sh0, v_shN))):
                     raise _lib.DnsplatError("the sliced exchange in recorded mode needs the gradients in a dp.GradArena (set_grad_arena) "
                                             "and .grad = None when the captured backward starts")
@@ -518,6 +521,7 @@ class _ProjectFn(torch.autograd.Function):
                     g_k.v_means2d = _ptr(v_m2d[c][g0:g1]) if v_m2d is not None else None
                     g_k.v_depths = _ptr(v_dep[c][g0:g1]) if v_dep is not None else None
                     g_k.v_conics = _ptr(v_con[c][g0:g1]) if v_con is not None else None
+                    g_k.v_compensations = _ptr(v_cmp[c][g0:g1]) if v_cmp is not None else None
                     g_k.v_means, g_k.v_quats = _ptr(v_means[g0:g1]), _ptr(v_quats[g0:g1])
                     g_k.v_scales, g_k.v_opacities = _ptr(v_scales[g0:g1]), _ptr(v_opac[g0:g1])
                     g_k.v_sh0, g_k.v_sh0_stride = _ptr(v_sh0[g0:g1]), 3
@@ -530,8 +534,12 @@ class _ProjectFn(torch.autograd.Function):
                     ex.record(launches, keep)
                     v_means = v_quats = v_scales = v_opac = None
                 else:
-                    for args in launches:
+                    # eager: slab k's all-gather is queued right behind launch k, so it travels while slices k+1.. compute
+                    works = []
+                    for k, args in enumerate(launches):
                         _lib.run("dnsplat_project_bwd", _lib.lib().dnsplat_project_bwd, *args, _stream())
+                        works.append(ex.gather_slice(k))
+                    ex.works = works
                 outs = [v_means, v_quats, v_scales, v_opac, v_coeffs, v_sh0, v_shN, v_colors]
                 total = outs
                 continue

@@ -105,6 +105,7 @@ class ShFactorExchange:
         self.meta = None
         self.means: Optional[Tensor] = None
         self.work = None      # the all-gather in flight (launch())
+        self.group = None     # the process group collectives issued from INSIDE the backward use (launch / eager slice gathers)
         # True: launch() does nothing and finish() runs the all-gather itself — for a backward that is being captured into a HIP
         # graph (graph.GraphedDpStep): no collective is issued from inside the capture, the exchange follows the replay eagerly
         self.deferred = False
@@ -145,6 +146,7 @@ class ShFactorExchange:
         """Start the all-gather of the slabs (enqueued after whatever filled ``mine`` on the current stream) without
         waiting for it: the projection backward calls this right after ``dnsplat_sh_factors`` and BEFORE
         ``dnsplat_project_bwd``, so the 12 B/Gaussian travel while the geometry gradients are computed."""
+        group = self.group if group is None else group
         if self.meta is None or self.deferred or not _collectives_on(group):
             return
         buf = self._gather_buffer(world_size(group))
@@ -245,6 +247,7 @@ class SlicedShExchange(ShFactorExchange):
 
     def gather_slice(self, k: int, group=None):
         """Queues the all-gather of slab k behind whatever filled it on the current stream; returns the handle (or None)."""
+        group = self.group if group is None else group
         w = world_size(group)
         buf = self._gathered(k, w)
         if w > 1 or _collectives_on(group):

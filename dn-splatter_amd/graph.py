@@ -44,6 +44,7 @@ class GraphedStep:
                  copies: int = 1, before_capture: Optional[Callable[[int], None]] = None):
         self.fn = fn
         self.params = params
+        self._warmup, self._before_capture = warmup, before_capture      # recapture() repeats the capture as it was asked for
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.stream = torch.cuda.Stream(self.device)
         self.graphs: List[torch.cuda.CUDAGraph] = []
@@ -140,11 +141,15 @@ class GraphedStep:
 
     def recapture(self, **kw) -> "GraphedStep":
         """close() + a new capture of the same function over the same parameters — what follows a check() that reported an overflow
-        (the capacity guess has been raised by then), a refinement that kept the tensors, or a change of image size.  Returns the new
-        step; this one is finished."""
+        (the capacity guess has been raised by then), a refinement that kept the tensors, or a change of image size.  Warm-up count,
+        number of copies and the ``before_capture`` hook are the original ones unless overridden.  Returns the new step; this one is
+        finished.  (The inner step of a GraphedDpStep is re-captured through GraphedDpStep.recapture(), which also restores the
+        exchange's recorded state.)"""
         n = max(len(self.done), 1)
         self.close()
         self._zero_grads()
+        kw.setdefault("warmup", self._warmup)
+        kw.setdefault("before_capture", self._before_capture)
         return GraphedStep(self.fn, self.params, copies=kw.pop("copies", n), **kw)
 
 
@@ -171,6 +176,11 @@ class GraphedDpStep:
         # dp.SlicedShExchange: the captured step ends in front of dnsplat_project_bwd; its K slice launches are issued behind each
         # replay, each followed by the all-gather of its slab (the exchange overlaps the projection backward again)
         self.sliced = exchange is not None and getattr(exchange, "slices", 1) > 1
+        if self.sliced and int(kw.get("copies", 1)) != 1:
+            # the exchange keeps ONE set of recorded launches / direct-gradient tensors: with two captures the replays of copy 0
+            # would run copy 1's slice launches on copy 1's pool tensors
+            raise _lib.DnsplatError("GraphedDpStep: the sliced (recorded) exchange supports copies=1 only")
+        self._fn, self._kw = fn, dict(kw)
         self.direct: Dict[str, Tensor] = {}
         if exchange is not None:
             exchange.deferred = True
@@ -245,6 +255,15 @@ class GraphedDpStep:
 
     def check(self) -> None:
         self.step.check()
+
+    def recapture(self, **kw) -> "GraphedDpStep":
+        """close() + a new capture of the same step with the same exchange (record_only / deferred state rebuilt by the constructor).
+        Do not call ``self.step.recapture()``: that would bypass the exchange's recorded launches."""
+        self.close()
+        for p in self.params.values():
+            if isinstance(p, Tensor):
+                p.grad = None
+        return GraphedDpStep(self._fn, self.params, self.arena, self.exchange, self.group, **{**self._kw, **kw})
 
     def close(self) -> None:
         self.step.close()

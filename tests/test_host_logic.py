@@ -53,7 +53,7 @@ def test_synthetic_inputs_follow_the_reference_init(dns):
     from dn_splatter_amd import synthetic
 
     gp = synthetic.make_gauss_params(5000, sh_degree=3, seed=0)
-    assert gp["means"].shape == (5000, 3) and float(gp["means"].abs().max()) <= 5.0          # (rand-0.5)*10
+    assert gp["means"].shape == (5000, 3) and float(gp["means"].detach().abs().max()) <= 5.0          # (rand-0.5)*10
     assert gp["features_rest"].shape == (5000, 15, 3) and gp["features_dc"].shape == (5000, 3)
     assert torch.allclose(torch.sigmoid(gp["opacities"]), torch.full((5000, 1), 0.1), atol=1e-6)   # logit(0.1)
     assert torch.allclose(gp["scales"][:, 0], gp["scales"][:, 1])                                  # isotropic
