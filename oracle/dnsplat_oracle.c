@@ -33,6 +33,9 @@
 int orc_exact_accum = 0;
 void orc_set_exact_accum(int on) { orc_exact_accum = on; }
 int orc_get_exact_accum(void) { return orc_exact_accum; }
+/* orc_project_bwd's rotation -> quaternion stage evaluated in magnitudes (oracle.py ConditionTrace's Jacobian sweeps only). */
+int orc_cond_quat_abs = 0;
+void orc_set_cond_quat_abs(int on) { orc_cond_quat_abs = on; }
 
 /* ---- fp32 instantiation ---- */
 #define REAL float

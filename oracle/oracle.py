@@ -283,6 +283,118 @@ def rasterize_bwd_hull(means2d, conics, colors, opacities, background, width, he
     return split(lo), split(hi), st
 
 
+def rasterize_bwd_cond(means2d, conics, colors, opacities, background, width, height, tile_size, isect_offsets, flatten_ids,
+                       alphas, last_ids, vabs_render, vabs_alphas):
+    """orc_rasterize_bwd_cond: per (Gaussian, raster-level gradient entry) the kappa-weighted sum of term magnitudes of A.7, float64
+    [N, 8 + D] with columns (vx vy |vx| |vy| conic_a conic_b conic_c opacity colours[D]) — the running error bound, in units of one
+    rounding, of that entry under any evaluation in the precision of the inputs (see oracle_impl.inc)."""
+    N, D = colors.shape
+    A = torch.zeros(N, 8 + D, dtype=torch.float64)
+    B = torch.zeros(N, 8 + D, dtype=torch.float64)
+    fn = getattr(lib(), "orc_rasterize_bwd_cond_" + _suffix(colors))
+    fn(ctypes.c_int(N), ctypes.c_int(D), _p(means2d.contiguous()), _p(conics.contiguous()), _p(colors.contiguous()),
+       _p(opacities.contiguous()), _p(background.contiguous() if background is not None else None),
+       ctypes.c_int(width), ctypes.c_int(height), ctypes.c_int(tile_size),
+       _p(isect_offsets.contiguous()), _p(flatten_ids.contiguous()), ctypes.c_int64(flatten_ids.shape[0]),
+       _p(alphas.contiguous()), _p(last_ids.contiguous()), _p(vabs_render.contiguous()), _p(vabs_alphas.contiguous()), _p(A), _p(B))
+    return A, B
+
+
+class ConditionTrace:
+    """Context manager: while active, every compositing call of this module (``_RasterizeToPixels``) remembers the autograd tensors
+    it was fed (means2d, conics, colours, opacities) and, when its backward runs, the running error bound ``A`` [N, 8 + D] of its
+    raster-level gradients for the cotangents it received (``rasterize_bwd_cond``).  Afterwards ``param_condition(leaves)`` chains
+    those bounds to the leaf parameters through the entry-wise absolute value of the per-Gaussian Jacobian of everything between the
+    leaves and the compositing inputs (activations, projection, SH, normals — Gaussians are independent there, so J column i is one
+    backward pass with a unit cotangent in column i):
+        cond[leaf][g] = sum over calls, over raster inputs i of |d input_i[g] / d leaf[g]| x A_call[g][i].
+    The main backward must keep the graph (``retain_graph=True``) for the Jacobian passes.  Test infrastructure for
+    tests/test_gpu_determinism.py: ||hip_g - oracle_g|| <= c x 2^-24 x ||cond_g|| for EVERY visible Gaussian."""
+
+    def __init__(self):
+        self.calls = []
+
+    def __enter__(self):
+        global _TRACE
+        self._prev, _TRACE = _TRACE, self
+        return self
+
+    def __exit__(self, *exc):
+        global _TRACE
+        _TRACE = self._prev
+        return False
+
+    def register(self, means2d, conics, colors, opacities):
+        slot = {"inputs": (means2d, conics, colors, opacities), "A": None, "B": None}
+        self.calls.append(slot)
+        return slot
+
+    # columns of A belonging to each compositing input
+    @staticmethod
+    def _columns(D):
+        return {0: [0, 1], 1: [4, 5, 6], 2: list(range(8, 8 + D)), 3: [7]}
+
+    def raster_condition(self, call: int = 0, which: str = "A"):
+        """dict(means2d [N,2], absgrad [N,2], conics [N,3], colors [N,D], opacities [N]) of compositing call ``call``: the worst-case
+        bound A, or with ``which="B"`` the standard deviation sqrt(B) of the independent-roundings model (both in units of u)."""
+        A = self.calls[call][which]
+        if which == "B":
+            A = A.sqrt()
+        D = A.shape[1] - 8
+        return {"means2d": A[:, 0:2], "absgrad": A[:, 2:4], "conics": A[:, 4:7], "opacities": A[:, 7], "colors": A[:, 8:8 + D]}
+
+    def param_condition(self, leaves: Dict[str, Tensor]):
+        """-> (A, S): dicts leaf name -> float64 tensor of the leaf's shape.  A = sum_i |J_i| A_i (worst case),
+        S = sqrt(sum_i J_i^2 B_i) (independent roundings), both in units of one rounding.  One Jacobian sweep serves both."""
+        names = [k for k, v in leaves.items() if v.requires_grad]
+        out_a = {k: torch.zeros(leaves[k].shape, dtype=torch.float64) for k in names}
+        out_b = {k: torch.zeros(leaves[k].shape, dtype=torch.float64) for k in names}
+        # tensors the caller called retain_grad() on (info["means2d"], dn_model.py:517-518) would collect the unit cotangents of the
+        # sweeps in their .grad / keep the last sweep's .absgrad: put both back afterwards
+        held = [(t, t.grad, getattr(t, "absgrad", None)) for slot in self.calls for t in slot["inputs"]
+                if torch.is_tensor(t) and t.requires_grad and t.retains_grad]
+        lib().orc_set_cond_quat_abs(ctypes.c_int(1))      # the quaternion stage of orc_project_bwd in magnitudes (see there)
+        try:
+            self._sweep(leaves, names, out_a, out_b)
+        finally:
+            lib().orc_set_cond_quat_abs(ctypes.c_int(0))
+            for t, g, ag in held:
+                t.grad = g
+                if ag is not None:
+                    t.absgrad = ag
+        return out_a, {k: v.sqrt() for k, v in out_b.items()}
+
+    def _sweep(self, leaves, names, out_a, out_b):
+        for slot in self.calls:
+            A, B = slot["A"], slot["B"]
+            if A is None:
+                continue
+            N, D = A.shape[0], A.shape[1] - 8
+            cols = self._columns(D)
+            for slot_input, t in enumerate(slot["inputs"]):
+                if not (torch.is_tensor(t) and t.requires_grad):
+                    continue
+                t2 = t.reshape(N, -1)
+                for j, col in enumerate(cols[slot_input]):
+                    if j >= t2.shape[1]:
+                        break
+                    if float(A[:, col].max()) == 0.0:
+                        continue
+                    unit = torch.zeros_like(t2)
+                    unit[:, j] = 1.0
+                    grads = torch.autograd.grad([t], [leaves[k] for k in names], grad_outputs=[unit.reshape(t.shape)],
+                                                retain_graph=True, allow_unused=True)
+                    for k, gk in zip(names, grads):
+                        if gk is not None:
+                            j_abs = gk.detach().double().abs()
+                            shape = (N,) + (1,) * (gk.dim() - 1)
+                            out_a[k] += j_abs * A[:, col].reshape(shape)
+                            out_b[k] += j_abs * j_abs * B[:, col].reshape(shape)
+
+
+_TRACE: Optional["ConditionTrace"] = None
+
+
 # --------------------------------------------------------------------------- autograd wiring
 
 
@@ -335,6 +447,7 @@ class _RasterizeToPixels(torch.autograd.Function):
         ctx.save_for_backward(means2d, conics, colors, opacities, isect_offsets, flatten_ids, alphas, last_ids)
         ctx.background = background
         ctx.cfg = (width, height, tile_size, absgrad)
+        ctx.trace_slot = _TRACE.register(means2d, conics, colors, opacities) if _TRACE is not None else None
         return render, alphas
 
     @staticmethod
@@ -346,6 +459,11 @@ class _RasterizeToPixels(torch.autograd.Function):
             flatten_ids, alphas, last_ids, v_render, v_alphas, absgrad)
         if absgrad:
             means2d.absgrad = v_abs.reshape(means2d.shape)
+        if ctx.trace_slot is not None:
+            A, B = rasterize_bwd_cond(means2d.reshape(-1, 2), conics, colors, opacities, ctx.background, width, height, tile_size,
+                                      isect_offsets, flatten_ids, alphas, last_ids, v_render.abs(), v_alphas.abs())
+            ctx.trace_slot["A"] = A if ctx.trace_slot["A"] is None else ctx.trace_slot["A"] + A
+            ctx.trace_slot["B"] = B if ctx.trace_slot["B"] is None else ctx.trace_slot["B"] + B
         return (v_means2d.reshape(means2d.shape), v_conics, v_colors, v_opac) + (None,) * 9
 
 

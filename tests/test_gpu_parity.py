@@ -135,13 +135,18 @@ GRAD_NAMES = ("means", "scales", "quats", "features_dc", "features_rest", "opaci
 OUT_KEYS = ("rgb", "depth", "normal", "accumulation")
 
 
-def _mirror_pair(dns, orc, gp, cam, hip_kw, cot_seed=2, what="mirror", config=None, step=None):
+def _mirror_pair(dns, orc, gp, cam, hip_kw, cot_seed=2, what="mirror", config=None, step=None, cond=False):
     """DNSplatterModel.get_outputs (dn_model.py:404-612) twice: the reference's own op sequence with the oracle plugged in
     for the two gsplat calls (CPU), and the product (GPU, ``hip_kw`` picks fused / two-call).  The oracle runs first: its
     borderline mask (plus the pixels whose pre-clamp rgb sits within rounding of the clamp(0, 1) corners, where the
     gradient gate of dn_model.py:528 may fall either way) selects the pixels that are compared and zeroes the cotangents of
-    the others on BOTH sides.  Returns ((out, params, renderer) for hip, the same for the oracle, keep)."""
+    the others on BOTH sides.  Returns ((out, params, renderer) for hip, the same for the oracle, keep).
+    ``cond``: the oracle side runs under an ``orc.ConditionTrace``; its renderer then carries ``cond_A`` / ``cond_S``, the running
+    error bounds of every gradient row (keys: GRAD_NAMES + "xys" + "xys.absgrad") for _scenes.check_rows_conditioned."""
+    import contextlib
+
     captured = {}
+    trace = orc.ConditionTrace() if cond else contextlib.nullcontext()
 
     def rasterization_spy(**kw):
         r, a, info = orc.rasterization(**kw)
@@ -163,7 +168,8 @@ def _mirror_pair(dns, orc, gp, cam, hip_kw, cot_seed=2, what="mirror", config=No
         m_o.step = step
     orc.last_borderline = None
     orc.last_flip_weight = None
-    out_o = m_o.get_outputs(cam)
+    with trace:
+        out_o = m_o.get_outputs(cam)
     border = captured["info"]["borderline"].clone()
     flip = captured["info"]["flip_weight"].clone()
     if orc.last_borderline is not None and orc.last_borderline.shape == border.shape:
@@ -187,7 +193,12 @@ def _mirror_pair(dns, orc, gp, cam, hip_kw, cot_seed=2, what="mirror", config=No
     gen = torch.Generator().manual_seed(cot_seed)
     cot = {k: zero_borderline(torch.rand(out_o[k].shape, generator=gen) * 2 - 1, keep) for k in OUT_KEYS}
     live = [k for k in OUT_KEYS if out_o[k].requires_grad]          # predict_normals=False hands out a constant normal image
-    torch.autograd.backward([out_o[k] for k in live], [cot[k] for k in live])
+    torch.autograd.backward([out_o[k] for k in live], [cot[k] for k in live], retain_graph=cond)
+    if cond:
+        m_o.cond_A, m_o.cond_S = trace.param_condition({k: p_o[k] for k in GRAD_NAMES})
+        ra, rs = trace.raster_condition(0, "A"), trace.raster_condition(0, "B")      # the first call is the one whose xys carry the gradient
+        m_o.cond_A.update({"xys": ra["means2d"], "xys.absgrad": ra["absgrad"]})
+        m_o.cond_S.update({"xys": rs["means2d"], "xys.absgrad": rs["absgrad"]})
 
     # the same sequence once more in float64 (same cotangents): the per-entry rounding envelope of the fp32 reference
     # algorithm for the gradient comparisons (_scenes.assert_close)
