@@ -18,7 +18,7 @@ _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["DNSPLAT_LIB"]).resolve() if os.environ.get("DNSPLAT_LIB") else _PKG_DIR / "libdnsplat.so"
 CSRC_DIR = _PKG_DIR / "csrc"
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 RECORD_FLOATS = 16
 MAX_CHANNELS = 8
 
@@ -35,7 +35,7 @@ class Scene(ctypes.Structure):
         ("sh_degree", c_int32), ("sh_K", c_int32),
         ("sh0", c_void_p), ("sh0_stride", c_int32),
         ("shN", c_void_p), ("shN_stride", c_int32),
-        ("colors", c_void_p), ("n_colors", c_int32),
+        ("colors", c_void_p), ("n_colors", c_int32), ("colors_are_logit", c_int32),
     ]
 
 
@@ -54,7 +54,7 @@ class ProjOut(ctypes.Structure):
         ("compensations", c_void_p), ("tiles_per_gauss", c_void_p), ("splats", c_void_p),
         ("normals_world", c_void_p),
         ("with_depth_channel", c_int32), ("with_normal_channels", c_int32), ("saturation_flag", c_void_p),
-        ("tiles_bin", c_void_p), ("tile_boxes", c_void_p), ("phase", c_int32),
+        ("tiles_bin", c_void_p), ("tile_boxes", c_void_p), ("phase", c_int32), ("skip_culled_records", c_int32),
     ]
 
 
@@ -134,6 +134,7 @@ class ProjGrads(ctypes.Structure):
         ("v_colors", c_void_p),
         ("sh_grads_skip", c_int32),
         ("sh_factors", c_void_p),
+        ("sh_grad_scale", c_float), ("sh_zero_state", c_void_p), ("sh_packed", c_void_p), ("sh_packed_index", c_void_p),
     ]
 
 
@@ -146,7 +147,8 @@ EXPORTS = [
     "dnsplat_raster_fwd", "dnsplat_raster_bwd", "dnsplat_det_workspace_bytes", "dnsplat_det_reduce",
     "dnsplat_dn_depth_normals", "dnsplat_camera_prepare", "dnsplat_densify_stats", "dnsplat_densify_classify",
     "dnsplat_densify_split", "dnsplat_dn_loss", "dnsplat_scale_reg", "dnsplat_sh_grads_from_factors", "dnsplat_sh_factors",
-    "dnsplat_project_bwd",
+    "dnsplat_project_bwd", "dnsplat_sh_grads_add_factors", "dnsplat_packed_slab_floats", "dnsplat_visible_index",
+    "dnsplat_sh_grads_from_packed",
 ]
 
 _lib = None
@@ -206,8 +208,16 @@ def lib() -> ctypes.CDLL:
         L.dnsplat_camera_prepare.argtypes = [c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_int32, c_void_p]
         L.dnsplat_sh_factors.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.dnsplat_sh_grads_add_factors.argtypes = [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p,
+                                                   c_int32, c_void_p, c_int32, c_void_p]
+        L.dnsplat_packed_slab_floats.restype = c_size_t
+        L.dnsplat_packed_slab_floats.argtypes = [c_int32, c_int32]
+        L.dnsplat_visible_index.argtypes = [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.dnsplat_sh_grads_from_packed.argtypes = [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_float,
+                                                   c_void_p, c_int32, c_void_p, c_int32, c_void_p]
         for name in EXPORTS:
-            if name not in ("dnsplat_strerror", "dnsplat_bin_workspace_bytes", "dnsplat_bin_status_offset", "dnsplat_det_workspace_bytes"):
+            if name not in ("dnsplat_strerror", "dnsplat_bin_workspace_bytes", "dnsplat_bin_status_offset", "dnsplat_det_workspace_bytes",
+                            "dnsplat_packed_slab_floats"):
                 getattr(L, name).restype = ctypes.c_int
         if L.dnsplat_abi_version() != ABI_VERSION:
             raise DnsplatError(f"libdnsplat ABI {L.dnsplat_abi_version()} != binding {ABI_VERSION}; rebuild")

@@ -45,8 +45,11 @@ extern "C" {
  * library of another version.  Round 4: 10 = dnsplat_raster_args.det_partials / dnsplat_det_reduce (deterministic gradient
  * scatter), 11 = dnsplat_scale_reg, 12 = dnsplat_proj_grads.sh_factors (the colour-gradient slab written by the projection
  * backward), 13 = dnsplat_proj_out.tile_boxes carries width | height << 16 and dnsplat_bin_args.tile_boxes takes the counts
- * from it. */
-#define DNSPLAT_ABI_VERSION 13
+ * from it.  Round 6: 14 = dnsplat_scene.colors_are_logit (the sh_degree == 0 branch of get_outputs in the fused pass),
+ * dnsplat_proj_out.skip_culled_records, dnsplat_proj_grads.sh_grad_scale / sh_zero_state (own-camera SH rows in the exchange step;
+ * gradient rows of persistently culled Gaussians are not re-zeroed), dnsplat_sh_grads_add_factors, the packed (visible rows only)
+ * colour-gradient slabs: dnsplat_visible_index, dnsplat_proj_grads.sh_packed, dnsplat_sh_grads_from_packed. */
+#define DNSPLAT_ABI_VERSION 14
 #define DNSPLAT_RECORD_FLOATS 16
 #define DNSPLAT_MAX_CHANNELS 8
 
@@ -90,6 +93,9 @@ typedef struct dnsplat_scene {
     int32_t shN_stride;
     const float *colors;          /* direct colours [N, n_colors] when sh_degree < 0 */
     int32_t n_colors;             /* 0..8 */
+    int32_t colors_are_logit;     /* 1 (ABI 14; direct colours only): apply sigmoid() — get_outputs with config.sh_degree == 0 feeds
+                                     gsplat sigmoid(features_dc) and sh_degree = None (dn_model.py:486-493); the gradient written to
+                                     v_colors is then w.r.t. the logits */
 } dnsplat_scene;
 
 typedef struct dnsplat_camera {
@@ -132,6 +138,9 @@ typedef struct dnsplat_proj_out {
                                      colour channels of the records (left 0; no coefficient is read), 2 = those three channels for the
                                      Gaussians with radii > 0 (reads radii and the records' location only).  A caller may run 2 on
                                      another stream beside dnsplat_bin_*: binning reads nothing phase 2 writes. */
+    int32_t skip_culled_records;  /* 1 (ABI 14): the 64-byte records of culled Gaussians (radii == 0) are NOT written (left as the caller
+                                     allocated them): nothing downstream reads them — the tile lists hold visible Gaussians only — and
+                                     they are 28 % of the record bytes on the benchmark scenes.  0: zero-filled, as before */
 } dnsplat_proj_out;
 
 int dnsplat_project_fwd(const dnsplat_scene *scene, const dnsplat_camera *cam,
@@ -334,6 +343,33 @@ int dnsplat_sh_grads_from_factors(int32_t N, int32_t n_views, const float *facto
 int dnsplat_sh_factors(int32_t N, const int32_t *radii, const float *viewmat, const float *splats, const float *v_splats,
                        float *factors, dnsplat_stream_t stream);
 
+/* ABI 14.  As dnsplat_sh_grads_from_factors, but ADDS  scale * sum over the views v != skip_view  to rows that already hold the
+ * (pre-scaled, dnsplat_proj_grads.sh_grad_scale) contribution of view skip_view — the rank's own camera, whose rows
+ * dnsplat_project_bwd wrote itself as on a single GPU.  With n_views == 1 there is nothing to add and nothing is launched: the
+ * exchange step costs a single rank no pass over the 192 B / Gaussian of coefficient gradients.  (At n_views >= 2 the read-modify-
+ * write moves more bytes than rebuilding every row from the slabs — dp.ShFactorExchange picks per world size.) */
+int dnsplat_sh_grads_add_factors(int32_t N, int32_t n_views, int32_t skip_view, const float *factors, const float *means,
+                                 int32_t sh_degree, int32_t sh_K, float scale, float *v_sh0, int32_t v_sh0_stride, float *v_shN,
+                                 int32_t v_shN_stride, dnsplat_stream_t stream);
+
+/* ABI 14.  Slabs of visible rows only.  A camera sees ~72 % of the Gaussians of the benchmark scenes; the colour gradients of the
+ * others are zero and need not travel.  One camera's PACKED slab (all ranks agree on `capacity` rows):
+ *     header  [0] count of visible Gaussians (uint32; > capacity = overflow: rows beyond it were dropped, the caller must notice)
+ *             [1..3] camera centre (float)        [4..7] reserved
+ *     masks   ceil(N / 64) 64-bit words, bit = radii > 0
+ *     offsets ceil(N / 64) uint32: visible Gaussians in front of the word's block (exclusive prefix sum of the popcounts)
+ *     rows    capacity x 3 floats: the clamp-masked colour gradient of the k-th visible Gaussian
+ * dnsplat_packed_slab_floats gives the size (in 4-byte words, a multiple of 4).  dnsplat_visible_index writes header, masks and
+ * offsets from the forward's radii (two small launches; `scratch`: ceil(N / 64) uint32); dnsplat_project_bwd fills the rows
+ * (dnsplat_proj_grads.sh_packed); dnsplat_sh_grads_from_packed is dnsplat_sh_grads_from_factors / _add_factors over n_views such slabs
+ * laid out `slab_floats` words apart (skip_view < 0: rebuild every row; >= 0: add the other views to the rows in place). */
+size_t dnsplat_packed_slab_floats(int32_t N, int32_t capacity);
+int dnsplat_visible_index(int32_t N, int32_t capacity, const int32_t *radii, const float *viewmat, float *slab, uint32_t *scratch,
+                          dnsplat_stream_t stream);
+int dnsplat_sh_grads_from_packed(int32_t N, int32_t capacity, int32_t n_views, int32_t skip_view, const float *slabs,
+                                 const float *means, int32_t sh_degree, int32_t sh_K, float scale, float *v_sh0, int32_t v_sh0_stride,
+                                 float *v_shN, int32_t v_shN_stride, dnsplat_stream_t stream);
+
 /* Densification statistics: the per-step accumulation nerfstudio's SplatfactoModel.after_train
  * performs on the renderer's outputs (called at dn_model.py:938-942, consumed by refinement_after dn_model.py:286-296):
  * for every Gaussian with radii > 0
@@ -432,6 +468,20 @@ typedef struct dnsplat_proj_grads {
                                     camera centre and a pad word — from the values it holds anyway, which saves that kernel's launch
                                     and its 128 B / Gaussian of reads.  For callers whose exchange starts after this launch (a
                                     captured step: graph.GraphedDpStep); dnsplat_sh_factors stays for those that start it before */
+    float sh_grad_scale;         /* ABI 14.  0 or 1: as before.  Otherwise the SH coefficient gradient rows this launch writes (v_sh0 / v_shN)
+                                    are multiplied by it — 1 / world size when the rank writes its OWN camera's rows itself and
+                                    dnsplat_sh_grads_add_factors adds the other cameras' (the mean over cameras; geometry gradients are not
+                                    scaled: their all-reduce averages) */
+    uint64_t *sh_zero_state;     /* ABI 14.  NULL, or device [ceil(N / 64)] words owned by whoever owns the v_sh0 / v_shN buffers (split or
+                                    [N,16,3] layout, K = 16): bit g % 64 of word g / 64 set = "the coefficient-gradient row of Gaussian g
+                                    is zero in memory".  The launch skips the stores of rows that are culled now AND known zero, and
+                                    leaves the word describing what memory holds afterwards (culled rows: zero).  Contract: nobody else
+                                    writes non-zero values into those rows without clearing the words (dp.GradArena.invalidate_sh_state).
+                                    Ignored with sh_grads_skip. */
+    float *sh_packed;            /* ABI 14.  NULL, or the packed slab of this camera (see dnsplat_visible_index): the colour gradients of
+                                    the VISIBLE Gaussians only, row block_offsets[g / 64] + popcount(mask word below bit g % 64); written
+                                    instead of / beside sh_factors.  Needs sh_packed_index. */
+    const void *sh_packed_index; /* the slab header dnsplat_visible_index wrote for the same radii */
 } dnsplat_proj_grads;
 
 int dnsplat_project_bwd(const dnsplat_scene *scene, const dnsplat_camera *cam,

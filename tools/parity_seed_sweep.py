@@ -15,8 +15,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 import dn_splatter_amd as dns  # noqa: E402
-from _scenes import (FP32_ENVELOPE, ROW_MAX, ROW_P99, assert_borderline_bounded, cotangents, gsplat_inputs, image_pixels, row_rel_stats,  # noqa: E402
-                     to_leaf, zero_borderline)
+from _scenes import (COND_C, COND_C_DEFAULT, COND_LAMBDA, COND_LAMBDA_DEFAULT, FP32_ENVELOPE, ROW_MAX, ROW_P99, assert_borderline_bounded,  # noqa: E402
+                     check_rows_conditioned, cotangents, gsplat_inputs, image_pixels, row_rel_stats, to_leaf, zero_borderline)
 from dn_splatter_amd import _ops  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
@@ -29,17 +29,23 @@ print(f"deterministic gradient mode: {_ops.DETERMINISTIC['on']} (oracle scatter 
       f"repeats per scene: {repeats}")
 worst_all, n_fail, n_vary = 0.0, 0, 0
 row_p99_out_all = 0.0
+cond_wa_all, cond_ws_all = 0.0, 0.0                             # every visible row / its own running error bound (A: worst case, S: independent roundings)
 row_p99_all, row_max_all, row_max_out_all = 0.0, 0.0, 0.0      # per-Gaussian relative error over the sweep (tests/_scenes.row_rel_stats)
 for seed in range(first, first + count):
     for aniso in (False, True):
         inp, viewmat, K, _ = gsplat_inputs(10_000, 256, 256, focal=160.0, seed=seed, anisotropic=aniso, view=seed % 8)
         ci = to_leaf(inp, "cpu")
         kw = dict(width=256, height=256, packed=False, sh_degree=3, render_mode="RGB+ED", absgrad=True)
-        r_o, a_o, info_o = orc.rasterization(**ci, viewmats=viewmat, Ks=K, **kw)
-        keep = ~info_o["borderline"]
-        v_r, v_a = cotangents([r_o.shape, a_o.shape], seed)
-        v_r, v_a = zero_borderline(v_r, keep), zero_borderline(v_a[..., 0], keep)[..., None]
-        ((r_o * v_r).sum() + (a_o * v_a).sum()).backward()
+        # the oracle under a ConditionTrace: the running error bound of EVERY visible Gaussian's gradient rows (tests/_scenes.py
+        # check_rows_conditioned)
+        with orc.ConditionTrace() as tr:
+            r_o, a_o, info_o = orc.rasterization(**ci, viewmats=viewmat, Ks=K, **kw)
+            keep = ~info_o["borderline"]
+            v_r, v_a = cotangents([r_o.shape, a_o.shape], seed)
+            v_r, v_a = zero_borderline(v_r, keep), zero_borderline(v_a[..., 0], keep)[..., None]
+            ((r_o * v_r).sum() + (a_o * v_a).sum()).backward(retain_graph=True)
+            cond_a, cond_s = tr.param_condition(ci)
+        del tr
         c64 = {k: v.detach().double().requires_grad_(True) for k, v in inp.items()}
         r_d, a_d, _ = orc.rasterization(**c64, viewmats=viewmat.double(), Ks=K.double(), **kw)
         ((r_d * v_r.double()).sum() + (a_d * v_a.double()).sum()).backward()
@@ -87,14 +93,30 @@ for seed in range(first, first + count):
         row_p99_all, row_max_all, row_max_out_all = max(row_p99_all, rp99), max(row_max_all, rmax), max(row_max_out_all, rout)
         row_p99_out_all = max(row_p99_out_all, rp99o)
         row_bad = _ops.DETERMINISTIC["on"] and (rp99o > ROW_P99 or rout > ROW_MAX)
+        # every visible row against its own bound (quiet: one line per scene below)
+        import contextlib
+        import io
+        visible = info_o["radii"][0] > 0
+        c_wa, c_ws = 0.0, 0.0
+        with contextlib.redirect_stdout(io.StringIO()):
+            for k in ci:
+                _n, wa, ws = check_rows_conditioned(first_run[k], ci[k].grad, cond_a[k], cond_s[k], visible, f"seed {seed} aniso {int(aniso)} grad {k}",
+                                                    enforce=False, strict=_ops.DETERMINISTIC["on"])
+                c_wa, c_ws = max(c_wa, wa), max(c_ws, ws)
+        cond_wa_all, cond_ws_all = max(cond_wa_all, c_wa), max(cond_ws_all, c_ws)
+        c_lim, l_lim = (COND_C, COND_LAMBDA) if _ops.DETERMINISTIC["on"] else (COND_C_DEFAULT, COND_LAMBDA_DEFAULT)
+        row_bad = row_bad or c_wa > c_lim or c_ws > l_lim
         bad = worst > 1.0 or not ints or row_bad
         n_fail += int(bad)
         n_vary += int(not same)
         print(f"seed {seed} aniso {int(aniso)}: ints {'bit-exact' if ints else 'DIFFER'}, borderline {int((~keep).sum())} px, "
               f"worst error / allowance = {worst:.3f} ({where}) [{worst_plain:.3f} without the fp64 envelope]; per Gaussian: p99 {rp99:.1e} "
               f"max {rmax:.1e} (outside the fp64 envelope: p99 {rp99o:.1e} max {rout:.1e}, {rwhere})"
+              + f"; ALL {int(visible.sum())} visible rows / own bound: max {c_wa:.3f} x 2^-24 A, {c_ws:.3f} x 2^-24 S"
               + (f", {repeats} runs {'bit-identical' if same else 'VARY'}" if repeats > 1 else "")
               + ("   <-- FAIL" if bad else ""), flush=True)
 print(f"worst over the sweep: {worst_all:.3f} of the allowance; {n_fail} scenes FAIL; {n_vary} scenes vary between repeats")
+print(f"every visible Gaussian against its own running error bound over the sweep: worst error = {cond_wa_all:.3f} x 2^-24 A (asserted <= "
+      f"{COND_C if _ops.DETERMINISTIC['on'] else COND_C_DEFAULT}), {cond_ws_all:.3f} x 2^-24 S (asserted <= {COND_LAMBDA if _ops.DETERMINISTIC['on'] else COND_LAMBDA_DEFAULT})")
 print(f"per-Gaussian relative error over the sweep: worst p99 {row_p99_all:.2e}, worst max {row_max_all:.2e}, outside the fp64 "
       f"envelope: worst p99 {row_p99_out_all:.2e}, worst max {row_max_out_all:.2e} ({f'asserted outside the envelope: p99 <= {ROW_P99:.0e}, max <= {ROW_MAX:.0e}' if _ops.DETERMINISTIC['on'] else 'logged only: default (atomics) mode'})")
