@@ -65,6 +65,8 @@ class ProjCfg:
     with_depth: bool = False
     with_normals: bool = False
     want_normals_world: bool = False
+    colors_are_logit: bool = False   # direct colours: sigmoid() inside the kernel (dn_model.py:491-492, config.sh_degree == 0)
+    skip_culled_records: bool = False   # dnsplat_proj_out.skip_culled_records: culled Gaussians' records are left unwritten
     tight_tiles: bool = False    # dnsplat_camera.tight_tiles: tile counts over the alpha >= 1/255 box instead of gsplat's 3-sigma box
     split_colours: bool = False  # dnsplat_proj_out.phase 1 + 2: the SH colours on a side stream, beside the binning kernels
 
@@ -174,6 +176,8 @@ def _grad_like(param: Tensor) -> Tensor:
         t = a.take(param)
         if t is not None:
             return t.view(param.shape)
+    if a is not None and a.in_use(param):
+        a.invalidate_sh_state()        # autograd is about to `+=` into the bucket: its rows are no longer what the kernel last wrote
     return torch.empty_like(param)
 
 # "sync": read n_isects back before emitting (one host round-trip per frame, what gsplat does).
@@ -313,6 +317,7 @@ def _scene_struct(N, means, quats, scales, opacities, cfg: ProjCfg, sh0, sh0_str
     s.shN, s.shN_stride = _ptr(shN), shN_stride
     s.colors = _ptr(colors)
     s.n_colors = 0 if colors is None else colors.shape[-1]
+    s.colors_are_logit = int(cfg.colors_are_logit and colors is not None)
     return s
 
 
@@ -400,6 +405,7 @@ class _ProjectFn(torch.autograd.Function):
             out.with_depth_channel = int(cfg.with_depth)
             out.with_normal_channels = int(cfg.with_normals)
             out.saturation_flag = _ptr(saturation_flag)      # one word for all cameras of the batch (zeroed by camera_prepare)
+            out.skip_culled_records = int(cfg.skip_culled_records)
             out.phase = 1 if split else 0
             _lib.run("dnsplat_project_fwd", _lib.lib().dnsplat_project_fwd, ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(out), _stream())
             outs.append((cam, out))
@@ -548,7 +554,16 @@ class _ProjectFn(torch.autograd.Function):
                 # factors come from their own small kernel so that their all-gather is already under way while the geometry
                 # gradients are computed below.
                 fac = ex.begin(N, dev, cfg.sh_degree, sh_K, means=means)
-                if ex.deferred:
+                own = ex.use_own_rows()
+                if ex.packed:
+                    # slabs of visible rows only: header, masks and block offsets from the forward's radii (two small launches),
+                    # the rows from dnsplat_project_bwd itself
+                    if ex.scratch is None or ex.scratch.numel() < (N + 63) // 64 or ex.scratch.device != dev:
+                        ex.scratch = torch.empty((N + 63) // 64, dtype=torch.int32, device=dev)
+                    _lib.run("dnsplat_visible_index", _lib.lib().dnsplat_visible_index, N, ex.packed_capacity(N), _ptr(radii[c]),
+                             _ptr(viewmat[c]), _ptr(fac), _ptr(ex.scratch), _stream())
+                    g.sh_packed = _ptr(fac)
+                elif ex.deferred or own:
                     # a captured step (graph.GraphedDpStep): the exchange only starts behind the replay, so nothing is gained by
                     # having the slab early — dnsplat_project_bwd writes it from the values it holds anyway (one launch less)
                     g.sh_factors = _ptr(fac)
@@ -556,7 +571,16 @@ class _ProjectFn(torch.autograd.Function):
                     _lib.run("dnsplat_sh_factors", _lib.lib().dnsplat_sh_factors, N, _ptr(radii[c]), _ptr(viewmat[c]),
                              _ptr(splats_fwd), _ptr(vs_c), _ptr(fac), _stream())
                     ex.launch()
-                g.sh_grads_skip = 1
+                if own:
+                    # this camera's rows as on a single GPU, pre-scaled by 1 / world; the exchange adds the other cameras' shares
+                    from . import dp as _dp
+                    g.sh_grad_scale = ex.scale_override if ex.scale_override is not None else 1.0 / _dp.world_size(ex.group)
+                else:
+                    g.sh_grads_skip = 1
+            elif (ex is None and GRAD_ARENA is not None and GRAD_ARENA.sh_state is not None and ctx.layout == "split" and sh_K == 16
+                  and C == 1 and GRAD_ARENA.holds(v_sh0) and GRAD_ARENA.holds(v_shN)):
+                # the rows land in the flat bucket, whose zero rows are tracked: a Gaussian that is culled again is not re-zeroed
+                g.sh_zero_state = _ptr(GRAD_ARENA.sh_state)
             _lib.run("dnsplat_project_bwd", _lib.lib().dnsplat_project_bwd, ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(fwd),
                      ctypes.byref(g), _stream())
             outs = [v_means, v_quats, v_scales, v_opac, v_coeffs, v_sh0, v_shN, v_colors]
@@ -975,6 +999,8 @@ TIGHT_TILES = os.environ.get("DNSPLAT_TIGHT_TILES", "1") != "0"
 SATURATION_FLAG = os.environ.get("DNSPLAT_SATURATION_FLAG", "1") != "0"
 # dnsplat_raster_args.zero_fill: the fused forward clears the gradient records its backward accumulates into
 FORWARD_ZERO_FILL = os.environ.get("DNSPLAT_FORWARD_ZERO_FILL", "1") != "0"
+# dnsplat_proj_out.skip_culled_records for the fused path (its records never leave the library; DNSPLAT_SKIP_CULLED_RECORDS=0: zero-filled)
+SKIP_CULLED_RECORDS = os.environ.get("DNSPLAT_SKIP_CULLED_RECORDS", "1") != "0"
 # the fused path's projection as two launches, the SH colour half on a side stream beside the binning kernels (ProjCfg.split_colours)
 SPLIT_COLOURS = os.environ.get("DNSPLAT_SPLIT_COLOURS", "0") != "0"
 

@@ -367,6 +367,67 @@ __device__ __forceinline__ void sh_stage_out(float *__restrict__ gbase, int nflo
     for (int e = (n4 << 2) + threadIdx.x; e < nfloats; e += SH_STAGE_THREADS) gbase[e] = lds[sh_lds_index<L>(e)];
 }
 
+// Row-selective staging (round 6): `rows` = one bit per Gaussian of the workgroup (a wave: SH_STAGE_THREADS ==
+// 64).  A 16-byte piece is moved only if a selected row owns one of its floats — the coefficient rows of culled Gaussians (28 % on
+// the benchmark scenes) are neither read nor, once known to be zero, written again.  Rows are 180 bytes at a 180-byte stride, so a
+// skipped row saves the lines it does not share with a selected neighbour.  DNS_PROJ_VISIBLE_ROWS=0 restores whole-span staging.
+#ifndef DNS_PROJ_VISIBLE_ROWS
+#define DNS_PROJ_VISIBLE_ROWS 1
+#endif
+template <int L>
+__device__ __forceinline__ bool sh_piece_selected(int piece, uint64_t rows)
+{
+    constexpr int ROW = ShRowTraits<L>::ROW;
+    const int r0 = (4 * piece) / ROW, r1 = (4 * piece + 3) / ROW;
+    return ((rows >> r0) | (rows >> r1)) & 1ull;
+}
+template <int L>
+__device__ __forceinline__ void sh_stage_in_rows(const float *__restrict__ gbase, int nfloats, float *lds, uint64_t rows)
+{
+    const dns_v4f *g4 = reinterpret_cast<const dns_v4f *>(gbase);
+    const int n4 = nfloats >> 2;
+    constexpr int MAXIT = (SH_STAGE_THREADS * ShRowTraits<L>::ROW / 4 + SH_STAGE_THREADS - 1) / SH_STAGE_THREADS;
+    dns_v4f v[MAXIT];
+#pragma unroll
+    for (int k = 0; k < MAXIT; ++k) {
+        const int i = (int)threadIdx.x + k * SH_STAGE_THREADS;
+        if (i < n4 && sh_piece_selected<L>(i, rows)) {
+#if DNS_PROJ_NT & 1
+            v[k] = __builtin_nontemporal_load(g4 + i);
+#else
+            v[k] = g4[i];
+#endif
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXIT; ++k) {
+        const int i = (int)threadIdx.x + k * SH_STAGE_THREADS;
+        if (i < n4 && sh_piece_selected<L>(i, rows)) {
+            const int o = sh_lds_index<L>(4 * i);
+            lds[o] = v[k].x; lds[o + 1] = v[k].y; lds[o + 2] = v[k].z; lds[o + 3] = v[k].w;
+        }
+    }
+    // the span of a block is a multiple of 16 bytes unless it is the scene's last, partial one
+    for (int e = (n4 << 2) + threadIdx.x; e < nfloats; e += SH_STAGE_THREADS) lds[sh_lds_index<L>(e)] = gbase[e];
+}
+template <int L>
+__device__ __forceinline__ void sh_stage_out_rows(float *__restrict__ gbase, int nfloats, const float *lds, uint64_t rows)
+{
+    dns_v4f *g4 = reinterpret_cast<dns_v4f *>(gbase);
+    const int n4 = nfloats >> 2;
+    for (int i = threadIdx.x; i < n4; i += SH_STAGE_THREADS) {
+        if (!sh_piece_selected<L>(i, rows)) continue;
+        const int o = sh_lds_index<L>(4 * i);
+        const dns_v4f v = {lds[o], lds[o + 1], lds[o + 2], lds[o + 3]};
+#if DNS_PROJ_NT & 2
+        __builtin_nontemporal_store(v, g4 + i);
+#else
+        g4[i] = v;
+#endif
+    }
+    for (int e = (n4 << 2) + threadIdx.x; e < nfloats; e += SH_STAGE_THREADS) gbase[e] = lds[sh_lds_index<L>(e)];
+}
+
 // Feature channel `ch` (run-time: 3 colours or n_colors direct ones, then depth, then the normal) of a record held in
 // registers.  A plain r[REC_CH0 + ch] with a run-time index sends the whole array — and every other privately indexed array
 // of the kernel — to scratch memory: 248 bytes per lane written out and read back per launch, which showed up as ~250 B per
@@ -386,6 +447,14 @@ __device__ __forceinline__ float rec_get_ch(const float *r, int ch)
     return v;
 }
 
+// Packed colour-gradient slab (include/dnsplat.h, dnsplat_visible_index), in 4-byte words: header 8 | masks 2 nb | offsets nb | pad to 4 |
+// rows 3 capacity | pad to 4;  nb = ceil(N / 64).
+__host__ __device__ __forceinline__ size_t dns_packed_rows_offset(int nb) { return ((size_t)8 + 3 * (size_t)nb + 3) & ~(size_t)3; }
+__host__ __device__ __forceinline__ size_t dns_packed_slab_words(int nb, int capacity)
+{
+    return (dns_packed_rows_offset(nb) + 3 * (size_t)capacity + 3) & ~(size_t)3;
+}
+
 struct FwdParams {
     dnsplat_scene s;
     dnsplat_camera c;
@@ -403,8 +472,9 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
     __shared__ float sh_lds[(L == SH_DIRECT || PHASE == 1) ? 1 : SH_STAGE_THREADS * ShRowTraits<L>::LDS_ROW];
     // PHASE 2 is launched with a FEW resident workgroups that walk the blocks of 256 Gaussians (p.blocks of them): it is meant to
     // run beside other kernels and must leave them most of the wave slots.  The other phases: one block per workgroup.
-    for (int vb = blockIdx.x; vb < (PHASE == 2 ? p.blocks : (int)blockIdx.x + 1); vb += gridDim.x) {
-    if (PHASE == 2 && vb != (int)blockIdx.x) __syncthreads();      // the previous block's rows are still being read
+    // The per-block work as a lambda: PHASE 2 calls it in a loop, the others exactly once — written as a loop for all of them, LLVM kept
+    // every loop-invariant of the body (the staging's per-lane row indices and LDS addresses: ~70 VGPRs) live across the projection.
+    auto block_body = [&](const int vb) {
     const int g = vb * blockDim.x + threadIdx.x;
     // The lane's own parameters are requested BEFORE the coefficient rows are staged (and waited for after): one memory round trip
     // for everything the Gaussian needs instead of three in a row (rows | camera | parameters).  A lane beyond N re-reads the last
@@ -420,14 +490,34 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
         for (int i = 0; i < 3; ++i) sc_raw[i] = p.s.scales[3 * gc + i];
         opac_raw = p.s.opacities[gc];
     }
+    // VISIBLE_ROWS (one-launch kernel, staged layouts): the lane projects its Gaussian FIRST and only the coefficient rows of the
+    // Gaussians that survive the culling are staged — a dependent round trip (parameters, then rows) that the other waves of the CU
+    // cover, for 28 % fewer row bytes on the benchmark scenes.
+    constexpr bool VISIBLE_ROWS = DNS_PROJ_VISIBLE_ROWS && PHASE == 0 && L != SH_DIRECT && SH_STAGE_THREADS == DNS_WAVE;
+    Cam cam_pre;
+    Proj st_pre;
+    float sc_pre[3] = {0.f, 0.f, 0.f};
+    bool ok_pre = false;
+    if (VISIBLE_ROWS) {
+        // every lane, no branch around it (a lane beyond N holds the last Gaussian's parameters): the camera stays in SGPRs
+        cam_pre = load_cam(p.c.viewmat, p.c.K);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sc_pre[i] = p.s.scales_are_log ? expf(sc_raw[i]) : sc_raw[i];
+        ok_pre = project_one(mean, quat, sc_pre, cam_pre, p.c.width, p.c.height, p.c.eps2d, p.c.near_plane, p.c.far_plane,
+                             p.c.radius_clip, st_pre) && g < p.s.N;
+    }
+    if (VISIBLE_ROWS) __builtin_amdgcn_sched_barrier(0);      // the projection is finished (registers released) before the rows are requested
+    const uint64_t vis_rows = VISIBLE_ROWS ? __ballot(ok_pre) : ~0ull;
     if (L != SH_DIRECT && PHASE != 1) {
         const int g0 = vb * SH_STAGE_THREADS;
         const int nG = min(SH_STAGE_THREADS, p.s.N - g0);
         const float *base = (L == SH_CAT ? p.s.sh0 : p.s.shN) + (size_t)g0 * ShRowTraits<L>::ROW;
-        sh_stage_in<L>(base, nG * ShRowTraits<L>::ROW, sh_lds);
+        if (VISIBLE_ROWS) sh_stage_in_rows<L>(base, nG * ShRowTraits<L>::ROW, sh_lds, vis_rows);
+        else sh_stage_in<L>(base, nG * ShRowTraits<L>::ROW, sh_lds);
         __syncthreads();
+        if (VISIBLE_ROWS) __builtin_amdgcn_sched_barrier(0);
     }
-    if (PHASE == 2 && (g >= p.s.N || p.o.radii[g] <= 0)) continue;
+    if (PHASE == 2 && (g >= p.s.N || p.o.radii[g] <= 0)) return;
     // STAGED: the 64-byte records of the workgroup's Gaussians leave through LDS as one coalesced stream (the coefficient rows are
     // dead by then) instead of four 16-byte pieces per lane at a 64-byte stride, which is 4x the write requests for the same lines.
     // Every lane has to reach that store, so the per-Gaussian work sits in a do { } while (false) whose `break`s replace the early returns.
@@ -438,7 +528,7 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
     bool phase2_done = false;
     do {                                       // `break` = this Gaussian is finished (beyond N, culled, or its record is in r[])
     if (g >= p.s.N) break;
-    const Cam cam = load_cam(p.c.viewmat, p.c.K);
+    const Cam cam = VISIBLE_ROWS ? cam_pre : load_cam(p.c.viewmat, p.c.K);
 
     float sc[3];
     if (PHASE == 2) {
@@ -469,13 +559,14 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
         break;
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) sc[i] = p.s.scales_are_log ? expf(sc_raw[i]) : sc_raw[i];
+    for (int i = 0; i < 3; ++i) sc[i] = VISIBLE_ROWS ? sc_pre[i] : (p.s.scales_are_log ? expf(sc_raw[i]) : sc_raw[i]);
     float opac = opac_raw;
     if (p.s.opacities_are_logit) opac = sigmoidf(opac);
 
     Proj st;
-    const bool ok = project_one(mean, quat, sc, cam, p.c.width, p.c.height, p.c.eps2d, p.c.near_plane,
-                                p.c.far_plane, p.c.radius_clip, st);
+    bool ok;
+    if (VISIBLE_ROWS) { st = st_pre; ok = ok_pre; }
+    else ok = project_one(mean, quat, sc, cam, p.c.width, p.c.height, p.c.eps2d, p.c.near_plane, p.c.far_plane, p.c.radius_clip, st);
 
     float *rec = p.o.splats + (size_t)g * DNS_REC;
     float4 *rec4 = reinterpret_cast<float4 *>(rec);
@@ -489,7 +580,7 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
         if (p.c.tight_tiles) p.o.tiles_bin[g] = 0;
         if (p.o.tile_boxes) reinterpret_cast<int2 *>(p.o.tile_boxes)[g] = make_int2(0, 0);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!STAGED) { rec4[0] = z4; rec4[1] = z4; rec4[2] = z4; rec4[3] = z4; }
+        if (!STAGED && !p.o.skip_culled_records) { rec4[0] = z4; rec4[1] = z4; rec4[2] = z4; rec4[3] = z4; }
         if (p.o.normals_world) {
             // the reference computes the normal for every Gaussian, visible or not (dn_model.py:544-558)
             float Rq[9], qn[4], inv, n[3], nrm, sgn; int k;
@@ -576,7 +667,10 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
     } else {
 #pragma unroll
         for (int k = 0; k < DNS_MAX_CH; ++k)
-            if (k < p.s.n_colors) r[REC_CH0 + k] = p.s.colors[(size_t)g * p.s.n_colors + k];
+            if (k < p.s.n_colors) {
+                const float cv = p.s.colors[(size_t)g * p.s.n_colors + k];
+                r[REC_CH0 + k] = p.s.colors_are_logit ? sigmoidf(cv) : cv;      // dn_model.py:491-492: sigmoid(colours), sh_degree = None
+            }
         ch = p.s.n_colors;
     }
     if (p.o.with_depth_channel) { rec_set_ch(r, ch, st.mean_c[2]); ch += 1; }
@@ -602,12 +696,15 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
         rec4[3] = make_float4(r[12], r[13], r[14], r[15]);
     }
     } while (false);
-    if (PHASE == 2 && phase2_done) continue;
+    if (PHASE == 2 && phase2_done) return;
     if constexpr (STAGED) {
         // One wave per workgroup: LDS operations complete in program order, so every lane's coefficient reads are behind us.
         // Lane l parks its record at a 20-float stride (conflict-free ds_write_b128), then the wave writes the block's records
         // as 16-byte pieces in address order: piece q = 64 k + lane belongs to the record of lane q / 4.
         __builtin_amdgcn_wave_barrier();
+        // skip_culled_records: the record of a culled Gaussian is all zeros (r[] was never filled) and nobody reads it
+        const bool skip_culled = p.o.skip_culled_records != 0;
+        const uint64_t rec_rows = __ballot(r[REC_OPAC] != 0.f || r[REC_CA] != 0.f);
         dns_v4f *park = reinterpret_cast<dns_v4f *>(sh_lds) + threadIdx.x * 5;
         park[0] = dns_v4f{r[0], r[1], r[2], r[3]};
         park[1] = dns_v4f{r[4], r[5], r[6], r[7]};
@@ -621,7 +718,7 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
         for (int k = 0; k < 4; ++k) {
             const int q = k * SH_STAGE_THREADS + (int)threadIdx.x;
             const dns_v4f v = reinterpret_cast<const dns_v4f *>(sh_lds)[(q >> 2) * 5 + (q & 3)];
-            if (q < pieces) {
+            if (q < pieces && (!skip_culled || ((rec_rows >> (q >> 2)) & 1ull))) {
 #if DNS_PROJ_NT & 2
                 __builtin_nontemporal_store(v, out + q);
 #else
@@ -630,6 +727,14 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_fwd_kernel(FwdParams
             }
         }
     }
+    };      // block_body
+    if constexpr (PHASE == 2) {
+        for (int vb = blockIdx.x; vb < p.blocks; vb += gridDim.x) {
+            if (vb != (int)blockIdx.x) __syncthreads();      // the previous block's rows are still being read
+            block_body(vb);
+        }
+    } else {
+        block_body((int)blockIdx.x);
     }
 }
 
@@ -640,8 +745,18 @@ struct BwdParams {
     dnsplat_proj_grads g;
 };
 
+// 169 VGPRs as hipcc allocates them freely = 2 waves / SIMD, one register over the 168 that allow 3: pinned to 3 (no scratch;
+// DNS_PROJ_BWD_WAVES=0 lets the compiler choose).
+#ifndef DNS_PROJ_BWD_WAVES
+#define DNS_PROJ_BWD_WAVES 3
+#endif
+#if DNS_PROJ_BWD_WAVES
+#define DNS_PROJ_BWD_OCC __attribute__((amdgpu_waves_per_eu(DNS_PROJ_BWD_WAVES, DNS_PROJ_BWD_WAVES)))
+#else
+#define DNS_PROJ_BWD_OCC
+#endif
 template <int L>
-__global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams p)
+__global__ __launch_bounds__(SH_STAGE_THREADS) DNS_PROJ_BWD_OCC void project_bwd_kernel(BwdParams p)
 {
     __shared__ float sh_lds[L == SH_DIRECT ? 1 : SH_STAGE_THREADS * ShRowTraits<L>::LDS_ROW];
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -663,18 +778,36 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
         for (int i = 0; i < 3; ++i) sc_raw[i] = p.s.scales[3 * gc + i];
         opac_in = p.s.opacities[gc];
     }
+    // the coefficient gradients are produced elsewhere (multi-view data parallelism): from the colour gradients dnsplat_sh_factors
+    // took ahead of this launch, all-gathered and turned into rows by dnsplat_sh_grads_from_factors
+    const bool sh_elsewhere = p.g.sh_grads_skip;
+    // Row-selective staging (see sh_stage_in_rows): only the coefficient rows of the visible Gaussians are read, and — with
+    // dnsplat_proj_grads.sh_zero_state — the zero gradient rows of Gaussians that were culled before and are culled again are not
+    // written a second time.  One 64-bit word per workgroup (a wave) on each side.
+    constexpr bool VISIBLE_ROWS = DNS_PROJ_VISIBLE_ROWS && L != SH_DIRECT && SH_STAGE_THREADS == DNS_WAVE;
+    // DNS_PROJ_BWD_ROWS_IN: 1 = READ only the visible Gaussians' coefficient rows (the staging then waits for the radii: a dependent
+    // round trip), 0 = the whole span is requested together with the radii, as before round 6.  Measured inside whole bench runs
+    // (profiles/r06_ab_per_gaussian.txt): at 2 waves / SIMD the round trip costs more than the bytes save (+5 %), at 3 waves it pays
+    // (C5: 0.474 -> 0.451 ms).
+#ifndef DNS_PROJ_BWD_ROWS_IN
+#define DNS_PROJ_BWD_ROWS_IN 1
+#endif
+    const uint64_t vis_rows = __ballot(g < p.s.N && radius_g > 0);
+    uint64_t zero_known = 0ull;
+    const bool track_zero = SH_STAGE_THREADS == DNS_WAVE && p.g.sh_zero_state != nullptr && !sh_elsewhere && p.s.sh_degree >= 0;
+    if (track_zero) zero_known = p.g.sh_zero_state[blockIdx.x];
+    const bool my_row_stays_zero = ((zero_known & ~vis_rows) >> threadIdx.x) & 1ull;   // culled now, zero in memory already
     if (L != SH_DIRECT) {
         const float *base = (L == SH_CAT ? p.s.sh0 : p.s.shN) + (size_t)g0 * ShRowTraits<L>::ROW;
-        sh_stage_in<L>(base, nG * ShRowTraits<L>::ROW, sh_lds);
+        if (VISIBLE_ROWS && DNS_PROJ_BWD_ROWS_IN) sh_stage_in_rows<L>(base, nG * ShRowTraits<L>::ROW, sh_lds, vis_rows);
+        else sh_stage_in<L>(base, nG * ShRowTraits<L>::ROW, sh_lds);
         __syncthreads();
     }
     // in the staged layouts a lane turns its LDS row of coefficients into its row of coefficient gradients in
     // place; the block then stores the whole span with coalesced 16-byte writes
     float *lrow = sh_lds + (L == SH_DIRECT ? 0 : threadIdx.x * ShRowTraits<L>::LDS_ROW);
     float *lN = L == SH_CAT ? lrow + 3 : lrow;
-    // the coefficient gradients are produced elsewhere (multi-view data parallelism): from the colour gradients dnsplat_sh_factors
-    // took ahead of this launch, all-gathered and turned into rows by dnsplat_sh_grads_from_factors
-    const bool sh_elsewhere = p.g.sh_grads_skip;
+    const float shs = (p.g.sh_grad_scale != 0.f) ? p.g.sh_grad_scale : 1.f;      // own-camera rows of a data-parallel step: x 1 / world
     if (g < p.s.N) {
     const int nbK = (p.s.sh_degree >= 0) ? (p.s.sh_degree + 1) * (p.s.sh_degree + 1) : 0;
 
@@ -707,9 +840,9 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
 
     if (!ok) {
         if (L == SH_CAT) { lrow[0] = 0.f; lrow[1] = 0.f; lrow[2] = 0.f; }
-        else if (vsh0) { vsh0[0] = 0.f; vsh0[1] = 0.f; vsh0[2] = 0.f; }
+        else if (vsh0 && !sh_elsewhere && !my_row_stays_zero) { vsh0[0] = 0.f; vsh0[1] = 0.f; vsh0[2] = 0.f; }
         if (L != SH_DIRECT) { for (int k = 0; k < 45; ++k) lN[k] = 0.f; }
-        else if (vshN) for (int k = 0; k < 3 * restK; ++k) vshN[k] = 0.f;
+        else if (vshN && !sh_elsewhere && !my_row_stays_zero) for (int k = 0; k < 3 * restK; ++k) vshN[k] = 0.f;
         if (p.g.v_colors) for (int k = 0; k < p.s.n_colors; ++k) p.g.v_colors[(size_t)g * p.s.n_colors + k] = 0.f;
     } else {
         float vr[DNS_REC];
@@ -763,14 +896,15 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
 #pragma unroll
                 for (int i = 0; i < 3; ++i) vcol[i] = (col[i] + 0.5f >= 0.f) ? vr[REC_CH0 + i] : 0.f;
                 fac3[0] = vcol[0]; fac3[1] = vcol[1]; fac3[2] = vcol[2];
-                if (vsh0 && !sh_elsewhere) { vsh0[0] = bas[0] * vcol[0]; vsh0[1] = bas[0] * vcol[1]; vsh0[2] = bas[0] * vcol[2]; }
+                const float vcs[3] = {vcol[0] * shs, vcol[1] * shs, vcol[2] * shs};
+                if (vsh0 && !sh_elsewhere) { vsh0[0] = bas[0] * vcs[0]; vsh0[1] = bas[0] * vcs[1]; vsh0[2] = bas[0] * vcs[2]; }
                 if (vshN && !sh_elsewhere) {
 #pragma unroll
                     for (int k = 1; k < 16; ++k)
                         if (k < nbK) {
-                            vshN[3 * (k - 1) + 0] = bas[k] * vcol[0];
-                            vshN[3 * (k - 1) + 1] = bas[k] * vcol[1];
-                            vshN[3 * (k - 1) + 2] = bas[k] * vcol[2];
+                            vshN[3 * (k - 1) + 0] = bas[k] * vcs[0];
+                            vshN[3 * (k - 1) + 1] = bas[k] * vcs[1];
+                            vshN[3 * (k - 1) + 2] = bas[k] * vcs[2];
                         }
                     for (int k = 3 * (nbK - 1); k < 3 * restK; ++k) vshN[k] = 0.f;
                 }
@@ -796,17 +930,18 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
 #pragma unroll
                 for (int i = 0; i < 3; ++i) vcol[i] = (col[i] + 0.5f >= 0.f) ? vr[REC_CH0 + i] : 0.f;
                 fac3[0] = vcol[0]; fac3[1] = vcol[1]; fac3[2] = vcol[2];
-                if (L == SH_CAT) { lrow[0] = bas[0] * vcol[0]; lrow[1] = bas[0] * vcol[1]; lrow[2] = bas[0] * vcol[2]; }
-                else if (vsh0 && !sh_elsewhere) { vsh0[0] = bas[0] * vcol[0]; vsh0[1] = bas[0] * vcol[1]; vsh0[2] = bas[0] * vcol[2]; }
+                const float vcs[3] = {vcol[0] * shs, vcol[1] * shs, vcol[2] * shs};
+                if (L == SH_CAT) { lrow[0] = bas[0] * vcs[0]; lrow[1] = bas[0] * vcs[1]; lrow[2] = bas[0] * vcs[2]; }
+                else if (vsh0 && !sh_elsewhere) { vsh0[0] = bas[0] * vcs[0]; vsh0[1] = bas[0] * vcs[1]; vsh0[2] = bas[0] * vcs[2]; }
 #pragma unroll
                 for (int k = 1; k < 16; ++k)     // read the coefficient, then overwrite it with its gradient
                     if (k < nbK) {
                         const float a0 = lN[3 * (k - 1)], a1 = lN[3 * (k - 1) + 1], a2 = lN[3 * (k - 1) + 2];
                         const float s = a0 * vcol[0] + a1 * vcol[1] + a2 * vcol[2];
                         vdn[0] += bx[k] * s; vdn[1] += by[k] * s; vdn[2] += bz[k] * s;
-                        lN[3 * (k - 1) + 0] = bas[k] * vcol[0];
-                        lN[3 * (k - 1) + 1] = bas[k] * vcol[1];
-                        lN[3 * (k - 1) + 2] = bas[k] * vcol[2];
+                        lN[3 * (k - 1) + 0] = bas[k] * vcs[0];
+                        lN[3 * (k - 1) + 1] = bas[k] * vcs[1];
+                        lN[3 * (k - 1) + 2] = bas[k] * vcs[2];
                     }
                 for (int k = 3 * (nbK - 1); k < 45; ++k) lN[k] = 0.f;
             }
@@ -821,7 +956,14 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
             if (p.g.v_colors)
 #pragma unroll
                 for (int k = 0; k < DNS_MAX_CH; ++k)
-                    if (k < p.s.n_colors) p.g.v_colors[(size_t)g * p.s.n_colors + k] = vr[REC_CH0 + k];
+                    if (k < p.s.n_colors) {
+                        float vck = vr[REC_CH0 + k];
+                        if (p.s.colors_are_logit) {      // through sigmoid(): s (1 - s), s re-derived from the logit as the forward did
+                            const float sg = sigmoidf(p.s.colors[(size_t)g * p.s.n_colors + k]);
+                            vck = vck * sg * (1.f - sg);
+                        }
+                        p.g.v_colors[(size_t)g * p.s.n_colors + k] = vck;
+                    }
             ch = p.s.n_colors;
         }
         if (p.o.with_depth_channel) { v_depth += rec_get_ch(vr, ch); ch += 1; }
@@ -942,6 +1084,18 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
     p.g.v_quats[4 * g] = v_quat[0]; p.g.v_quats[4 * g + 1] = v_quat[1]; p.g.v_quats[4 * g + 2] = v_quat[2]; p.g.v_quats[4 * g + 3] = v_quat[3];
     p.g.v_scales[3 * g] = v_scale[0]; p.g.v_scales[3 * g + 1] = v_scale[1]; p.g.v_scales[3 * g + 2] = v_scale[2];
     p.g.v_opacities[g] = v_opac;
+    if (p.g.sh_packed) {
+        // packed slab (dnsplat_visible_index wrote header, masks and offsets from the same radii): rows of the visible Gaussians only
+        const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.g.sh_packed);
+        const uint32_t cap = hdr[4];
+        const int nb = (p.s.N + 63) >> 6;
+        const uint32_t *offs = hdr + 8 + 2 * nb;
+        float *rows = p.g.sh_packed + dns_packed_rows_offset(nb);
+        if (visible) {
+            const uint32_t k = offs[blockIdx.x] + (uint32_t)__popcll(vis_rows & ((1ull << threadIdx.x) - 1ull));
+            if (k < cap) { rows[3 * (size_t)k] = fac3[0]; rows[3 * (size_t)k + 1] = fac3[1]; rows[3 * (size_t)k + 2] = fac3[2]; }
+        }
+    }
     if (p.g.sh_factors) {
         // the slab of dnsplat_sh_factors, from what this lane holds anyway (one launch and two record lines per Gaussian less)
         float *f = p.g.sh_factors + 3 * (size_t)g;
@@ -956,8 +1110,12 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void project_bwd_kernel(BwdParams
     if (L != SH_DIRECT && !p.g.sh_grads_skip) {
         __syncthreads();
         float *base = (L == SH_CAT ? p.g.v_sh0 : p.g.v_shN) + (size_t)g0 * ShRowTraits<L>::ROW;
-        sh_stage_out<L>(base, nG * ShRowTraits<L>::ROW, sh_lds);
+        // rows to store: the visible ones and the culled ones whose memory is not known to be zero
+        if (VISIBLE_ROWS && track_zero) sh_stage_out_rows<L>(base, nG * ShRowTraits<L>::ROW, sh_lds, vis_rows | ~zero_known);
+        else sh_stage_out<L>(base, nG * ShRowTraits<L>::ROW, sh_lds);
     }
+    // what memory holds now: zero rows exactly where the Gaussian is culled (lanes beyond N: bits unused)
+    if (track_zero && threadIdx.x == 0) p.g.sh_zero_state[blockIdx.x] = ~vis_rows;
 }
 
 __global__ __launch_bounds__(256) void pack_splats_kernel(int N, const float *__restrict__ means2d,
@@ -982,10 +1140,12 @@ __global__ __launch_bounds__(256) void pack_splats_kernel(int N, const float *__
     rec4[3] = make_float4(r[12], r[13], r[14], r[15]);
 }
 
-// v_coeff = scale * sum over views of basis(dir_view) (x) v_colour_view  — see dnsplat_sh_grads_from_factors
-template <int L>
-__global__ __launch_bounds__(SH_STAGE_THREADS) void sh_from_factors_kernel(int N, int n_views, const float *__restrict__ factors,
-                                                              const float *__restrict__ means, int degree,
+// v_coeff = scale * sum over views of basis(dir_view) (x) v_colour_view  — see dnsplat_sh_grads_from_factors.
+// PACKED: the views' slabs hold the rows of their visible Gaussians only (dnsplat_visible_index); `slab_words` apart.
+// ADD: the rows already hold view `skip_view`'s (pre-scaled) share, the other views are added in place (dnsplat_sh_grads_add_factors).
+template <int L, bool PACKED, bool ADD>
+__global__ __launch_bounds__(SH_STAGE_THREADS) void sh_from_factors_kernel(int N, int n_views, int skip_view, const float *__restrict__ factors,
+                                                              size_t slab_words, const float *__restrict__ means, int degree,
                                                               float scale, float *__restrict__ v_sh0, int s0,
                                                               float *__restrict__ v_shN, int sN, int restK)
 {
@@ -994,18 +1154,34 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void sh_from_factors_kernel(int N
     const int g0 = blockIdx.x * SH_STAGE_THREADS;
     const int nG = min(SH_STAGE_THREADS, N - g0);
     const int nb = (degree + 1) * (degree + 1);
+    const int nblk = (N + 63) >> 6;
     float acc[48];
 #pragma unroll
     for (int i = 0; i < 48; ++i) acc[i] = 0.f;
+    bool any = false;
     if (g < N) {
-        const size_t slab = (size_t)3 * N + 4;             // one view: [N,3] colour gradients | camera position (3) | pad
         const float mx = means[3 * g], my = means[3 * g + 1], mz = means[3 * g + 2];
         for (int v = 0; v < n_views; ++v) {
-            const float *f = factors + (size_t)v * slab;
-            const float c0 = f[3 * (size_t)g], c1 = f[3 * (size_t)g + 1], c2 = f[3 * (size_t)g + 2];
+            if (v == skip_view) continue;
+            const float *f = factors + (size_t)v * slab_words;
+            float c0, c1, c2;
+            const float *pos;
+            if (PACKED) {
+                const uint32_t *hdr = reinterpret_cast<const uint32_t *>(f);
+                const uint64_t word = reinterpret_cast<const uint64_t *>(hdr + 8)[blockIdx.x];
+                if (!((word >> threadIdx.x) & 1ull)) continue;
+                const uint32_t k = (hdr + 8 + 2 * nblk)[blockIdx.x] + (uint32_t)__popcll(word & ((1ull << threadIdx.x) - 1ull));
+                if (k >= hdr[4]) continue;                     // beyond the slab's capacity: dropped by the sender (it reports the overflow)
+                const float *row = f + dns_packed_rows_offset(nblk) + 3 * (size_t)k;
+                c0 = row[0]; c1 = row[1]; c2 = row[2];
+                pos = f + 1;
+            } else {
+                c0 = f[3 * (size_t)g]; c1 = f[3 * (size_t)g + 1]; c2 = f[3 * (size_t)g + 2];
+                pos = f + (size_t)3 * N;
+            }
             if (c0 == 0.f && c1 == 0.f && c2 == 0.f) continue;
+            any = true;
             // the view direction of camera v, re-derived as the projection kernels of rank v derived it (same operations)
-            const float *pos = f + (size_t)3 * N;
             float dx = mx - pos[0], dy = my - pos[1], dz = mz - pos[2];
             const float inorm = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
             dx *= inorm; dy *= inorm; dz *= inorm;
@@ -1021,30 +1197,106 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) void sh_from_factors_kernel(int N
         }
     }
     if (L == SH_DIRECT) {
-        if (g >= N) return;
+        if (g >= N || (ADD && !any)) return;
         float *r0 = v_sh0 + (size_t)g * s0;
-        r0[0] = scale * acc[0]; r0[1] = scale * acc[1]; r0[2] = scale * acc[2];
+        if (ADD) { r0[0] += scale * acc[0]; r0[1] += scale * acc[1]; r0[2] += scale * acc[2]; }
+        else { r0[0] = scale * acc[0]; r0[1] = scale * acc[1]; r0[2] = scale * acc[2]; }
         if (v_shN) {
             float *rN = v_shN + (size_t)g * sN;
-            for (int k = 0; k < 3 * restK; ++k) rN[k] = k < 45 ? scale * acc[3 + k] : 0.f;
+            if (ADD) { for (int k = 0; k < 3 * restK && k < 45; ++k) rN[k] += scale * acc[3 + k]; }
+            else for (int k = 0; k < 3 * restK; ++k) rN[k] = k < 45 ? scale * acc[3 + k] : 0.f;
         }
         return;
+    }
+    float *base = (L == SH_CAT ? v_sh0 : v_shN) + (size_t)g0 * ShRowTraits<L>::ROW;
+    const uint64_t touched = __ballot(any);
+    if (ADD) {
+        if (touched == 0ull) return;                         // nobody else saw this block's Gaussians: the own rows stand (wave-uniform)
+        sh_stage_in_rows<L>(base, nG * ShRowTraits<L>::ROW, sh_lds, touched);
+        __syncthreads();
     }
     if (g < N) {
         float *lrow = sh_lds + threadIdx.x * ShRowTraits<L>::LDS_ROW;
         if (L == SH_CAT) {
+            if (ADD) {
+                if (any) {
 #pragma unroll
-            for (int k = 0; k < 48; ++k) lrow[k] = scale * acc[k];
+                    for (int k = 0; k < 48; ++k) lrow[k] += scale * acc[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 48; ++k) lrow[k] = scale * acc[k];
+            }
         } else {
             float *r0 = v_sh0 + (size_t)g * s0;
-            r0[0] = scale * acc[0]; r0[1] = scale * acc[1]; r0[2] = scale * acc[2];
+            if (ADD) {
+                if (any) {
+                    r0[0] += scale * acc[0]; r0[1] += scale * acc[1]; r0[2] += scale * acc[2];
 #pragma unroll
-            for (int k = 0; k < 45; ++k) lrow[k] = scale * acc[3 + k];
+                    for (int k = 0; k < 45; ++k) lrow[k] += scale * acc[3 + k];
+                }
+            } else {
+                r0[0] = scale * acc[0]; r0[1] = scale * acc[1]; r0[2] = scale * acc[2];
+#pragma unroll
+                for (int k = 0; k < 45; ++k) lrow[k] = scale * acc[3 + k];
+            }
         }
     }
     __syncthreads();
-    float *base = (L == SH_CAT ? v_sh0 : v_shN) + (size_t)g0 * ShRowTraits<L>::ROW;
-    sh_stage_out<L>(base, nG * ShRowTraits<L>::ROW, sh_lds);
+    if (ADD) sh_stage_out_rows<L>(base, nG * ShRowTraits<L>::ROW, sh_lds, touched);
+    else sh_stage_out<L>(base, nG * ShRowTraits<L>::ROW, sh_lds);
+}
+
+// dnsplat_visible_index, launch 1: one wave per block of 64 Gaussians -> mask word + popcount; thread 0 of the grid writes the header
+__global__ __launch_bounds__(256) void visible_mask_kernel(int N, uint32_t capacity, const int32_t *__restrict__ radii,
+                                                           const float *__restrict__ viewmat, float *__restrict__ slab,
+                                                           uint32_t *__restrict__ counts)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nblk = (N + 63) >> 6;
+    const bool vis = g < N && radii[g] > 0;
+    const uint64_t word = __ballot(vis);
+    const int b = g >> 6;
+    if ((threadIdx.x & 63) == 0 && b < nblk) {
+        reinterpret_cast<uint64_t *>(reinterpret_cast<uint32_t *>(slab) + 8)[b] = word;
+        counts[b] = (uint32_t)__popcll(word);
+    }
+    if (g == 0) {
+        float Rv[9], t[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Rv[3 * i + j] = viewmat[4 * i + j];
+            t[i] = viewmat[4 * i + 3];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) slab[1 + i] = -(Rv[0 + i] * t[0] + Rv[3 + i] * t[1] + Rv[6 + i] * t[2]);   // = load_cam().pos
+        uint32_t *hdr = reinterpret_cast<uint32_t *>(slab);
+        hdr[4] = capacity; hdr[5] = (uint32_t)N; hdr[6] = 0u; hdr[7] = 0u;
+    }
+}
+
+// launch 2: exclusive prefix sum of the block popcounts (one workgroup; 78 k words at 5 M Gaussians) + the total
+__global__ __launch_bounds__(1024) void visible_scan_kernel(int nblk, const uint32_t *__restrict__ counts, float *__restrict__ slab)
+{
+    __shared__ uint32_t part[1024];
+    uint32_t *hdr = reinterpret_cast<uint32_t *>(slab);
+    uint32_t *offs = hdr + 8 + 2 * nblk;
+    const int per = (nblk + 1023) / 1024;
+    const int b0 = threadIdx.x * per, b1 = min(nblk, b0 + per);
+    uint32_t sum = 0;
+    for (int b = b0; b < b1; ++b) sum += counts[b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (int b = b0; b < b1; ++b) { offs[b] = run; run += counts[b]; }
+    if (threadIdx.x == 1023) hdr[0] = part[1023];
 }
 
 }  // namespace
@@ -1192,34 +1444,86 @@ extern "C" int dnsplat_sh_factors(int32_t N, const int32_t *radii, const float *
     return DNSPLAT_OK;
 }
 
-extern "C" int dnsplat_sh_grads_from_factors(int32_t N, int32_t n_views, const float *factors, const float *means,
-                                             int32_t sh_degree, int32_t sh_K,
-                                             float scale, float *v_sh0, int32_t v_sh0_stride, float *v_shN,
-                                             int32_t v_shN_stride, dnsplat_stream_t stream)
+template <bool PACKED, bool ADD>
+static int launch_sh_from_factors(int32_t N, int32_t n_views, int32_t skip_view, const float *factors, size_t slab_words, const float *means,
+                                  int32_t sh_degree, int32_t sh_K, float scale, float *v_sh0, int32_t v_sh0_stride, float *v_shN,
+                                  int32_t v_shN_stride, dnsplat_stream_t stream)
 {
     if (N < 0 || n_views < 1 || sh_degree < 0 || sh_degree > 3 || sh_K < (sh_degree + 1) * (sh_degree + 1)) return DNSPLAT_ERR_INVALID_ARG;
-    if (N == 0) return DNSPLAT_OK;
+    if (ADD && (skip_view < 0 || skip_view >= n_views)) return DNSPLAT_ERR_INVALID_ARG;
+    if (N == 0 || (ADD && n_views == 1)) return DNSPLAT_OK;         // a single view: its rows are complete, nothing is launched
     if (!factors || !means || !v_sh0 || (sh_K > 1 && !v_shN)) return DNSPLAT_ERR_INVALID_ARG;
     dnsplat_scene fake{};
     fake.sh_degree = sh_degree; fake.sh_K = sh_K;
     const int layout = sh_layout(&fake, v_sh0, v_sh0_stride, v_shN, v_shN_stride);
     dim3 block(SH_STAGE_THREADS), grid((N + SH_STAGE_THREADS - 1) / SH_STAGE_THREADS);
     const int restK = sh_K - 1;
+    const int skip = ADD ? skip_view : -1;
     switch (layout) {
         case SH_SPLIT:
-            hipLaunchKernelGGL(sh_from_factors_kernel<SH_SPLIT>, grid, block, 0, (hipStream_t)stream, N, n_views, factors, means, sh_degree,
-                               scale, v_sh0, v_sh0_stride, v_shN, v_shN_stride, restK);
+            hipLaunchKernelGGL((sh_from_factors_kernel<SH_SPLIT, PACKED, ADD>), grid, block, 0, (hipStream_t)stream, N, n_views, skip, factors,
+                               slab_words, means, sh_degree, scale, v_sh0, v_sh0_stride, v_shN, v_shN_stride, restK);
             break;
         case SH_CAT:
-            hipLaunchKernelGGL(sh_from_factors_kernel<SH_CAT>, grid, block, 0, (hipStream_t)stream, N, n_views, factors, means, sh_degree,
-                               scale, v_sh0, v_sh0_stride, v_shN, v_shN_stride, restK);
+            hipLaunchKernelGGL((sh_from_factors_kernel<SH_CAT, PACKED, ADD>), grid, block, 0, (hipStream_t)stream, N, n_views, skip, factors,
+                               slab_words, means, sh_degree, scale, v_sh0, v_sh0_stride, v_shN, v_shN_stride, restK);
             break;
         default:
-            hipLaunchKernelGGL(sh_from_factors_kernel<SH_DIRECT>, grid, block, 0, (hipStream_t)stream, N, n_views, factors, means, sh_degree,
-                               scale, v_sh0, v_sh0_stride, v_shN, v_shN_stride, restK);
+            hipLaunchKernelGGL((sh_from_factors_kernel<SH_DIRECT, PACKED, ADD>), grid, block, 0, (hipStream_t)stream, N, n_views, skip, factors,
+                               slab_words, means, sh_degree, scale, v_sh0, v_sh0_stride, v_shN, v_shN_stride, restK);
     }
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;
+}
+
+extern "C" int dnsplat_sh_grads_from_factors(int32_t N, int32_t n_views, const float *factors, const float *means,
+                                             int32_t sh_degree, int32_t sh_K,
+                                             float scale, float *v_sh0, int32_t v_sh0_stride, float *v_shN,
+                                             int32_t v_shN_stride, dnsplat_stream_t stream)
+{
+    return launch_sh_from_factors<false, false>(N, n_views, -1, factors, (size_t)3 * (size_t)(N > 0 ? N : 0) + 4, means, sh_degree, sh_K, scale,
+                                                v_sh0, v_sh0_stride, v_shN, v_shN_stride, stream);
+}
+
+extern "C" int dnsplat_sh_grads_add_factors(int32_t N, int32_t n_views, int32_t skip_view, const float *factors, const float *means,
+                                            int32_t sh_degree, int32_t sh_K, float scale, float *v_sh0, int32_t v_sh0_stride,
+                                            float *v_shN, int32_t v_shN_stride, dnsplat_stream_t stream)
+{
+    return launch_sh_from_factors<false, true>(N, n_views, skip_view, factors, (size_t)3 * (size_t)(N > 0 ? N : 0) + 4, means, sh_degree, sh_K,
+                                               scale, v_sh0, v_sh0_stride, v_shN, v_shN_stride, stream);
+}
+
+extern "C" size_t dnsplat_packed_slab_floats(int32_t N, int32_t capacity)
+{
+    if (N < 0 || capacity < 0) return 0;
+    return dns_packed_slab_words((N + 63) >> 6, capacity);
+}
+
+extern "C" int dnsplat_visible_index(int32_t N, int32_t capacity, const int32_t *radii, const float *viewmat, float *slab,
+                                     uint32_t *scratch, dnsplat_stream_t stream)
+{
+    if (N < 0 || capacity < 0 || !viewmat || !slab) return DNSPLAT_ERR_INVALID_ARG;
+    if (N > 0 && (!radii || !scratch)) return DNSPLAT_ERR_INVALID_ARG;
+    const int nblk = (N + 63) >> 6;
+    hipLaunchKernelGGL(visible_mask_kernel, dim3((N + 256) / 256), dim3(256), 0, (hipStream_t)stream, N, (uint32_t)capacity, radii, viewmat,
+                       slab, scratch);
+    DNS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(visible_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nblk, scratch, slab);
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}
+
+extern "C" int dnsplat_sh_grads_from_packed(int32_t N, int32_t capacity, int32_t n_views, int32_t skip_view, const float *slabs,
+                                            const float *means, int32_t sh_degree, int32_t sh_K, float scale, float *v_sh0,
+                                            int32_t v_sh0_stride, float *v_shN, int32_t v_shN_stride, dnsplat_stream_t stream)
+{
+    if (capacity < 0) return DNSPLAT_ERR_INVALID_ARG;
+    const size_t words = dns_packed_slab_words(((N > 0 ? N : 0) + 63) >> 6, capacity);
+    if (skip_view >= 0)
+        return launch_sh_from_factors<true, true>(N, n_views, skip_view, slabs, words, means, sh_degree, sh_K, scale, v_sh0, v_sh0_stride, v_shN,
+                                                  v_shN_stride, stream);
+    return launch_sh_from_factors<true, false>(N, n_views, -1, slabs, words, means, sh_degree, sh_K, scale, v_sh0, v_sh0_stride, v_shN,
+                                               v_shN_stride, stream);
 }
 
 extern "C" int dnsplat_pack_splats(int32_t N, const float *means2d, const float *conics, const float *opacities,

@@ -54,6 +54,18 @@ class GradArena:
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self._by_ptr = {params[k].data_ptr(): k for k in GRAD_KEYS}
         self._leaf = {k: params[k] for k in GRAD_KEYS}      # the leaves whose .grad the slices become
+        # dnsplat_proj_grads.sh_zero_state: one bit per Gaussian, "the SH coefficient-gradient rows of this Gaussian are zero in the
+        # bucket" — the projection backward then does not write the zero rows of a Gaussian that is culled again (28 % of the rows on
+        # the benchmark scenes).  The bucket starts zero-filled, so every bit starts set.  CONTRACT: whoever else writes non-zero
+        # values into the features_dc / features_rest slices (a collective over the bucket, an accumulation `+=` by autograd, user
+        # code) calls invalidate_sh_state(); scaling or zeroing them in place keeps the bits valid.
+        # OFF by default (DNSPLAT_SH_ZERO_STATE=1 turns it on): measured on MI355X (profiles/r06_ab_per_gaussian.txt) the skipped rows
+        # turn the backward's one streaming store per workgroup into 16-byte pieces with holes — partial lines — and the kernel gets
+        # 5-10 % SLOWER although it writes 10 % fewer bytes.
+        n_gauss = params["features_dc"].shape[0]
+        on = os.environ.get("DNSPLAT_SH_ZERO_STATE", "0") == "1"
+        self.sh_state = (torch.full(((n_gauss + 63) // 64,), -1, dtype=torch.int64, device=dev)
+                         if on and dev is not None and dev.type == "cuda" else None)
 
     def view(self, name: str) -> Tensor:
         off, n, shape = self.slices[name]
@@ -84,6 +96,11 @@ class GradArena:
     def bytes(self) -> int:
         return self.flat.numel() * 4
 
+    def invalidate_sh_state(self) -> None:
+        """Nothing is known about the SH gradient rows any more (see ``sh_state``): the next projection backward writes them all."""
+        if self.sh_state is not None:
+            self.sh_state.zero_()
+
 
 class ShFactorExchange:
     """Compact exchange of the SH-coefficient gradients between the cameras of a data-parallel step.
@@ -99,7 +116,19 @@ class ShFactorExchange:
     One rank's slab: ``[N,3]`` colour gradients, then its camera position (3 floats) and a pad word: 3 N + 4 floats.
     """
 
-    def __init__(self):
+    def __init__(self, own_rows: Optional[bool] = None, packed: bool = False, capacity: Optional[int] = None):
+        # own_rows: the projection backward writes THIS rank's camera's coefficient rows itself (pre-scaled by 1 / world) and the
+        # rebuild only ADDS the other cameras' (dnsplat_sh_grads_add_factors / _from_packed with skip_view = rank): with one rank there
+        # is nothing to add and no pass over the 192 B / Gaussian at all.  At world >= 2 the read-modify-write moves more bytes than
+        # rebuilding every row from the slabs (DESIGN.md 6), hence None = "only when the world is one rank".
+        self.own_rows = own_rows
+        # packed: slabs of the VISIBLE Gaussians' rows only (include/dnsplat.h, dnsplat_visible_index): mask + block offsets + rows,
+        # ``capacity`` rows per slab — the same on every rank (all-gather of equal pieces); None = N (never overflows, saves nothing on
+        # the wire: call calibrate() once the scene has been rendered).  Whole scenes only (not SlicedShExchange).
+        self.packed = bool(packed)
+        self.capacity = capacity
+        self.scratch: Optional[Tensor] = None
+        self.scale_override: Optional[float] = None   # tests: the own-rows pre-scale of a world this process is not part of
         self.mine: Optional[Tensor] = None
         self.gathered: Optional[Tensor] = None
         self.meta = None
@@ -114,9 +143,36 @@ class ShFactorExchange:
         """Forgets factors that were produced but never rebuilt (warm-up frames of a graph capture)."""
         self.meta, self.work = None, None
 
-    @staticmethod
-    def slab_floats(N: int) -> int:
+    def slab_floats(self, N: int) -> int:
+        if self.packed:
+            cap = N if self.capacity is None else min(int(self.capacity), N)
+            nb = (N + 63) // 64
+            rows0 = (8 + 3 * nb + 3) & ~3                    # = dnsplat_packed_slab_floats(N, cap): header | masks | offsets | rows
+            return (rows0 + 3 * cap + 3) & ~3
         return 3 * N + 4
+
+    def packed_capacity(self, N: int) -> int:
+        return N if self.capacity is None else min(int(self.capacity), N)
+
+    def use_own_rows(self, group=None) -> bool:
+        return (world_size(self.group if group is None else group) == 1) if self.own_rows is None else bool(self.own_rows)
+
+    def calibrate(self, radii: Tensor, group=None, slack: float = 1.1) -> int:
+        """Packed slabs: sets ``capacity`` to ``slack`` x the largest visible count any rank reports for ``radii`` (its last frame),
+        rounded up to 1024 rows — one host sync and one tiny collective, outside the step.  Call it again after densification."""
+        n_vis = int((radii.reshape(-1) > 0).sum().item())
+        n_vis = int(max_over_ranks(float(n_vis), radii.device, self.group if group is None else group))
+        self.capacity = min(radii.numel(), (int(n_vis * slack) + 1023) // 1024 * 1024)
+        self.mine = self.gathered = None
+        return self.capacity
+
+    def overflowed(self) -> bool:
+        """Packed slabs: True if a gathered slab of the last step reported more visible Gaussians than its capacity (rows were dropped:
+        the SH gradients of that step are incomplete).  Synchronises; call it now and then, like GraphedStep.check()."""
+        if not self.packed or self.gathered is None:
+            return False
+        hdr = self.gathered.view(torch.int32).reshape(self.gathered.shape[0], -1)[:, :8].cpu()
+        return bool((hdr[:, 0] > hdr[:, 4]).any())
 
     def begin(self, N, device, sh_degree, sh_K, means: Optional[Tensor] = None) -> Tensor:
         """Called by the projection backward: returns the slab (3 N + 4 floats) dnsplat_sh_factors fills and remembers the
@@ -161,6 +217,10 @@ class ShFactorExchange:
             return 0
         N, sh_degree, sh_K = self.meta
         w = world_size(group)
+        own = self.use_own_rows(group)
+        if own and w == 1 and not _collectives_on(group):
+            self.meta = None              # one rank, no process group: the projection backward has written the complete rows
+            return 0
         buf = self._gather_buffer(w)
         if self.work is not None:
             self.work.wait()
@@ -170,7 +230,12 @@ class ShFactorExchange:
         else:
             buf.copy_(self.mine[None])
         self.meta = None
-        self._rebuild(buf, self.means, N, w, sh_degree, sh_K, v_coeffs, v_sh0, v_shN)
+        if own or self.packed:
+            if not (own and w == 1):      # a single view whose rows are already in place: nothing to add
+                self._rebuild(buf, self.means, N, w, sh_degree, sh_K, v_coeffs, v_sh0, v_shN,
+                              skip_view=(rank_of(group) if own else -1), packed_capacity=(self.packed_capacity(N) if self.packed else None))
+        else:
+            self._rebuild(buf, self.means, N, w, sh_degree, sh_K, v_coeffs, v_sh0, v_shN)
         return (w - 1) * self.slab_floats(N) * 4
 
 
@@ -196,7 +261,7 @@ class SlicedShExchange(ShFactorExchange):
     ALIGN = 256
 
     def __init__(self, slices: int = 4):
-        super().__init__()
+        super().__init__(own_rows=False)          # every slice's rows are rebuilt from the gathered mini slabs
         self.slices = max(1, int(slices))
         self.record_only = False
         self.records = None            # [(entry point args..., keep-alive tensors)] of the captured backward
@@ -311,7 +376,8 @@ class SlicedShExchange(ShFactorExchange):
         return n_geo * 4 + got
 
 
-def _rebuild_hip(gathered: Tensor, means: Tensor, N: int, w: int, sh_degree: int, sh_K: int, v_coeffs, v_sh0, v_shN) -> None:
+def _rebuild_hip(gathered: Tensor, means: Tensor, N: int, w: int, sh_degree: int, sh_K: int, v_coeffs, v_sh0, v_shN, skip_view: int = -1,
+                 packed_capacity: Optional[int] = None) -> None:
     from . import _lib
     from ._ops import _ptr, _stream
 
@@ -319,6 +385,14 @@ def _rebuild_hip(gathered: Tensor, means: Tensor, N: int, w: int, sh_degree: int
         p0, s0, pN, sN = v_coeffs, 3 * sh_K, v_coeffs.view(-1)[3:], 3 * sh_K
     else:
         p0, s0, pN, sN = v_sh0, 3, v_shN, 3 * (sh_K - 1)
+    if packed_capacity is not None:
+        _lib.run("dnsplat_sh_grads_from_packed", _lib.lib().dnsplat_sh_grads_from_packed, N, int(packed_capacity), w, int(skip_view),
+                 _ptr(gathered), _ptr(means.contiguous()), sh_degree, sh_K, 1.0 / w, _ptr(p0), s0, _ptr(pN), sN, _stream())
+        return
+    if skip_view >= 0:
+        _lib.run("dnsplat_sh_grads_add_factors", _lib.lib().dnsplat_sh_grads_add_factors, N, w, int(skip_view), _ptr(gathered),
+                 _ptr(means.contiguous()), sh_degree, sh_K, 1.0 / w, _ptr(p0), s0, _ptr(pN), sN, _stream())
+        return
     _lib.run("dnsplat_sh_grads_from_factors", _lib.lib().dnsplat_sh_grads_from_factors, N, w, _ptr(gathered), _ptr(means.contiguous()),
              sh_degree, sh_K, 1.0 / w, _ptr(p0), s0, _ptr(pN), sN, _stream())
 
@@ -365,6 +439,10 @@ def init_from_env(device_type: Optional[str] = None):
 
 def world_size(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank_of(group=None) -> int:
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
 
 
 def _collectives_on(group=None) -> bool:
@@ -432,6 +510,7 @@ def allreduce_gradients(params: Dict[str, Tensor], arena: Optional[GradArena] = 
         return 0
     grads = [params[k].grad for k in GRAD_KEYS]
     if arena is not None and all(arena.holds(g) for g in grads):
+        arena.invalidate_sh_state()          # rows culled on this rank receive the other ranks' gradients
         allreduce_mean_(arena.flat, group)
         return arena.bytes()
     present = [g for g in grads if g is not None]

@@ -100,7 +100,7 @@ def render_dn_outputs(
     camera_to_world: Tensor,  # [3,4] nerfstudio (OpenGL) c2w on the GPU
     fx: float, fy: float, cx: float, cy: float, width: int, height: int, sh_degree: int, background_rgb: Tensor,
     near_plane: float = 0.01, far_plane: float = 1e10, eps2d: float = 0.3, absgrad: bool = True,
-    pair_counters: Optional[Tensor] = None,
+    pair_counters: Optional[Tensor] = None, sigmoid_colors: bool = False,
 ) -> Tuple[Dict[str, Tensor], Dict]:
     """The whole replaced part of ``get_outputs`` (classic mode, predict_normals=True) in six launches:
     camera prepare, fused projection, binning, compositing with the dn-splatter epilogue, depth fill +
@@ -110,7 +110,7 @@ def render_dn_outputs(
     viewmat, K, nf, flag = _ops.camera_prepare(camera_to_world, fx, fy, cx, cy, with_flag=True, n_depth_max=1)
     outs, info = _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest, viewmat[None], K[None], nf[None],
                                   [(fx, fy, cx, cy)], width, height, sh_degree, background_rgb, near_plane, far_plane, eps2d,
-                                  absgrad, pair_counters, flag)
+                                  absgrad, pair_counters, flag, sigmoid_colors=sigmoid_colors)
     # squeeze, not [0]: the backward of a select would zero-fill a full-size gradient and copy the slice into it (a fill + a copy
     # kernel per output image, ~60 us per frame at 1080p); the backward of a squeeze is a view
     return {k: v.squeeze(0) for k, v in outs.items()}, info
@@ -119,7 +119,7 @@ def render_dn_outputs(
 def render_dn_outputs_batch(
     means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, features_dc: Tensor, features_rest: Tensor,
     cameras, width: int, height: int, sh_degree: int, background_rgb: Tensor,
-    near_plane: float = 0.01, far_plane: float = 1e10, eps2d: float = 0.3, absgrad: bool = True,
+    near_plane: float = 0.01, far_plane: float = 1e10, eps2d: float = 0.3, absgrad: bool = True, sigmoid_colors: bool = False,
 ) -> Tuple[Dict[str, Tensor], Dict]:
     """``render_dn_outputs`` for C cameras (records with camera_to_worlds [1,3,4], fx, fy, cx, cy; one image size) in ONE
     binning pass and ONE compositing launch: outputs are [C,H,W,.] stacks whose slices equal the
@@ -127,20 +127,27 @@ def render_dn_outputs_batch(
     viewmats, Ks, nfs, flag = _ops.camera_prepare_batch(cameras, with_flag=True)
     intr = [(float(c.fx), float(c.fy), float(c.cx), float(c.cy)) for c in cameras]
     return _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest, viewmats, Ks, nfs, intr, width, height,
-                            sh_degree, background_rgb, near_plane, far_plane, eps2d, absgrad, None, flag)
+                            sh_degree, background_rgb, near_plane, far_plane, eps2d, absgrad, None, flag, sigmoid_colors=sigmoid_colors)
 
 
 def _render_dn_batch(means, quats, scales, opacities, features_dc, features_rest, viewmats, Ks, nfs, intr, width, height,
-                     sh_degree, background_rgb, near_plane, far_plane, eps2d, absgrad, pair_counters, saturation_flag=None):
+                     sh_degree, background_rgb, near_plane, far_plane, eps2d, absgrad, pair_counters, saturation_flag=None,
+                     sigmoid_colors=False):
     N = means.shape[0]
     C = viewmats.shape[0]
+    # sigmoid_colors: the config.sh_degree == 0 branch of get_outputs (dn_model.py:491-493) — colours = sigmoid(features_dc), no SH
+    # evaluation (sh_degree = None for gsplat); the sigmoid and its backward run inside the projection kernels
     cfg = ProjCfg(width=width, height=height, tile_size=16, eps2d=eps2d, near_plane=near_plane, far_plane=far_plane,
-                  antialiased=False, scales_are_log=True, opacities_are_logit=True, sh_degree=int(sh_degree),
-                  with_depth=True, with_normals=True, want_normals_world=True, tight_tiles=_ops.TIGHT_TILES,
-                  split_colours=_ops.SPLIT_COLOURS)
+                  antialiased=False, scales_are_log=True, opacities_are_logit=True, sh_degree=-1 if sigmoid_colors else int(sh_degree),
+                  colors_are_logit=bool(sigmoid_colors), with_depth=True, with_normals=True, want_normals_world=True,
+                  tight_tiles=_ops.TIGHT_TILES, split_colours=_ops.SPLIT_COLOURS, skip_culled_records=_ops.SKIP_CULLED_RECORDS)
     side: Dict = {}
-    pr = _ops.project(means, quats, scales, opacities.reshape(N), sh0=features_dc, shN=features_rest, viewmat=viewmats,
-                      K=Ks, normal_frame=nfs, cfg=cfg, saturation_flag=saturation_flag, side=side)
+    if sigmoid_colors:
+        pr = _ops.project(means, quats, scales, opacities.reshape(N), colors=features_dc.reshape(N, 3), viewmat=viewmats,
+                          K=Ks, normal_frame=nfs, cfg=cfg, saturation_flag=saturation_flag, side=side)
+    else:
+        pr = _ops.project(means, quats, scales, opacities.reshape(N), sh0=features_dc, shN=features_rest, viewmat=viewmats,
+                          K=Ks, normal_frame=nfs, cfg=cfg, saturation_flag=saturation_flag, side=side)
     # the tile lists of this path are internal: tight tile boxes; the projection's "some visible opacity > 0.999" word
     holder: Dict = {"saturation_flag": saturation_flag, "colours_ready": side.get("colours_ready")}
     if pair_counters is not None:

@@ -138,7 +138,7 @@ class DNSplatterRenderer:
         gauss_params["normals"]) is left as after the LAST camera, as a sequential loop would leave it."""
         gp = self.gauss_params
         cfg = self.config
-        fused_ok = (self.fused and self.fused_postops and cfg.sh_degree > 0 and cfg.predict_normals and cfg.rasterize_mode == "classic")
+        fused_ok = (self.fused and self.fused_postops and cfg.sh_degree >= 0 and cfg.predict_normals and cfg.rasterize_mode == "classic")
         same = all((int(c.width), int(c.height)) == (int(cameras[0].width), int(cameras[0].height)) for c in cameras)
         if not (fused_ok and same) or len(cameras) == 1:
             was_training, self.training = self.training, False
@@ -154,7 +154,7 @@ class DNSplatterRenderer:
             chunk = cameras[i:i + max_batch]
             out, info = _fused.render_dn_outputs_batch(
                 gp["means"], gp["quats"], gp["scales"], gp["opacities"], gp["features_dc"], gp["features_rest"], chunk, W, H,
-                sh_degree=self._sh_degree_to_use(), background_rgb=background, absgrad=False)
+                sh_degree=self._sh_degree_to_use(), background_rgb=background, absgrad=False, sigmoid_colors=(cfg.sh_degree == 0))
             for c in range(len(chunk)):
                 d = {k: v[c] for k, v in out.items()}
                 d["background"] = background
@@ -191,13 +191,14 @@ class DNSplatterRenderer:
         means, scales, quats = gp["means"], gp["scales"], gp["quats"]
         features_dc, features_rest, opacities = gp["features_dc"], gp["features_rest"], gp["opacities"]
 
-        if (self.fused and self.fused_postops and cfg.sh_degree > 0 and cfg.predict_normals
+        if (self.fused and self.fused_postops and cfg.sh_degree >= 0 and cfg.predict_normals
                 and cfg.rasterize_mode == "classic"):
-            # everything between the parameters and the output dict in HIP
+            # everything between the parameters and the output dict in HIP; config.sh_degree == 0
+            # (dn_model.py:486-493: sigmoid(colours), no SH) is the same pass with the sigmoid inside the projection kernels
             out, info = _fused.render_dn_outputs(
                 means, quats, scales, opacities, features_dc, features_rest, c2w[0], float(camera.fx), float(camera.fy),
                 float(camera.cx), float(camera.cy), W, H, sh_degree=self._sh_degree_to_use(), background_rgb=background,
-                absgrad=True)
+                absgrad=True, sigmoid_colors=(cfg.sh_degree == 0))
             gp["normals"] = info["normals_world"]          # dn_model.py:558
             if self.training and info["means2d"].requires_grad:
                 info["means2d"].retain_grad()              # dn_model.py:517-518

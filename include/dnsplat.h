@@ -478,10 +478,10 @@ typedef struct dnsplat_proj_grads {
                                     leaves the word describing what memory holds afterwards (culled rows: zero).  Contract: nobody else
                                     writes non-zero values into those rows without clearing the words (dp.GradArena.invalidate_sh_state).
                                     Ignored with sh_grads_skip. */
-    float *sh_packed;            /* ABI 14.  NULL, or the packed slab of this camera (see dnsplat_visible_index): the colour gradients of
-                                    the VISIBLE Gaussians only, row block_offsets[g / 64] + popcount(mask word below bit g % 64); written
-                                    instead of / beside sh_factors.  Needs sh_packed_index. */
-    const void *sh_packed_index; /* the slab header dnsplat_visible_index wrote for the same radii */
+    float *sh_packed;            /* ABI 14.  NULL, or this camera's PACKED slab, whose header / masks / offsets dnsplat_visible_index wrote for
+                                    the same radii (see there): the launch fills its rows — the colour gradients of the VISIBLE Gaussians
+                                    only, row offsets[g / 64] + popcount(mask bits below g % 64) — beside or instead of sh_factors.  Whole
+                                    scenes only (the slices of dp.SlicedShExchange keep dense slabs). */
 } dnsplat_proj_grads;
 
 int dnsplat_project_bwd(const dnsplat_scene *scene, const dnsplat_camera *cam,

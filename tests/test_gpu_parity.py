@@ -308,8 +308,8 @@ def _check_mirror(hip, ora, keep, what="mirror", quat_atol=0.0, ints=True):
         return fp64_envelope(g32, g64[name]) if g64 is not None and g64.get(name) is not None else None
 
     for k in GRAD_NAMES:
-        if p_o[k].grad is None:           # e.g. the inactive SH bands' tensor when sh_degree == 0 feeds sigmoid(colours)
-            assert p_g[k].grad is None or float(p_g[k].grad.abs().max()) == 0.0, k
+        if p_o[k].grad is None or p_o[k].grad.numel() == 0:   # e.g. the (empty) higher-band tensor when sh_degree == 0 feeds sigmoid(colours)
+            assert p_g[k].grad is None or p_g[k].grad.numel() == 0 or float(p_g[k].grad.abs().max()) == 0.0, k
             continue
         if k == "features_rest" and p_o[k].grad.dim() == 3 and p_o[k].grad.shape[1] == 15:
             # band by band: each SH band against its own scale
@@ -938,7 +938,7 @@ def test_sh_factor_exchange_rebuilds_the_multi_camera_gradient(dns, layout, defe
         return gp, sh
 
     dense = [one(c, None) for c in cams]
-    ex = dp.ShFactorExchange()
+    ex = dp.ShFactorExchange(own_rows=False)      # the rebuild-every-row form (what runs at world >= 2)
     ex.deferred = deferred
     if layout == "cat":
         # gsplat's concatenated [N,16,3] layout: its gradient is an intermediate autograd tensor that dp.allreduce_gradients
@@ -987,8 +987,143 @@ def test_sh_factor_exchange_rebuilds_the_multi_camera_gradient(dns, layout, defe
     if layout == "split":
         assert_close(gp_1["features_rest"].grad, dense[0][0]["features_rest"].grad, "single-rank exchange", 1e-6)
         assert_close(gp_1["features_dc"].grad, dense[0][0]["features_dc"].grad, "single-rank exchange dc", 1e-6)
+        # the default exchange at world 1: own rows — dnsplat_project_bwd writes the complete rows, finish() launches nothing
+        ex1 = dp.ShFactorExchange()
+        ex1.deferred = deferred
+        gp_2, _ = one(cams[0], ex1)
+        assert ex1.use_own_rows() and ex1.finish(v_sh0=gp_2["features_dc"].grad, v_shN=gp_2["features_rest"].grad) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(gp_2["features_rest"].grad, dense[0][0]["features_rest"].grad), "own rows at world 1 != the single-GPU rows"
+        assert torch.equal(gp_2["features_dc"].grad, dense[0][0]["features_dc"].grad)
     else:
         assert_close(sh_1.grad, dense[0][1].grad, "single-rank exchange", 1e-6)
+
+
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.usefixtures("hip_deterministic")
+def test_own_rows_and_visible_row_slabs_equal_the_dense_mean(dns, packed):
+    """(a) own rows — each camera's coefficient rows written by its own dnsplat_project_bwd, pre-scaled by 1 / W,
+    the other W - 1 cameras ADDED from the gathered slabs (dnsplat_sh_grads_add_factors); (b) slabs of the visible rows only (mask +
+    block offsets + packed rows: dnsplat_visible_index, dnsplat_proj_grads.sh_packed, dnsplat_sh_grads_from_packed).  Three cameras
+    one after the other on one GPU stand in for three ranks; every "rank" must end with the dense mean of the three gradients."""
+    from dn_splatter_amd import _lib, _ops, dp, synthetic
+
+    N, W, H = 20_000, 320, 240
+    gp0 = synthetic.make_gauss_params(N, sh_rest_std=0.2, seed=9)
+    gp0["scales"] = gp0["scales"].detach() + torch.randn(N, 3, generator=torch.Generator().manual_seed(10)) * 0.5
+    cams = [synthetic.orbit_camera(v, width=W, height=H, focal=200.0).to(DEV) for v in (0, 2, 5)]
+    n_views = len(cams)
+
+    def one(cam, exchange):
+        gp = {k: v.detach().to(DEV).clone().requires_grad_(k != "normals") for k, v in gp0.items()}
+        dns.set_sh_exchange(exchange)
+        try:
+            m = dns.DNSplatterRenderer(gp, fused=True)
+            out = m.get_outputs(cam)
+            ((out["rgb"] * torch.linspace(0.5, 1.5, 3, device=DEV)).sum() + out["depth"].sum() + out["normal"].sum()).backward()
+        finally:
+            dns.set_sh_exchange(None)
+        torch.cuda.synchronize()
+        return gp, m
+
+    dense = [one(c, None)[0] for c in cams]
+    ref0 = sum(d["features_dc"].grad for d in dense) / n_views
+    refN = sum(d["features_rest"].grad for d in dense) / n_views
+    n_vis = []
+    cap = None
+    if packed:
+        n_vis = [int((one(c, None)[1].radii > 0).sum()) for c in cams]
+        cap = (max(n_vis) + 1023) // 1024 * 1024
+        assert cap < N                                  # the slabs are smaller than dense ones
+    ex = dp.ShFactorExchange(own_rows=True, packed=packed, capacity=cap)
+    ex.scale_override = 1.0 / n_views
+    own, slabs = [], []
+    for c in cams:
+        gp_f, m_f = one(c, ex)
+        assert ex.meta is not None
+        slabs.append(ex.mine.clone())
+        ex.meta = None
+        own.append((gp_f["features_dc"].grad.clone(), gp_f["features_rest"].grad.clone()))
+    fac = torch.stack(slabs).contiguous()
+    if packed:
+        assert fac.shape[1] == _lib.lib().dnsplat_packed_slab_floats(N, cap) < 3 * N + 4
+        hdr = fac.view(torch.int32)[:, :8].cpu()
+        assert hdr[:, 0].tolist() == n_vis and hdr[:, 4].tolist() == [cap] * n_views and not ex.overflowed()
+    means_dev = gp0["means"].detach().to(DEV).contiguous()
+    for r in range(n_views):                            # "rank" r: its own pre-scaled rows + the others' slabs
+        # own rows, pre-scaled: exactly the single-GPU rows x 1 / W
+        assert_close(own[r][1], dense[r]["features_rest"].grad / n_views, f"rank {r}: own pre-scaled rows", 1e-6)
+        v0, vN = own[r][0].clone(), own[r][1].clone()
+        dp._rebuild_hip(fac, means_dev, N, n_views, 3, 16, None, v0, vN, skip_view=r, packed_capacity=cap)
+        torch.cuda.synchronize()
+        assert_close(v0, ref0, f"rank {r}: own rows + added slabs, band 0", 1e-5)
+        assert_close(vN, refN, f"rank {r}: own rows + added slabs, bands 1..3", 1e-5)
+    if packed:
+        # rebuild-every-row form over packed slabs
+        v0 = torch.full((N, 3), float("nan"), device=DEV)
+        vN = torch.full((N, 15, 3), float("nan"), device=DEV)
+        dp._rebuild_hip(fac, means_dev, N, n_views, 3, 16, None, v0, vN, skip_view=-1, packed_capacity=cap)
+        torch.cuda.synchronize()
+        assert_close(v0, ref0, "packed slabs, every row rebuilt, band 0", 1e-5)
+        assert_close(vN, refN, "packed slabs, every row rebuilt", 1e-5)
+        # a capacity below the visible count is REPORTED (rows beyond it are dropped by the sender)
+        ex_small = dp.ShFactorExchange(own_rows=False, packed=True, capacity=1024)
+        one(cams[0], ex_small)
+        ex_small.gathered = ex_small.mine.clone()[None]
+        assert ex_small.overflowed()
+        ex_small.meta = None
+
+
+@pytest.mark.usefixtures("hip_deterministic")
+def test_zero_rows_of_persistently_culled_gaussians_are_not_rewritten_and_stay_exact(dns):
+    """with the gradients in a dp.GradArena the projection backward skips the zero SH rows of Gaussians that
+    were culled before and are culled again (dnsplat_proj_grads.sh_zero_state).  A pose sequence in which Gaussians enter and leave
+    the frustum must give, frame by frame, the bits of the run without the bucket — in particular a Gaussian visible in frame k
+    and hidden in frame k + 1 gets ZERO gradient in frame k + 1 — and the state words must describe memory after every frame."""
+    from dn_splatter_amd import dp, synthetic
+
+    N, W, H = 30_000, 320, 240
+    gp = synthetic.make_gauss_params(N, sh_rest_std=0.2, seed=6, device=DEV)
+    cams = [synthetic.orbit_camera(v, width=W, height=H, focal=260.0).to(DEV) for v in (0, 3, 0, 5, 3)]
+    m = dns.DNSplatterRenderer(gp, fused=True)
+
+    def frame(cam):
+        for k in GRAD_NAMES:
+            gp[k].grad = None
+        out = m.get_outputs(cam)
+        (out["rgb"].sum() + out["depth"].sum() + out["normal"].sum()).backward()
+        torch.cuda.synchronize()
+        return {k: gp[k].grad.clone() for k in GRAD_NAMES}, m.radii.clone()
+
+    plain = [frame(c) for c in cams]
+    arena = dp.GradArena(gp)
+    assert arena.sh_state is not None and bool((arena.sh_state == -1).all())       # zero-filled bucket: every row known zero
+    dns.set_grad_arena(arena)
+    try:
+        seen = torch.zeros(N, dtype=torch.bool, device=DEV)
+        for i, c in enumerate(cams):
+            g, radii = frame(c)
+            assert arena.holds(gp["features_rest"].grad)
+            for k in GRAD_NAMES:
+                assert torch.equal(g[k], plain[i][0][k]), f"frame {i}: {k} differs from the run without the bucket"
+            vis = radii > 0
+            hidden_now = seen & ~vis
+            assert int(hidden_now.sum()) > 0 or i == 0
+            assert float(g["features_rest"][~vis].abs().max()) == 0.0 and float(g["features_dc"][~vis].abs().max()) == 0.0
+            seen |= vis
+            bits = torch.zeros(arena.sh_state.numel() * 64, dtype=torch.bool, device=DEV)
+            words = arena.sh_state.clone()
+            for b in range(64):
+                bits[b::64] = ((words >> b) & 1).bool()
+            assert torch.equal(bits[:N], ~vis), f"frame {i}: sh_zero_state does not describe the bucket"
+        # an in-place all-reduce of the bucket (or any foreign write) must be followed by invalidate_sh_state(): after it every row is
+        # written again
+        arena.view("features_rest").fill_(7.0)
+        arena.invalidate_sh_state()
+        g, radii = frame(cams[1])
+        assert torch.equal(g["features_rest"], plain[1][0]["features_rest"])
+    finally:
+        dns.set_grad_arena(None)
 
 
 @pytest.mark.parametrize("n_views,sh_degree", [(8, 3), (4, 2), (2, 1)])
