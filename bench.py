@@ -519,6 +519,16 @@ def main():
                          "waits for it in the steady state (verified as soon as it has arrived, an overflow raises)")
     ap.add_argument("--dense-allreduce", action="store_true",
                     help="all-reduce the full 236 B/Gaussian bucket instead of exchanging the SH gradients as factors")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rebuild", "own", "packed", "own+packed"],
+                    help="N > 1 ranks (or DNSPLAT_FORCE_DIST=1), the SH part of the exchange step (dp.ShFactorExchange): 'auto' = own-camera "
+                         "rows at world 1 (nothing to rebuild), every row rebuilt from dense slabs at world > 1; 'rebuild' = every row rebuilt at "
+                         "any world size (round 5); 'packed' = slabs of the visible rows only (84 -> ~61 B / Gaussian received at 8 GPUs; "
+                         "+0.03 / +0.13 ms of kernels at C2 / C5 on one rank, profiles/r06_exchange_single_rank_rccl.txt); 'own' / "
+                         "'own+packed' force own-camera rows at any world size")
+    ap.add_argument("--reduction", default="sum", choices=["sum", "mean"],
+                    help="N > 1 ranks: 'sum' = every rank scales its image cotangents by 1 / world and the collectives ADD (dp.set_reduction: "
+                         "RCCL's AVG is pre-multiply + sum, which on one rank still runs a kernel over the whole bucket prefix); 'mean' = "
+                         "unscaled cotangents, averaging collectives (round 5)")
     ap.add_argument("--slices", type=int, default=1,
                     help="N > 1 ranks (or DNSPLAT_FORCE_DIST=1): the projection backward as this many slices of Gaussians, slice k's "
                          "colour-gradient slab all-gathered while slices k+1.. compute (dp.SlicedShExchange); 1 (default) = one launch, "
@@ -598,11 +608,21 @@ def main():
     dns.set_grad_arena(arena)
     exchange = None
     if (world > 1 or os.environ.get("DNSPLAT_FORCE_DIST", "0") == "1") and not args.dense_allreduce and not args.two_call:
-        exchange = dp.SlicedShExchange(args.slices) if args.slices > 1 else dp.ShFactorExchange()
+        if args.slices > 1:
+            exchange = dp.SlicedShExchange(args.slices)
+        else:
+            mode = args.exchange
+            own = {"auto": None, "rebuild": False, "own": True, "packed": False, "own+packed": True}[mode]
+            packed = mode in ("packed", "own+packed")
+            exchange = dp.ShFactorExchange(own_rows=own, packed=packed)
         dns.set_sh_exchange(exchange)
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
     shapes = {"rgb": (H, W, 3), "depth": (H, W, 1), "normal": (H, W, 3), "accumulation": (H, W, 1)}
     cot = {k: torch.rand(shapes[k], device=dev, generator=gen) * 2 - 1 for k in OUT_KEYS}
+    if exchange is not None or world > 1:
+        dp.set_reduction(args.reduction)
+        if args.reduction == "sum" and world > 1:
+            cot = {k: v / world for k, v in cot.items()}      # the loss of a data-parallel step is the mean over the ranks' cameras
 
     batch = None
     if args.losses:
@@ -617,17 +637,31 @@ def main():
             gp[k].grad = None
         out = renderer.get_outputs(cam)
         if batch is not None and args.losses == "fused":
-            fused_loss.dn_loss_fused(out, batch, gp["scales"], counts=loss_counts).backward()
+            loss = fused_loss.dn_loss_fused(out, batch, gp["scales"], counts=loss_counts)
+            (loss * loss_scale if loss_scale != 1.0 else loss).backward()
         elif batch is not None:
-            torch_losses.dn_loss(out, batch, gp["scales"], capturable=(args.losses == "torch_capturable")).backward()
+            loss = torch_losses.dn_loss(out, batch, gp["scales"], capturable=(args.losses == "torch_capturable"))
+            (loss * loss_scale if loss_scale != 1.0 else loss).backward()
         else:
             # the losses stay in PyTorch (north star); their result is a dense cotangent per output image
             torch.autograd.backward([out[k] for k in OUT_KEYS], [cot[k] for k in OUT_KEYS])
         return dp.allreduce_gradients(gp, arena, exchange=exchange)
 
+    # "sum" reduction: the step's loss is the MEAN over the ranks' cameras, so every rank scales its own by 1 / world
+    loss_scale = (1.0 / world) if (world > 1 and dp.REDUCTION["mode"] == "sum") else 1.0
     step_eager = step
     for _ in range(FIRST_TOUCH_STEPS):     # allocations, capacity guesses, code objects (the W warm-up steps come right before the timed region)
         step()
+    if exchange is not None and getattr(exchange, "packed", False):
+        # slabs of visible rows only: every rank's capacity = 1.1 x the largest visible count of the ranks' cameras (one host sync and
+        # one tiny collective, here, outside every timed region); a step that overflowed it anyway falls back to dense slabs
+        exchange.calibrate(renderer.radii)
+        step(); step()
+        torch.cuda.synchronize()
+        if dp.max_over_ranks(float(exchange.overflowed()), dev) > 0:
+            exchange.packed = False
+            exchange.mine = exchange.gathered = None
+            step()
     # Stage breakdown: PROBE_STEPS fully instrumented steps OUTSIDE the timed region.  Bracketing all six stages with
     # HIP events costs ~80 us of stream time per frame (a ~6 us bubble per event pair, seen in the rocprofv3 timeline),
     # so the timed region below only brackets the dominant stage, whose live duration the roofline figure needs.
@@ -975,6 +1009,15 @@ def main():
                  "single_gpu_graphed_step_ms": (round(t_single, 4) if t_single is not None else None),
                  "exchange_exposed_vs_single_gpu_step_ms": (round(t_step - t_single, 4) if t_single is not None else None),
                  "exchange_slices": getattr(exchange, "slices", 1) if exchange is not None else None,
+                 "reduction": dp.REDUCTION["mode"] + (" (cotangents pre-scaled by 1 / world, collectives add)" if dp.REDUCTION["mode"] == "sum" else ""),
+                 "exchange_sh_rows": (None if exchange is None else
+                                      ("own camera's rows written by dnsplat_project_bwd (x 1/W), the other W-1 added from the slabs"
+                                       if exchange.use_own_rows() else "every row rebuilt from the W gathered slabs")),
+                 "exchange_slabs": (None if exchange is None else
+                                    (f"packed: mask + block offsets + the colour gradients of the visible Gaussians only, capacity "
+                                     f"{exchange.packed_capacity(N)} of {N} rows" if getattr(exchange, "packed", False)
+                                     else "dense: 12 B per Gaussian")),
+                 "slab_bytes_per_rank": (None if exchange is None or getattr(exchange, "slices", 1) > 1 else int(exchange.slab_floats(N) * 4)),
                  "launch": (("everything up to the projection backward = one HIP graph replay per step; its K slice launches, each "
                              "followed by the all-gather of its slab, the geometry all-reduce and the rebuilds issued eagerly behind it "
                              "(graph.GraphedDpStep + dp.SlicedShExchange)") if (gdp is not None and gdp.sliced)

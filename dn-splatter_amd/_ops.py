@@ -574,7 +574,7 @@ class _ProjectFn(torch.autograd.Function):
                 if own:
                     # this camera's rows as on a single GPU, pre-scaled by 1 / world; the exchange adds the other cameras' shares
                     from . import dp as _dp
-                    g.sh_grad_scale = ex.scale_override if ex.scale_override is not None else 1.0 / _dp.world_size(ex.group)
+                    g.sh_grad_scale = ex.scale_override if ex.scale_override is not None else _dp.reduction_scale(_dp.world_size(ex.group))
                 else:
                     g.sh_grads_skip = 1
             elif (ex is None and GRAD_ARENA is not None and GRAD_ARENA.sh_state is not None and ctx.layout == "split" and sh_K == 16

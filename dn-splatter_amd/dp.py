@@ -27,6 +27,23 @@ from torch import Tensor
 GRAD_KEYS = ("means", "scales", "quats", "opacities", "features_dc", "features_rest")
 GEOMETRY_KEYS = GRAD_KEYS[:4]
 
+# "mean": the collectives average (DDP semantics; RCCL's AVG).  "sum": they add, and the CALLER has scaled its loss (its image
+# cotangents) by 1 / world_size — the same numbers up to rounding, but nothing in the exchange step multiplies by 1 / W any more: RCCL
+# implements AVG as pre-multiply + sum, which on ONE rank still runs a kernel over the whole 44 B / Gaussian prefix (oneRankReduce:
+# 0.32 ms at 5 M Gaussians, profiles/r06_frame_timeline_single_rank_rccl_c5_*.txt), where a one-rank in-place SUM is nothing at all.
+REDUCTION = {"mode": "mean"}
+
+
+def set_reduction(mode: str) -> None:
+    if mode not in ("mean", "sum"):
+        raise ValueError(mode)
+    REDUCTION["mode"] = mode
+
+
+def reduction_scale(w: int) -> float:
+    """What a rank's own contribution is multiplied by inside the exchange step (own-camera SH rows, rebuilt rows)."""
+    return 1.0 / w if REDUCTION["mode"] == "mean" else 1.0
+
 
 class GradArena:
     """One flat fp32 buffer holding the gradients of all optimised tensors of a Gaussian set.
@@ -230,12 +247,14 @@ class ShFactorExchange:
         else:
             buf.copy_(self.mine[None])
         self.meta = None
+        extra = {} if REDUCTION["mode"] == "mean" else {"scale": 1.0}
         if own or self.packed:
             if not (own and w == 1):      # a single view whose rows are already in place: nothing to add
                 self._rebuild(buf, self.means, N, w, sh_degree, sh_K, v_coeffs, v_sh0, v_shN,
-                              skip_view=(rank_of(group) if own else -1), packed_capacity=(self.packed_capacity(N) if self.packed else None))
+                              skip_view=(rank_of(group) if own else -1), packed_capacity=(self.packed_capacity(N) if self.packed else None),
+                              **extra)
         else:
-            self._rebuild(buf, self.means, N, w, sh_degree, sh_K, v_coeffs, v_sh0, v_shN)
+            self._rebuild(buf, self.means, N, w, sh_degree, sh_K, v_coeffs, v_sh0, v_shN, **extra)
         return (w - 1) * self.slab_floats(N) * 4
 
 
@@ -324,7 +343,8 @@ class SlicedShExchange(ShFactorExchange):
         N, sh_degree, sh_K = self.meta
         g0, g1 = self.bounds[k]
         if g1 > g0:
-            self._rebuild(self._gathered(k, w), self.means[g0:g1], g1 - g0, w, sh_degree, sh_K, None, v_sh0[g0:g1], v_shN[g0:g1])
+            extra = {} if REDUCTION["mode"] == "mean" else {"scale": 1.0}
+            self._rebuild(self._gathered(k, w), self.means[g0:g1], g1 - g0, w, sh_degree, sh_K, None, v_sh0[g0:g1], v_shN[g0:g1], **extra)
 
     def finish(self, group=None, v_coeffs: Optional[Tensor] = None, v_sh0: Optional[Tensor] = None,
                v_shN: Optional[Tensor] = None) -> int:
@@ -377,9 +397,11 @@ class SlicedShExchange(ShFactorExchange):
 
 
 def _rebuild_hip(gathered: Tensor, means: Tensor, N: int, w: int, sh_degree: int, sh_K: int, v_coeffs, v_sh0, v_shN, skip_view: int = -1,
-                 packed_capacity: Optional[int] = None) -> None:
+                 packed_capacity: Optional[int] = None, scale: Optional[float] = None) -> None:
     from . import _lib
     from ._ops import _ptr, _stream
+
+    scale = 1.0 / w if scale is None else float(scale)
 
     if v_coeffs is not None:      # gsplat layout [N,16,3]
         p0, s0, pN, sN = v_coeffs, 3 * sh_K, v_coeffs.view(-1)[3:], 3 * sh_K
@@ -387,14 +409,14 @@ def _rebuild_hip(gathered: Tensor, means: Tensor, N: int, w: int, sh_degree: int
         p0, s0, pN, sN = v_sh0, 3, v_shN, 3 * (sh_K - 1)
     if packed_capacity is not None:
         _lib.run("dnsplat_sh_grads_from_packed", _lib.lib().dnsplat_sh_grads_from_packed, N, int(packed_capacity), w, int(skip_view),
-                 _ptr(gathered), _ptr(means.contiguous()), sh_degree, sh_K, 1.0 / w, _ptr(p0), s0, _ptr(pN), sN, _stream())
+                 _ptr(gathered), _ptr(means.contiguous()), sh_degree, sh_K, scale, _ptr(p0), s0, _ptr(pN), sN, _stream())
         return
     if skip_view >= 0:
         _lib.run("dnsplat_sh_grads_add_factors", _lib.lib().dnsplat_sh_grads_add_factors, N, w, int(skip_view), _ptr(gathered),
-                 _ptr(means.contiguous()), sh_degree, sh_K, 1.0 / w, _ptr(p0), s0, _ptr(pN), sN, _stream())
+                 _ptr(means.contiguous()), sh_degree, sh_K, scale, _ptr(p0), s0, _ptr(pN), sN, _stream())
         return
     _lib.run("dnsplat_sh_grads_from_factors", _lib.lib().dnsplat_sh_grads_from_factors, N, w, _ptr(gathered), _ptr(means.contiguous()),
-             sh_degree, sh_K, 1.0 / w, _ptr(p0), s0, _ptr(pN), sN, _stream())
+             sh_degree, sh_K, scale, _ptr(p0), s0, _ptr(pN), sN, _stream())
 
 
 ShFactorExchange._rebuild = staticmethod(_rebuild_hip)   # the CPU gloo test swaps in a torch reference
@@ -467,10 +489,14 @@ class _MeanWork:
 
 
 def allreduce_mean_(t: Tensor, group=None, async_op: bool = False):
-    """In-place mean over ranks.  With ``async_op`` the collective is only enqueued; call ``wait()`` on the result."""
+    """In-place mean over ranks (REDUCTION "sum": in-place sum — the caller scaled its loss by 1 / world).  With ``async_op`` the
+    collective is only enqueued; call ``wait()`` on the result."""
     w = world_size(group)
     if not _collectives_on(group):
         return _MeanWork(None, None, 1.0) if async_op else None
+    if REDUCTION["mode"] == "sum":
+        work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return _MeanWork(work, None, 1.0) if async_op else work
     if t.is_cuda:
         work = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
         return _MeanWork(work, None, 1.0) if async_op else work

@@ -50,7 +50,7 @@ def make_rebuild_ref(dense_ref):
     """The stand-in the gloo tests install as ``dp.ShFactorExchange._rebuild``: autograd through the oracle's dense SH evaluation,
     summed over the views; ``skip_view >= 0`` ADDS the other views to rows that hold that view's pre-scaled share."""
 
-    def rebuild_ref(gathered, means_, n, w, deg, K, v_coeffs, v_sh0, v_shN, skip_view=-1, packed_capacity=None):
+    def rebuild_ref(gathered, means_, n, w, deg, K, v_coeffs, v_sh0, v_shN, skip_view=-1, packed_capacity=None, scale=None):
         tot = torch.zeros(n, K, 3)
         for v in range(w):
             if v == skip_view:
@@ -62,7 +62,7 @@ def make_rebuild_ref(dense_ref):
             co = torch.zeros(n, K, 3, requires_grad=True)
             (dense_ref.sh_colors(deg, torch.nn.functional.normalize(means_ - pos_v, dim=-1), co) * cols_v).sum().backward()
             tot += co.grad
-        tot /= w
+        tot *= (1.0 / w) if scale is None else scale
         if skip_view >= 0:
             v_sh0.add_(tot[:, 0])
             v_shN.add_(tot[:, 1:])
