@@ -14,6 +14,7 @@ with the renderer; nothing here is a kernel of ours.  It follows
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -44,6 +45,83 @@ def ssim(pred: Tensor, gt: Tensor, data_range: float = 1.0) -> Tensor:
     sxx = blur(x * x) - mu_x * mu_x
     syy = blur(y * y) - mu_y * mu_y
     sxy = blur(x * y) - mu_x * mu_y
+    cs = (2 * sxy + c2) / (sxx + syy + c2)
+    s = ((2 * mu_x * mu_y + c1) / (mu_x * mu_x + mu_y * mu_y + c1)) * cs
+    return s.mean()
+
+
+_TOEPLITZ: Dict = {}
+SSIM_GEMM_BLOCK = int(os.environ.get("DNSPLAT_SSIM_GEMM_BLOCK", "64"))
+SSIM_FAST_IMPL = os.environ.get("DNSPLAT_SSIM_IMPL", "conv")      # what dn_loss(capturable=True) uses: "conv" (ten grouped conv2d calls, the fastest measured) | "gemm" | "stacked"
+
+
+def _toeplitz(block: int, device, size: int = 11, sigma: float = 1.5) -> Tensor:
+    """[block + size - 1, block] banded matrix: column j holds the Gaussian window at rows j .. j + size - 1, so that a block of
+    ``block + size - 1`` consecutive samples times it is the VALID 11-tap blur of that block (``block`` outputs)."""
+    key = (block, str(device), size, sigma)
+    T = _TOEPLITZ.get(key)
+    if T is None:
+        w = _gaussian_window(size, sigma)
+        T = torch.zeros(block + size - 1, block)
+        for j in range(block):
+            T[j:j + size, j] = w
+        T = T.to(device)
+        _TOEPLITZ[key] = T
+    return T
+
+
+def _blur_valid_gemm(t: Tensor, block: int = 64, size: int = 11) -> Tensor:
+    """Separable 11-tap Gaussian blur (valid padding) of the last two dims of ``t`` [..., H, W] as two block-Toeplitz GEMMs: the
+    windows of ``block + 10`` samples at a stride of ``block`` are a view (``unfold``), the taps a [block + 10, block] banded matrix.
+    Same sums as conv2d with the separable window, in hipBLASLt's order.  Why not conv2d: MIOpen runs the depthwise 11 x 1 / 1 x 11
+    convolutions of a 1600 x 1200 image through general-purpose convolution kernels at ~250-500 us each, thirty of them per step
+    (profiles/r06_c5_torch_loss_kernel_stats.txt): 5.5 ms, more than the whole render step."""
+    T = _toeplitz(block, t.device, size)
+
+    def along_last(x):
+        n = x.shape[-1]
+        out = n - size + 1
+        nb = -(-out // block)
+        need = nb * block + size - 1
+        if need > n:
+            x = F.pad(x, (0, need - n))
+        y = x.unfold(-1, block + size - 1, block) @ T                  # [..., nb, block]
+        return y.reshape(*x.shape[:-1], nb * block)[..., :out]
+
+    t = along_last(t)                                                   # along W
+    return along_last(t.transpose(-1, -2)).transpose(-1, -2)            # along H
+
+
+def ssim_stacked(pred: Tensor, gt: Tensor, data_range: float = 1.0) -> Tensor:
+    """``ssim`` with the five maps (x, y, x^2, y^2, xy) stacked into ONE [1, 15, H, W] tensor: two grouped conv2d calls (and two in the
+    backward) instead of ten (and six)."""
+    x = pred.permute(2, 0, 1)
+    y = gt.permute(2, 0, 1)
+    C = x.shape[0]
+    t = torch.cat([x, y, x * x, y * y, x * y], 0)[None]
+    w = _gaussian_window(device=x.device)
+    wh = w.view(1, 1, -1, 1).repeat(5 * C, 1, 1, 1)
+    ww = w.view(1, 1, 1, -1).repeat(5 * C, 1, 1, 1)
+    b = F.conv2d(F.conv2d(t, wh, groups=5 * C), ww, groups=5 * C)[0]
+    mu_x, mu_y, bxx, byy, bxy = b[:C], b[C:2 * C], b[2 * C:3 * C], b[3 * C:4 * C], b[4 * C:]
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    cs = (2 * (bxy - mu_x * mu_y) + c2) / ((bxx - mu_x * mu_x) + (byy - mu_y * mu_y) + c2)
+    s = ((2 * mu_x * mu_y + c1) / (mu_x * mu_x + mu_y * mu_y + c1)) * cs
+    return s.mean()
+
+
+def ssim_gemm(pred: Tensor, gt: Tensor, data_range: float = 1.0) -> Tensor:
+    """``ssim`` with the five blurs (x, y, x^2, y^2, xy) stacked into one [15, H, W] tensor and run as two GEMMs (see
+    ``_blur_valid_gemm``) instead of ten grouped conv2d calls: same value and gradient up to fp32 summation order, 5x fewer kernels."""
+    x = pred.permute(2, 0, 1)
+    y = gt.permute(2, 0, 1)
+    C = x.shape[0]
+    b = _blur_valid_gemm(torch.cat([x, y, x * x, y * y, x * y], 0), block=SSIM_GEMM_BLOCK)
+    mu_x, mu_y, bxx, byy, bxy = b[:C], b[C:2 * C], b[2 * C:3 * C], b[3 * C:4 * C], b[4 * C:]
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    sxx = bxx - mu_x * mu_x
+    syy = byy - mu_y * mu_y
+    sxy = bxy - mu_x * mu_y
     cs = (2 * sxy + c2) / (sxx + syy + c2)
     s = ((2 * mu_x * mu_y + c1) / (mu_x * mu_x + mu_y * mu_y + c1)) * cs
     return s.mean()
@@ -85,12 +163,14 @@ def tv_loss(pred: Tensor) -> Tensor:
     return _dcol(pred).abs().mean() + _drow(pred).abs().mean()
 
 
-def rgb_term(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], ssim_lambda: float = 0.2) -> Tensor:
+def rgb_term(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], ssim_lambda: float = 0.2, fast: bool = False) -> Tensor:
     """nerfstudio splatfacto's main_loss, which DNSplatterModel.get_loss_dict takes over unchanged (dn_model.py:624-627, :663):
-    (1 - l) * L1 + l * (1 - SSIM).  Restated from nerfstudio / pytorch_msssim's published definitions (not vendored: unpinned)."""
+    (1 - l) * L1 + l * (1 - SSIM).  Restated from nerfstudio / pytorch_msssim's published definitions (not vendored: unpinned).
+    ``fast``: the SSIM blurs as two GEMMs (``ssim_gemm``) instead of pytorch_msssim's ten grouped conv2d calls."""
     pred_img = outputs["rgb"]
     ll1 = torch.abs(batch["image"] - pred_img).mean()
-    simloss = 1 - ssim(pred_img, batch["image"])
+    impl = {"gemm": ssim_gemm, "stacked": ssim_stacked}.get(SSIM_FAST_IMPL, ssim) if fast else ssim
+    simloss = 1 - impl(pred_img, batch["image"])
     return (1 - ssim_lambda) * ll1 + ssim_lambda * simloss
 
 
@@ -124,8 +204,10 @@ def dn_loss(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], scales: Tensor
             depth_lambda: float = 0.2, depth_tolerance: float = 0.1, use_depth_loss: bool = True,
             use_normal_loss: bool = True, capturable: bool = False) -> Tensor:
     """main_loss of ``DNSplatterModel.get_loss_dict`` for regularization_strategy == "dn-splatter" with mono depth
-    and mono normal supervision (dn_model.py:614-729): rgb_loss + regularization_strategy_loss (:727)."""
-    return rgb_term(outputs, batch, ssim_lambda) + regularization_term(outputs, batch, scales, depth_lambda, depth_tolerance,
+    and mono normal supervision (dn_model.py:614-729): rgb_loss + regularization_strategy_loss (:727).
+    ``capturable``: the same terms in PyTorch ops that need no host synchronisation and no convolution library — masked means as
+    sum / count (``edge_aware_log_l1``), SSIM blurs as GEMMs (``ssim_gemm``): the whole step can be captured into a HIP graph."""
+    return rgb_term(outputs, batch, ssim_lambda, fast=capturable) + regularization_term(outputs, batch, scales, depth_lambda, depth_tolerance,
                                                                        use_depth_loss, use_normal_loss, capturable)
 
 

@@ -339,6 +339,23 @@ def test_capturable_torch_losses_equal_the_reference_form():
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-8), float((a - b).abs().max())
 
 
+def test_ssim_as_block_toeplitz_gemms_equals_the_conv2d_form():
+    """torch_losses.ssim_gemm (what the capturable stack uses: the five 11-tap Gaussian blurs of SSIM stacked and run as two GEMMs over
+    unfolded blocks) == torch_losses.ssim (pytorch_msssim's separable conv2d form), value and gradient, at sizes below, at and beyond
+    one block and with ragged last blocks."""
+    from dn_splatter_amd import torch_losses as tl
+
+    g = torch.Generator().manual_seed(1)
+    for H, W in ((11, 11), (28, 40), (74, 75), (97, 203), (150, 139)):
+        a = torch.rand(H, W, 3, generator=g).requires_grad_(True)
+        b = torch.rand(H, W, 3, generator=g)
+        s1, s2 = tl.ssim(a, b), tl.ssim_gemm(a, b)
+        g1, = torch.autograd.grad(s1, a)
+        g2, = torch.autograd.grad(s2, a)
+        assert abs(float(s1.detach()) - float(s2.detach())) < 1e-6, (H, W)
+        assert float((g1 - g2).abs().max()) <= 2e-6 * float(g1.abs().max()), (H, W)
+
+
 def test_capacity_guesses_are_carried_over_a_refinement(dns):
     """densify.after_refinement(report=...) files the binning's capacity guesses of the old Gaussian count under the new one, scaled
     by n_new / n_old (x 1.1), instead of dropping them: the capture that follows needs no eager frames to size its buffers again.
