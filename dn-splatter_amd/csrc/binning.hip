@@ -400,13 +400,18 @@ __global__ __launch_bounds__(SC_THREADS) void radix_scan_kernel(uint32_t *__rest
 #define DNS_TI_WAVES_PER_EU 1
 #endif
 #define DNS_TI_OCCUPANCY(th, K) __attribute__((amdgpu_waves_per_eu(((th) == 512 && sizeof(K) == 2) ? DNS_TI_WAVES_PER_EU : 1, 8)))
-template <typename K, bool LAST, int DBITS, int ITEMS, bool FIRST = false, bool GEN = false, int TH = RS_THREADS>
+// BOXG (round 6: the LAST pass of the depth sort): every value is a Gaussian id whose final depth rank `dst` is known here — its tile
+// box (dnsplat_proj_out.tile_boxes: one random 8-byte record) is gathered by this kernel and left behind in depth order together with
+// the tile count, instead of by scan_sums_kernel<true> afterwards: the 3.6 M random line fetches of a 5 M-Gaussian frame (92 us as a
+// kernel of their own) travel beside the scatter's own streams.
+template <typename K, bool LAST, int DBITS, int ITEMS, bool FIRST = false, bool GEN = false, int TH = RS_THREADS, bool BOXG = false>
 __global__ __launch_bounds__(TH) DNS_TI_OCCUPANCY(TH, K) void radix_scatter_kernel(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ n_ptr, uint32_t n_cap, int shift,
     const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nb, int32_t *__restrict__ tile_first,
     const int32_t *__restrict__ radii = nullptr, const float *__restrict__ depths = nullptr,
-    int32_t *__restrict__ tile_end = nullptr, GenArgs gen = GenArgs{}, uint32_t *__restrict__ count_out = nullptr)
+    int32_t *__restrict__ tile_end = nullptr, GenArgs gen = GenArgs{}, uint32_t *__restrict__ count_out = nullptr,
+    const int2 *__restrict__ box_in = nullptr, int2 *__restrict__ box_out = nullptr, uint32_t *__restrict__ tiles_out = nullptr)
 {
     // The chunk is first sorted by digit INSIDE LDS (stable), then written out run by run: consecutive lanes
     // store to consecutive addresses of one digit's run, so the stores coalesce.  A direct scatter from the
@@ -543,6 +548,28 @@ __global__ __launch_bounds__(TH) DNS_TI_OCCUPANCY(TH, K) void radix_scatter_kern
         }
     }
     __syncthreads();
+    if constexpr (BOXG) {
+        // all gathers of a thread in flight together, then the stores (keys are not needed after the last pass)
+        uint32_t dsts[ITEMS], vs[ITEMS];
+        int2 bx[ITEMS];
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const uint32_t i = min((uint32_t)(r * TH + threadIdx.x), n_out - 1u);
+            const uint32_t d = ((uint32_t)keys_s[i] >> shift) & DMASK;
+            dsts[r] = gbase[d] + (i - dstart[d]);
+            vs[r] = vals_s[i];
+        }
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) bx[r] = box_in[vs[r]];
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r)
+            if ((uint32_t)(r * TH + threadIdx.x) < n_out) {
+                vals_out[dsts[r]] = vs[r];
+                box_out[dsts[r]] = bx[r];
+                tiles_out[dsts[r]] = ((uint32_t)bx[r].y & 0xffffu) * ((uint32_t)bx[r].y >> 16);
+            }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const uint32_t i = r * TH + threadIdx.x;
@@ -603,6 +630,22 @@ __global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(int N, const uint
                 if (BOXES) boxes_sorted[base + i] = bx[i];
             }
     }
+    uint32_t tot;
+    block_incl_scan_256(s, lds_wave, tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// scan_sums_kernel when the last depth pass has already left the counts in depth order (radix_scatter_kernel<..., BOXG>): a coalesced sum
+__global__ __launch_bounds__(SC_THREADS) void scan_sums_sorted_kernel(int N, const uint32_t *__restrict__ n_ptr,
+                                                                      const uint32_t *__restrict__ tiles_sorted, uint32_t *__restrict__ sums)
+{
+    __shared__ uint32_t lds_wave[4];
+    const int n = (int)min(*n_ptr, (uint32_t)N);
+    const int base = blockIdx.x * SC_CHUNK + threadIdx.x * SC_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SC_ITEMS; ++i)
+        if (base + i < n) s += tiles_sorted[base + i];
     uint32_t tot;
     block_incl_scan_256(s, lds_wave, tot);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
@@ -829,7 +872,8 @@ template <typename K, int ITEMS, int TH = RS_THREADS>
 void radix_pass(hipStream_t stream, const K *ka, const uint32_t *va, K *kb, uint32_t *vb, const uint32_t *n_ptr,
                 uint32_t n_cap, int shift, int dbits, uint32_t *table, uint32_t *totals, int nb, int32_t *tile_first = nullptr,
                 const int32_t *radii = nullptr, const float *depths = nullptr, int32_t *init_offsets = nullptr, int n_tiles = 0,
-                int32_t *tile_end = nullptr, const GenArgs *gen = nullptr, uint32_t *status = nullptr, uint32_t *count_out = nullptr)
+                int32_t *tile_end = nullptr, const GenArgs *gen = nullptr, uint32_t *status = nullptr, uint32_t *count_out = nullptr,
+                const int2 *box_in = nullptr, int2 *box_out = nullptr, uint32_t *tiles_out = nullptr)
 {
     const uint32_t mask = (1u << dbits) - 1u;
     if (radii) {   // first pass of the depth sort: 8-bit digit, keys synthesised from (radii, depths)
@@ -850,6 +894,14 @@ void radix_pass(hipStream_t stream, const K *ka, const uint32_t *va, K *kb, uint
         hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS, false, false, TH>), dim3(nb), dim3(TH), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb,
                            (const int32_t *)nullptr, (const float *)nullptr, init_offsets, n_tiles, init_offsets ? tile_end : nullptr, g, status);
     hipLaunchKernelGGL(radix_scan_kernel, dim3(1 << dbits), dim3(SC_THREADS), 0, stream, table, nb, totals);
+    if constexpr (sizeof(K) == 4) {
+        if (box_in && !gen && !tile_first && dbits == 8) {      // last depth pass with the box gather folded in
+            hipLaunchKernelGGL((radix_scatter_kernel<K, false, 8, ITEMS, false, false, TH, true>), dim3(nb), dim3(TH), 0, stream, ka, va, kb, vb,
+                               n_ptr, n_cap, shift, table, totals, nb, tile_first, (const int32_t *)nullptr, (const float *)nullptr,
+                               (int32_t *)nullptr, GenArgs{}, (uint32_t *)nullptr, box_in, box_out, tiles_out);
+            return;
+        }
+    }
 #define DNS_SCATTER3(B, L, G)                                                                                               \
     hipLaunchKernelGGL((radix_scatter_kernel<K, L, B, ITEMS, false, G, TH>), dim3(nb), dim3(TH), 0, stream, ka, va, kb, vb,    \
                        n_ptr, n_cap, shift, table, totals, nb, tile_first, (const int32_t *)nullptr, (const float *)nullptr, \
@@ -1051,27 +1103,35 @@ extern "C" int dnsplat_bin_prepare(const dnsplat_bin_args *a, dnsplat_stream_t s
     } else {
         const uint32_t n_u32 = (uint32_t)N;
         uint32_t *ka = w.key_a, *kb = w.key_b, *va = w.val_a, *vb = w.val_b;
+        const int2 *boxes = reinterpret_cast<const int2 *>(a->tile_boxes);
+        // DNSPLAT_BIN_BOX_GATHER=0: the round-3 route (counts gathered here, boxes gathered again by emit_prep_kernel), for A/B runs
+        static const bool box_gather = [] { const char *e = getenv("DNSPLAT_BIN_BOX_GATHER"); return !(e && e[0] == '0'); }();
+        const bool sorted_boxes = boxes && box_gather;
+        // DNSPLAT_BIN_BOX_FOLD=0: the box gather as scan_sums_kernel<true> behind the depth sort (round 4 / 5) instead of inside its last pass
+        static const bool box_fold = [] { const char *e = getenv("DNSPLAT_BIN_BOX_FOLD"); return !(e && e[0] == '0'); }();
+        const bool fold = sorted_boxes && box_fold;
         for (int pass = 0; pass < 4; ++pass) {
             const int shift = 8 * pass;
+            const bool fold_here = fold && pass == 3;
             // pass 0 knows its element count on the host (n_ptr = NULL), reads (radii, depths) instead of a key / value pair and drops
             // the culled Gaussians; it leaves the number it kept in w.n_ranked, which bounds every later pass and the scans
             if (rs_items_n(N) == RS_ITEMS_N_LARGE)
                 radix_pass<uint32_t, RS_ITEMS_N_LARGE>(stream, ka, va, kb, vb, pass == 0 ? nullptr : w.n_ranked, n_u32, shift, 8, w.tab_n, w.totals,
                                                        w.nb_n, nullptr, pass == 0 ? a->radii : nullptr, pass == 0 ? a->depths : nullptr, nullptr, 0,
-                                                       nullptr, nullptr, nullptr, pass == 0 ? w.n_ranked : nullptr);
+                                                       nullptr, nullptr, nullptr, pass == 0 ? w.n_ranked : nullptr,
+                                                       fold_here ? boxes : nullptr, w.boxes_sorted, w.tiles_sorted);
             else
                 radix_pass<uint32_t, RS_ITEMS_N>(stream, ka, va, kb, vb, pass == 0 ? nullptr : w.n_ranked, n_u32, shift, 8, w.tab_n, w.totals,
                                                  w.nb_n, nullptr, pass == 0 ? a->radii : nullptr, pass == 0 ? a->depths : nullptr, nullptr, 0,
-                                                 nullptr, nullptr, nullptr, pass == 0 ? w.n_ranked : nullptr);
+                                                 nullptr, nullptr, nullptr, pass == 0 ? w.n_ranked : nullptr,
+                                                 fold_here ? boxes : nullptr, w.boxes_sorted, w.tiles_sorted);
             uint32_t *t = ka; ka = kb; kb = t;
             t = va; va = vb; vb = t;
         }
         // after 4 passes the sorted order is back in val_a
-        const int2 *boxes = reinterpret_cast<const int2 *>(a->tile_boxes);
-        // DNSPLAT_BIN_BOX_GATHER=0: the round-3 route (counts gathered here, boxes gathered again by emit_prep_kernel), for A/B runs
-        static const bool box_gather = [] { const char *e = getenv("DNSPLAT_BIN_BOX_GATHER"); return !(e && e[0] == '0'); }();
-        const bool sorted_boxes = boxes && box_gather;
-        if (sorted_boxes)
+        if (fold)
+            hipLaunchKernelGGL(scan_sums_sorted_kernel, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.n_ranked, w.tiles_sorted, w.sums);
+        else if (sorted_boxes)
             hipLaunchKernelGGL(scan_sums_kernel<true>, dim3(w.nb_scan), dim3(SC_THREADS), 0, stream, N, w.n_ranked, w.val_a, a->tiles_per_gauss,
                                w.sums, w.tiles_sorted, boxes, w.boxes_sorted);
         else
