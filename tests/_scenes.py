@@ -398,8 +398,11 @@ def check_pixels(a, b, what, keep=None, enforce=False, p99=PIX_P99, rmax=PIX_MAX
 # statistic is asserted with COND_*_DEFAULT (the arrival order of ~30 fp32 atomic rows per Gaussian adds roundings the model of the
 # double-accumulated reduction does not count).
 U24 = 2.0 ** -24
-COND_C, COND_LAMBDA = 1.0, 8.0
-COND_C_DEFAULT, COND_LAMBDA_DEFAULT = 2.0, 16.0
+# c = 2: the bound is on ONE evaluation's distance from exact arithmetic; two evaluations (HIP, oracle fp32) are each within 1 x of it.
+# Measured worst over the suite + the 60-scene sweep: 0.68 A / 2.0 S deterministic, 1.96 A / 2.0 S with atomics (whose arrival order adds
+# the roundings of ~30 sequential fp32 adds per Gaussian that the double-accumulated model does not count): c = 4 there.
+COND_C, COND_LAMBDA = 2.0, 8.0
+COND_C_DEFAULT, COND_LAMBDA_DEFAULT = 4.0, 16.0
 
 
 def check_rows_conditioned(a, b, cond_a, cond_s, visible, what, enforce=True, strict=True):
