@@ -1,0 +1,7 @@
+#!/usr/bin/env bash
+# Round 6 final measurement on the final tree: the driver's own command, a 40-step profiled run of it, the deterministic seed sweep.
+cd "${GRAFT_REPO_ROOT:-.}"; R=$(pwd); O=gpurun_out/r06_final; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
+python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -1 $O/bench_default.json | cut -c1-400
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof" -o trace -- python "$R/bench.py" --steps 40 --warmup 5 --no-cpu-baseline --no-strict --no-extra-workloads > "$R/$O/prof_bench.json" 2> "$R/$O/prof.err"); echo "rocprof rc=$?"
+cp $(ls $O/prof/*/*kernel_stats.csv $O/prof/*kernel_stats.csv 2>/dev/null | head -1) $O/c2_kernel_stats.csv; rm -rf $O/prof; head -4 $O/c2_kernel_stats.csv | cut -c1-200
+DNSPLAT_DETERMINISTIC=1 timeout 1200 python tools/parity_seed_sweep.py 100 30 3 2>&1 | grep -v amdgpu > $O/parity_seed_sweep_deterministic.txt; tail -3 $O/parity_seed_sweep_deterministic.txt | cut -c1-300
