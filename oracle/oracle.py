@@ -283,8 +283,20 @@ def rasterize_bwd_hull(means2d, conics, colors, opacities, background, width, he
     return split(lo), split(hi), st
 
 
+def input_perturbation(means2d, conics, width, height):
+    """[N,3] float64 for ``rasterize_bwd_cond(pert=)``: how many roundings (2^-24) the projection's fp32 outputs are away from exact —
+    the conic relatively: 8 x kappa_det, kappa_det = (a c + b^2) / (a c - b^2) the cancellation of the 2x2 determinant behind the
+    inverse (1 for a round splat, 10-100 for an elongated diagonal one); the centre absolutely, in pixels:
+    4 x (|x| + W/2), 4 x (|y| + H/2) (f x / z + c: products, a quotient and the sum with the principal point)."""
+    m = means2d.detach().double().reshape(-1, 2)
+    c = conics.detach().double().reshape(-1, 3)
+    ac, b2 = c[:, 0] * c[:, 2], c[:, 1] * c[:, 1]
+    kdet = torch.where(ac - b2 > 0, (ac + b2) / (ac - b2).clamp_min(1e-300), torch.ones_like(ac))
+    return torch.stack([8.0 * kdet, 4.0 * (m[:, 0].abs() + width / 2), 4.0 * (m[:, 1].abs() + height / 2)], dim=1).contiguous()
+
+
 def rasterize_bwd_cond(means2d, conics, colors, opacities, background, width, height, tile_size, isect_offsets, flatten_ids,
-                       alphas, last_ids, vabs_render, vabs_alphas):
+                       alphas, last_ids, vabs_render, vabs_alphas, pert=None):
     """orc_rasterize_bwd_cond: per (Gaussian, raster-level gradient entry) the kappa-weighted sum of term magnitudes of A.7, float64
     [N, 8 + D] with columns (vx vy |vx| |vy| conic_a conic_b conic_c opacity colours[D]) — the running error bound, in units of one
     rounding, of that entry under any evaluation in the precision of the inputs (see oracle_impl.inc)."""
@@ -296,7 +308,8 @@ def rasterize_bwd_cond(means2d, conics, colors, opacities, background, width, he
        _p(opacities.contiguous()), _p(background.contiguous() if background is not None else None),
        ctypes.c_int(width), ctypes.c_int(height), ctypes.c_int(tile_size),
        _p(isect_offsets.contiguous()), _p(flatten_ids.contiguous()), ctypes.c_int64(flatten_ids.shape[0]),
-       _p(alphas.contiguous()), _p(last_ids.contiguous()), _p(vabs_render.contiguous()), _p(vabs_alphas.contiguous()), _p(A), _p(B))
+       _p(alphas.contiguous()), _p(last_ids.contiguous()), _p(vabs_render.contiguous()), _p(vabs_alphas.contiguous()), _p(A), _p(B),
+       _p(pert.contiguous() if pert is not None else None))
     return A, B
 
 
@@ -311,8 +324,10 @@ class ConditionTrace:
     The main backward must keep the graph (``retain_graph=True``) for the Jacobian passes.  Test infrastructure for
     tests/test_gpu_determinism.py: ||hip_g - oracle_g|| <= c x 2^-24 x ||cond_g|| for EVERY visible Gaussian."""
 
-    def __init__(self):
+    def __init__(self, input_rounding: bool = True):
         self.calls = []
+        # count the roundings of the projection's outputs (conic, centre) as a coherent shift of each splat's alphas (input_perturbation)
+        self.input_rounding = input_rounding
 
     def __enter__(self):
         global _TRACE
@@ -460,8 +475,11 @@ class _RasterizeToPixels(torch.autograd.Function):
         if absgrad:
             means2d.absgrad = v_abs.reshape(means2d.shape)
         if ctx.trace_slot is not None:
+            # the compositing inputs are the fp32 projection's outputs when they come out of this module's graph (requires_grad / grad_fn),
+            # exact when the caller hands them in as data (the legacy call's detached xys: still rounded values -> keep the term)
+            pert = input_perturbation(means2d, conics, width, height) if _TRACE is None or _TRACE.input_rounding else None
             A, B = rasterize_bwd_cond(means2d.reshape(-1, 2), conics, colors, opacities, ctx.background, width, height, tile_size,
-                                      isect_offsets, flatten_ids, alphas, last_ids, v_render.abs(), v_alphas.abs())
+                                      isect_offsets, flatten_ids, alphas, last_ids, v_render.abs(), v_alphas.abs(), pert)
             ctx.trace_slot["A"] = A if ctx.trace_slot["A"] is None else ctx.trace_slot["A"] + A
             ctx.trace_slot["B"] = B if ctx.trace_slot["B"] is None else ctx.trace_slot["B"] + B
         return (v_means2d.reshape(means2d.shape), v_conics, v_colors, v_opac) + (None,) * 9
