@@ -402,7 +402,7 @@ U24 = 2.0 ** -24
 # sit on opposite sides of the exact value (2 x), with a factor 2 of room.  Worst row seen: 1.45 x A (seed 104 anisotropic, an SH-coefficient
 # row of a 48-pixel-radius splat, tools/cond_outlier.py; 1.96 before kappa counted the splat's own rounded conic / centre, which shift the
 # alphas of all its pixels the same way: oracle.input_perturbation); everything else <= 0.60 A over the suite and the sweep's other 59
-# scenes (median 0.08), <= 2.0 S everywhere; C2 frame 0.30 A / 0.81 S.
+# scenes (median 0.08), <= 2.0 S everywhere; C2 frame 0.22 A / 0.77 S.
 # With atomics the arrival order adds the roundings of ~30 sequential fp32 adds per Gaussian: c = 8 there.
 COND_C, COND_LAMBDA = 4.0, 8.0
 COND_C_DEFAULT, COND_LAMBDA_DEFAULT = 8.0, 16.0
