@@ -280,6 +280,9 @@ __global__ __launch_bounds__(TH) void radix_hist_kernel(const K *__restrict__ ke
                 ok[i] = ok[i] && r > 0;
             } else k[i] = (uint32_t)keys[idc];
         }
+        // (measured and not kept, round 6: counting the lanes that share the first lane's digit with one ballot + ONE ds_add — the top byte of
+        // the depth keys takes two or three values per frame, 64 same-address LDS atomics serialise — changed nothing: binning 0.275 vs 0.274 ms
+        // at C2, 0.609 vs 0.610 at C5, gpurun_out/r06k)
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i)
             if (ok[i]) atomicAdd(&hist[(k[i] >> shift) & mask], 1u);
@@ -352,21 +355,27 @@ __global__ __launch_bounds__(TH) void radix_hist_ranges_kernel(const uint32_t *_
     if (threadIdx.x < ND) table[(size_t)threadIdx.x * nb + blockIdx.x] = inc + all_s;
 }
 
-// one workgroup per digit: exclusive scan of table[d][0..nb) in place, totals[d] = row sum.  Eight consecutive
-// counters per thread and round: the tile passes scan ~5 k counters per digit, which is 3 rounds instead of 21.
-__global__ __launch_bounds__(SC_THREADS) void radix_scan_kernel(uint32_t *__restrict__ table, int nb,
-                                                                uint32_t *__restrict__ totals)
+// Exclusive scan of every digit's row table[d][0..nb) in place, in SEGMENTS (round 6): workgroup (d, s) scans chunks [s x seg_len,
+// (s + 1) x seg_len) of row d on its own and leaves the segment's sum in segsum[d x segs + s]; nobody waits for anybody — the scatter
+// kernel adds the sums of the segments in front of its chunk itself (<= 7 words per digit thread, requested together with its table entry)
+// and forms the digit's total from all of them.  One workgroup per digit walked the ~11 k chunk counters of a 46 M-pair tile pass in six
+// sequential rounds with 128 workgroups on the chip: 13.6 us, twice per frame at C5.
+constexpr int SC_MAX_SEGS = 8;
+__global__ __launch_bounds__(SC_THREADS) void radix_scan_kernel(uint32_t *__restrict__ table, int nb, uint32_t *__restrict__ segsum,
+                                                                int segs, int seg_len)
 {
     __shared__ uint32_t lds_wave[4];
-    uint32_t *row = table + (size_t)blockIdx.x * nb;
+    const int d = blockIdx.x / segs, sgm = blockIdx.x - d * segs;
+    uint32_t *row = table + (size_t)d * nb;
+    const int lo = sgm * seg_len, hi = min(nb, lo + seg_len);
     uint32_t carry = 0;
-    for (int start = 0; start < nb; start += SC_CHUNK) {
+    for (int start = lo; start < hi; start += SC_CHUNK) {
         const int i0 = start + threadIdx.x * SC_ITEMS;
         uint32_t v[SC_ITEMS];
         uint32_t s = 0;
 #pragma unroll
         for (int k = 0; k < SC_ITEMS; ++k) {
-            v[k] = (i0 + k < nb) ? row[i0 + k] : 0u;
+            v[k] = (i0 + k < hi) ? row[i0 + k] : 0u;
             s += v[k];
         }
         uint32_t tot;
@@ -374,12 +383,21 @@ __global__ __launch_bounds__(SC_THREADS) void radix_scan_kernel(uint32_t *__rest
         uint32_t run = carry + inc - s;
 #pragma unroll
         for (int k = 0; k < SC_ITEMS; ++k) {
-            if (i0 + k < nb) row[i0 + k] = run;
+            if (i0 + k < hi) row[i0 + k] = run;
             run += v[k];
         }
         carry += tot;
     }
-    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+    if (threadIdx.x == 0) segsum[blockIdx.x] = carry;
+}
+// segments for a row of nb chunk counters: one per 2048 counters (one round of the scan), at most SC_MAX_SEGS
+inline void scan_segments(int nb, int &segs, int &seg_len)
+{
+    segs = (nb + SC_CHUNK - 1) / SC_CHUNK;
+    if (segs < 1) segs = 1;
+    if (segs > SC_MAX_SEGS) segs = SC_MAX_SEGS;
+    seg_len = (nb + segs - 1) / segs;
+    if (seg_len < 1) seg_len = 1;
 }
 
 // DBITS = digit width of this pass (<= 8): the tile passes split their 13 bits 7 + 6 instead of 8 + 8 — fewer
@@ -411,7 +429,8 @@ __global__ __launch_bounds__(TH) DNS_TI_OCCUPANCY(TH, K) void radix_scatter_kern
     const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nb, int32_t *__restrict__ tile_first,
     const int32_t *__restrict__ radii = nullptr, const float *__restrict__ depths = nullptr,
     int32_t *__restrict__ tile_end = nullptr, GenArgs gen = GenArgs{}, uint32_t *__restrict__ count_out = nullptr,
-    const int2 *__restrict__ box_in = nullptr, int2 *__restrict__ box_out = nullptr, uint32_t *__restrict__ tiles_out = nullptr)
+    const int2 *__restrict__ box_in = nullptr, int2 *__restrict__ box_out = nullptr, uint32_t *__restrict__ tiles_out = nullptr,
+    int segs = 1, int seg_len = 0x7fffffff)
 {
     // The chunk is first sorted by digit INSIDE LDS (stable), then written out run by run: consecutive lanes
     // store to consecutive addresses of one digit's run, so the stores coalesce.  A direct scatter from the
@@ -443,8 +462,20 @@ __global__ __launch_bounds__(TH) DNS_TI_OCCUPANCY(TH, K) void radix_scatter_kern
     // this thread's digit: its global total and the count of the chunks before this one — requested now, needed only
     // after the ranking (two loads that depend on nothing and otherwise sit exposed between two barriers)
     const bool is_digit = threadIdx.x <= DMASK;
-    const uint32_t pre_tot = is_digit ? totals[threadIdx.x] : 0u;
-    const uint32_t pre_tab = is_digit ? table[(size_t)threadIdx.x * nb + blockIdx.x] : 0u;
+    // segmented scan (radix_scan_kernel): the digit's total is the sum of its segment sums, and the chunk's table entry is relative to its
+    // segment — the sums of the segments in front of it are added here
+    uint32_t pre_tot = 0u, pre_tab = is_digit ? table[(size_t)threadIdx.x * nb + blockIdx.x] : 0u;
+    {
+        const int my_seg = (int)blockIdx.x / seg_len;
+        uint32_t sg[SC_MAX_SEGS];
+#pragma unroll
+        for (int q = 0; q < SC_MAX_SEGS; ++q) sg[q] = (is_digit && q < segs) ? totals[threadIdx.x * segs + q] : 0u;
+#pragma unroll
+        for (int q = 0; q < SC_MAX_SEGS; ++q) {
+            pre_tot += sg[q];
+            if (q < my_seg) pre_tab += sg[q];
+        }
+    }
 
     if (threadIdx.x < ND) {
 #pragma unroll
@@ -812,7 +843,7 @@ struct BinWs {
     EmitRec *jrec;                            // [N]
     uint32_t *chunk_first;                    // [MAX_CHUNKS]
     uint32_t *tab_n;                          // [256 * nb_n]
-    uint32_t *totals;                         // [256]
+    uint32_t *totals;                         // [256 x SC_MAX_SEGS] segment sums of the digit scans
     uint32_t *sums;                           // [nb_scan]
     uint32_t *total;                          // [1] n_isects as u32
     uint32_t *status;                         // [1] reserved status word (dnsplat_bin_status_offset): 0
@@ -851,7 +882,7 @@ BinWs carve(void *ws, int N, int64_t cap)
     b.jrec = reinterpret_cast<EmitRec *>(take(4 * n));
     b.chunk_first = take(MAX_CHUNKS);
     b.tab_n = take((size_t)RS_DIGITS * b.nb_n);
-    b.totals = take(RS_DIGITS);
+    b.totals = take((size_t)RS_DIGITS * SC_MAX_SEGS);
     b.sums = take(b.nb_scan);
     b.total = take(1);
     b.status = take(1);
@@ -876,11 +907,14 @@ void radix_pass(hipStream_t stream, const K *ka, const uint32_t *va, K *kb, uint
                 const int2 *box_in = nullptr, int2 *box_out = nullptr, uint32_t *tiles_out = nullptr)
 {
     const uint32_t mask = (1u << dbits) - 1u;
+    int segs, seg_len;
+    scan_segments(nb, segs, seg_len);
     if (radii) {   // first pass of the depth sort: 8-bit digit, keys synthesised from (radii, depths)
         hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS, true, false, TH>), dim3(nb), dim3(TH), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb, radii, depths);
-        hipLaunchKernelGGL(radix_scan_kernel, dim3(1 << dbits), dim3(SC_THREADS), 0, stream, table, nb, totals);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3((1 << dbits) * segs), dim3(SC_THREADS), 0, stream, table, nb, totals, segs, seg_len);
         hipLaunchKernelGGL((radix_scatter_kernel<K, false, 8, ITEMS, true, false, TH>), dim3(nb), dim3(TH), 0, stream, ka, va, kb, vb,
-                           n_ptr, n_cap, shift, table, totals, nb, tile_first, radii, depths, (int32_t *)nullptr, GenArgs{}, count_out);
+                           n_ptr, n_cap, shift, table, totals, nb, tile_first, radii, depths, (int32_t *)nullptr, GenArgs{}, count_out,
+                           (const int2 *)nullptr, (int2 *)nullptr, (uint32_t *)nullptr, segs, seg_len);
         return;
     }
     const GenArgs g = gen ? *gen : GenArgs{};
@@ -893,19 +927,19 @@ void radix_pass(hipStream_t stream, const K *ka, const uint32_t *va, K *kb, uint
     else
         hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS, false, false, TH>), dim3(nb), dim3(TH), 0, stream, ka, n_ptr, n_cap, shift, mask, table, nb,
                            (const int32_t *)nullptr, (const float *)nullptr, init_offsets, n_tiles, init_offsets ? tile_end : nullptr, g, status);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(1 << dbits), dim3(SC_THREADS), 0, stream, table, nb, totals);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3((1 << dbits) * segs), dim3(SC_THREADS), 0, stream, table, nb, totals, segs, seg_len);
     if constexpr (sizeof(K) == 4) {
         if (box_in && !gen && !tile_first && dbits == 8) {      // last depth pass with the box gather folded in
             hipLaunchKernelGGL((radix_scatter_kernel<K, false, 8, ITEMS, false, false, TH, true>), dim3(nb), dim3(TH), 0, stream, ka, va, kb, vb,
                                n_ptr, n_cap, shift, table, totals, nb, tile_first, (const int32_t *)nullptr, (const float *)nullptr,
-                               (int32_t *)nullptr, GenArgs{}, (uint32_t *)nullptr, box_in, box_out, tiles_out);
+                               (int32_t *)nullptr, GenArgs{}, (uint32_t *)nullptr, box_in, box_out, tiles_out, segs, seg_len);
             return;
         }
     }
 #define DNS_SCATTER3(B, L, G)                                                                                               \
     hipLaunchKernelGGL((radix_scatter_kernel<K, L, B, ITEMS, false, G, TH>), dim3(nb), dim3(TH), 0, stream, ka, va, kb, vb,    \
                        n_ptr, n_cap, shift, table, totals, nb, tile_first, (const int32_t *)nullptr, (const float *)nullptr, \
-                       tile_end, g)
+                       tile_end, g, (uint32_t *)nullptr, (const int2 *)nullptr, (int2 *)nullptr, (uint32_t *)nullptr, segs, seg_len)
 #define DNS_SCATTER(B)                                                                                                      \
     do {                                                                                                                    \
         if (tile_first) { if (gen) DNS_SCATTER3(B, true, true); else DNS_SCATTER3(B, true, false); }                        \
@@ -971,7 +1005,7 @@ int tile_bits(int n_tiles)
 struct DetWs {
     uint32_t *key_a, *key_b, *val_a, *val_b;   // [cap]
     uint32_t *table;                           // [256 * nb]
-    uint32_t *totals;                          // [256]
+    uint32_t *totals;                          // [256 x SC_MAX_SEGS]
     uint32_t *count;                           // [1]
     int nb;
     size_t bytes;
@@ -992,7 +1026,7 @@ DetWs det_carve(void *ws, int64_t cap)
     const size_t c = (size_t)(cap > 0 ? cap : 1);
     d.key_a = take(c); d.key_b = take(c); d.val_a = take(c); d.val_b = take(c);
     d.table = take((size_t)RS_DIGITS * d.nb);
-    d.totals = take(RS_DIGITS);
+    d.totals = take((size_t)RS_DIGITS * SC_MAX_SEGS);
     d.count = take(1);
     d.bytes = off;
     return d;
