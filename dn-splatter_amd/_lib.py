@@ -18,7 +18,7 @@ _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["DNSPLAT_LIB"]).resolve() if os.environ.get("DNSPLAT_LIB") else _PKG_DIR / "libdnsplat.so"
 CSRC_DIR = _PKG_DIR / "csrc"
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 RECORD_FLOATS = 16
 MAX_CHANNELS = 8
 
@@ -146,7 +146,7 @@ EXPORTS = [
     "dnsplat_bin_workspace_bytes", "dnsplat_bin_status_offset", "dnsplat_bin_prepare", "dnsplat_bin_emit_sort", "dnsplat_bin_isect_ids",
     "dnsplat_raster_fwd", "dnsplat_raster_bwd", "dnsplat_det_workspace_bytes", "dnsplat_det_reduce",
     "dnsplat_dn_depth_normals", "dnsplat_camera_prepare", "dnsplat_densify_stats", "dnsplat_densify_classify",
-    "dnsplat_densify_split", "dnsplat_dn_loss", "dnsplat_scale_reg", "dnsplat_sh_grads_from_factors", "dnsplat_sh_factors",
+    "dnsplat_densify_split", "dnsplat_dn_loss", "dnsplat_ssim", "dnsplat_scale_reg", "dnsplat_sh_grads_from_factors", "dnsplat_sh_factors",
     "dnsplat_project_bwd", "dnsplat_sh_grads_add_factors", "dnsplat_packed_slab_floats", "dnsplat_visible_index",
     "dnsplat_sh_grads_from_packed",
 ]
@@ -205,6 +205,7 @@ def lib() -> ctypes.CDLL:
                                                     c_void_p, c_int32, c_void_p]
         L.dnsplat_dn_loss.argtypes = [ctypes.POINTER(DnLossArgs), c_void_p]
         L.dnsplat_scale_reg.argtypes = [c_int32, c_void_p, c_float, c_void_p, c_void_p, c_void_p]
+        L.dnsplat_ssim.argtypes = [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.dnsplat_camera_prepare.argtypes = [c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_int32, c_void_p]
         L.dnsplat_sh_factors.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]

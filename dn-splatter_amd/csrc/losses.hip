@@ -160,6 +160,8 @@ __global__ __launch_bounds__(LS_THREADS) void dn_ssim_stats_kernel(LossArgs a)
     if (threadIdx.x == 0) atomicAdd(a.slots + 8 * ((blockIdx.y * gridDim.x + blockIdx.x) % LS_SLOTS) + 0, tot);
 }
 
+// SSIM_ONLY (dnsplat_ssim): only v_rgb = d(mean SSIM)/d(rgb) is produced — no L1 term, no depth / normal section, no partial sums.
+template <bool SSIM_ONLY>
 __global__ __launch_bounds__(LS_THREADS) void dn_loss_grad_kernel(LossArgs a)
 {
     __shared__ float in_tile[3][LS_IH][LS_IW];   // a, b, c maps of one channel
@@ -171,7 +173,8 @@ __global__ __launch_bounds__(LS_THREADS) void dn_loss_grad_kernel(LossArgs a)
     const size_t plane = (size_t)W * H * 3;
     const float P = (float)W * (float)H;
     const float M = 3.f * (float)VW * (float)VH;              // SSIM windows x channels
-    const float w_l1 = (1.f - a.ssim_lambda) / (3.f * P), w_ss = -a.ssim_lambda / M;   // loss has + l (1 - mean s)
+    const float w_l1 = SSIM_ONLY ? 0.f : (1.f - a.ssim_lambda) / (3.f * P);
+    const float w_ss = SSIM_ONLY ? 1.f / M : -a.ssim_lambda / M;   // loss has + l (1 - mean s)
     float s_l1 = 0.f, s_eax = 0.f, s_eay = 0.f, s_nl1 = 0.f, s_tvh = 0.f, s_tvw = 0.f;
 
     // ---- RGB: L1 + transposed blur of the SSIM sensitivities.  As in the statistics kernel, everything the workgroup reads for the
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(LS_THREADS) void dn_loss_grad_kernel(LossArgs a)
             }
         }
     }
+    if (SSIM_ONLY) return;
 
     // ---- depth (EdgeAwareLogL1) and normal (L1 + TV): 3-point stencils
     const float n_x = a.gt_depth ? a.counts[0] : 1.f, n_y = a.gt_depth ? a.counts[1] : 1.f;
@@ -362,6 +366,36 @@ extern "C" int dnsplat_scale_reg(int32_t N, const float *scales_log, float weigh
     return DNSPLAT_OK;
 }
 
+static void ssim_window(Gauss11 &win)
+{
+    // pytorch_msssim window: exp(-(x - 5)^2 / (2 * 1.5^2)), normalised
+    double g[LS_K], tot = 0.0;
+    for (int t = 0; t < LS_K; ++t) { const double x = t - LS_K / 2; g[t] = exp(-(x * x) / (2.0 * 1.5 * 1.5)); tot += g[t]; }
+    for (int t = 0; t < LS_K; ++t) win.g[t] = (float)(g[t] / tot);
+}
+
+extern "C" int dnsplat_ssim(int32_t width, int32_t height, const float *x, const float *y, float *maps, float *v_x, float *sums,
+                            dnsplat_stream_t stream_)
+{
+    if (width <= LS_R || height <= LS_R) return DNSPLAT_ERR_UNSUPPORTED;           // SSIM needs an 11x11 window
+    if (!x || !y || !maps || !sums) return DNSPLAT_ERR_INVALID_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    LossArgs a = {};
+    a.W = width; a.H = height;
+    a.rgb = x; a.gt_rgb = y; a.v_rgb = v_x; a.sums = sums;
+    ssim_window(a.win);
+    a.slots = maps;
+    a.maps = maps + LS_SLOTS * 8;
+    if (hipMemsetAsync(a.slots, 0, LS_SLOTS * 8 * sizeof(float), stream) != hipSuccess) return DNSPLAT_ERR_LAUNCH;
+    dim3 grid_v((a.W - LS_R + LS_TW - 1) / LS_TW, (a.H - LS_R + LS_TH - 1) / LS_TH);
+    dim3 grid((a.W + LS_TW - 1) / LS_TW, (a.H + LS_TH - 1) / LS_TH);
+    hipLaunchKernelGGL(dn_ssim_stats_kernel, grid_v, dim3(LS_THREADS), 0, stream, a);
+    if (v_x) hipLaunchKernelGGL(dn_loss_grad_kernel<true>, grid, dim3(LS_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(dn_loss_fold_kernel, dim3(1), dim3(DNS_WAVE), 0, stream, (const float *)a.slots, a.sums);
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}
+
 extern "C" int dnsplat_dn_loss(const dnsplat_dn_loss_args *u, dnsplat_stream_t stream_)
 {
     if (!u) return DNSPLAT_ERR_INVALID_ARG;
@@ -376,10 +410,7 @@ extern "C" int dnsplat_dn_loss(const dnsplat_dn_loss_args *u, dnsplat_stream_t s
     a.gt_rgb = u->gt_rgb; a.gt_depth = u->gt_depth; a.gt_normal = u->gt_normal; a.counts = u->depth_counts;
     a.ssim_lambda = u->ssim_lambda; a.depth_weight = u->depth_weight; a.depth_tolerance = u->depth_tolerance;
     a.maps = u->maps; a.v_rgb = u->v_rgb; a.v_depth = u->v_depth; a.v_normal = u->v_normal; a.sums = u->sums;
-    // pytorch_msssim window: exp(-(x - 5)^2 / (2 * 1.5^2)), normalised
-    double g[LS_K], tot = 0.0;
-    for (int t = 0; t < LS_K; ++t) { const double x = t - LS_K / 2; g[t] = exp(-(x * x) / (2.0 * 1.5 * 1.5)); tot += g[t]; }
-    for (int t = 0; t < LS_K; ++t) a.win.g[t] = (float)(g[t] / tot);
+    ssim_window(a.win);
     // the partial sums live at the front of the scratch `maps` (9 H W floats, of which the kernels use the valid-window part): the
     // first LS_SLOTS x 8 floats are NOT map entries — see LossArgs::maps below
     a.slots = u->maps;
@@ -388,7 +419,7 @@ extern "C" int dnsplat_dn_loss(const dnsplat_dn_loss_args *u, dnsplat_stream_t s
     dim3 grid_v((a.W - LS_R + LS_TW - 1) / LS_TW, (a.H - LS_R + LS_TH - 1) / LS_TH);
     dim3 grid((a.W + LS_TW - 1) / LS_TW, (a.H + LS_TH - 1) / LS_TH);
     hipLaunchKernelGGL(dn_ssim_stats_kernel, grid_v, dim3(LS_THREADS), 0, stream, a);
-    hipLaunchKernelGGL(dn_loss_grad_kernel, grid, dim3(LS_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(dn_loss_grad_kernel<false>, grid, dim3(LS_THREADS), 0, stream, a);
     hipLaunchKernelGGL(dn_loss_fold_kernel, dim3(1), dim3(DNS_WAVE), 0, stream, (const float *)a.slots, a.sums);
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;

@@ -25,6 +25,12 @@
 #ifndef DNS_FWD_PAIR_OPSEL
 #define DNS_FWD_PAIR_OPSEL 1
 #endif
+// 1: the splat loop takes TWO kept splats per trip — both records read and both exponents / alphas evaluated before the first is
+// blended (the evaluation does not depend on the running transmittance), then blended in list order with the same per-pixel
+// operation sequence as the one-splat loop (bit-identical images); an odd last splat pairs with itself under an empty mask.
+#ifndef DNS_FWD_UNROLL2
+#define DNS_FWD_UNROLL2 0
+#endif
 
 namespace {
 
@@ -202,6 +208,97 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
         // every predicate that is live across a branch with three scalar instructions per merge and rebuilds masks through
         // v_cndmask + v_cmp: the loop then issued as many scalar as vector instructions and was bound by both.
         // A kept splat nearly always hits some pixel of the strip, so the blend is unconditional (weight 0 for a skipped pair).
+#if DNS_FWD_UNROLL2
+        // what of a splat does not depend on the pixels' running state: exponents, capped alphas, channels
+        auto eval = [&](int t, float &e0, float &e1, float &alpha0, float &alpha1, float (&ch)[8]) __attribute__((always_inline)) {
+            const float4 g0 = my[t][0];  // x y na nb
+            const float4 g1 = my[t][1];  // nc opac ch0 ch1
+            float4 g2, g3;
+            if (D > 2) g2 = my[t][2];
+            if (D > 6) g3 = my[t][3];
+            DnsConicE q;
+            q.na = g0.z; q.nb = g0.w; q.nc = g1.x;
+            const float dx = g0.x - px;
+            const float dy0 = g0.y - py0, dy1 = g0.y - py1;
+#if DNS_EXP_SYM
+            const float adx = q.na * dx, bdx = q.nb * dx;
+#if DNS_FWD_PAIR_OPSEL
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 an = {adx, q.nb}, dyv = {dy0, dy1};
+            f2 hu;
+            asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(hu) : "v"(an), "v"(dyv));
+            e0 = __builtin_fmaf(dx, hu.x, dy0 * __builtin_fmaf(q.nc, dy0, bdx));
+            e1 = __builtin_fmaf(dx, hu.y, dy1 * __builtin_fmaf(q.nc, dy1, bdx));
+#else
+            e0 = __builtin_fmaf(dx, __builtin_fmaf(q.nb, dy0, adx), dy0 * __builtin_fmaf(q.nc, dy0, bdx));
+            e1 = __builtin_fmaf(dx, __builtin_fmaf(q.nb, dy1, adx), dy1 * __builtin_fmaf(q.nc, dy1, bdx));
+#endif
+#else
+            e0 = dns_exponent(q, dx, dy0);
+            e1 = dns_exponent(q, dx, dy1);
+#endif
+            alpha0 = fminf((float)DNS_ALPHA_MAX, g1.y * dns_exp2(e0));
+            alpha1 = fminf((float)DNS_ALPHA_MAX, g1.y * dns_exp2(e1));
+            ch[0] = g1.z; ch[1] = g1.w;
+            if (D > 2) { ch[2] = g2.x; ch[3] = g2.y; ch[4] = g2.z; ch[5] = g2.w; }
+            if (D > 6) { ch[6] = g3.x; ch[7] = g3.y; }
+        };
+        // the order-dependent part, exactly the one-splat loop's: `has` = ~0 (a list entry) or 0 (the filler of an odd trip)
+        auto blend = [&](int t, uint64_t has, float e0, float e1, float alpha0, float alpha1, const float (&ch)[8]) __attribute__((always_inline)) {
+            float nT0, nT1, v0, v1;
+            const uint64_t valid0 = dns_ballot(e0 <= 0.f) & dns_ballot(alpha0 >= (float)DNS_ALPHA_MIN) & ~done0 & has;
+            const uint64_t valid1 = dns_ballot(e1 <= 0.f) & dns_ballot(alpha1 >= (float)DNS_ALPHA_MIN) & ~done1 & has;
+            const float a0 = sel0(valid0, alpha0), a1 = sel0(valid1, alpha1);
+            nT0 = T0 * (1.f - a0); nT1 = T1 * (1.f - a1);
+            const uint64_t stop0 = dns_ballot(nT0 <= (float)DNS_T_MIN), stop1 = dns_ballot(nT1 <= (float)DNS_T_MIN);
+            v0 = a0 * T0; v1 = a1 * T1;
+            any0 |= valid0; any1 |= valid1;
+            if (COUNT && has) {
+                n_walked += 1;
+                n_live += __popcll(~done0) + __popcll(~done1);
+                n_blend += __popcll(valid0 & ~stop0) + __popcll(valid1 & ~stop1);
+            }
+            const int before = batch_start + t - 1;
+            float tmp;
+            asm volatile(
+                "s_or_b64 vcc, %9, %10\n\t"
+                "s_cmp_eq_u64 vcc, 0\n\t"
+                "s_cbranch_scc1 1f\n\t"
+                "v_mov_b32_e32 %8, %13\n\t"
+                "v_cndmask_b32_e64 %0, %0, 0, %9\n\t"
+                "v_cndmask_b32_e64 %1, %1, 0, %10\n\t"
+                "v_cndmask_b32_e64 %2, %2, %11, %9\n\t"
+                "v_cndmask_b32_e64 %3, %3, %12, %10\n\t"
+                "v_cndmask_b32_e64 %4, %4, %8, %9\n\t"
+                "v_cndmask_b32_e64 %5, %5, %8, %10\n\t"
+                "s_or_b64 %6, %6, %9\n\t"
+                "s_or_b64 %7, %7, %10\n\t"
+                "1:"
+                : "+v"(v0), "+v"(v1), "+v"(nT0), "+v"(nT1), "+v"(last0), "+v"(last1), "+s"(done0), "+s"(done1), "=&v"(tmp)
+                : "s"(stop0), "s"(stop1), "v"(T0), "v"(T1), "s"(before)
+                : "vcc", "scc");
+#pragma unroll
+            for (int k = 0; k < D; ++k) { acc0[k] += ch[k] * v0; acc1[k] += ch[k] * v1; }
+            T0 = nT0; T1 = nT1;
+        };
+        while (todo) {
+            const int tA = __ffsll((unsigned long long)todo) - 1;
+            asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(tA));
+            const uint64_t hasB = todo ? ~0ull : 0ull;
+            const int tB = todo ? __ffsll((unsigned long long)todo) - 1 : tA;
+            asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(tB));       // no second splat: clears bit tA again
+            float eA0, eA1, aA0, aA1, chA[8], eB0, eB1, aB0, aB1, chB[8];
+            eval(tA, eA0, eA1, aA0, aA1, chA);
+            eval(tB, eB0, eB1, aB0, aB1, chB);
+            blend(tA, ~0ull, eA0, eA1, aA0, aA1, chA);
+            blend(tB, hasB, eB0, eB1, aB0, aB1, chB);
+            {
+                [[maybe_unused]] uint64_t tmp_s;
+                asm("s_and_b64 %1, %2, %3\n\ts_cmp_eq_u64 %1, -1\n\ts_cselect_b64 %0, 0, %0"
+                    : "+s"(todo), "=&s"(tmp_s) : "s"(done0), "s"(done1) : "scc");
+            }
+        }
+#else
         while (todo) {
             const int t = __ffsll((unsigned long long)todo) - 1;
             asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(t));      // todo &= todo - 1 as one scalar instruction instead of three
@@ -298,6 +395,7 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
             for (int k = 0; k < D; ++k) { acc0[k] += ch[k] * v0; acc1[k] += ch[k] * v1; }
             T0 = nT0; T1 = nT1;
         }
+#endif
         // A pixel that blended anything in this batch and is still open: every entry of the batch behind its last blended one was
         // skipped for it, so the END of the batch serves as its "last index" — the backward replays a few no-ops more, and the loop
         // above does not have to remember the index splat by splat (two selects per splat).

@@ -66,6 +66,65 @@ class _DnLossFn(torch.autograd.Function):
         return (v_rgb * g, v_depth * g, v_normal * g) + (None,) * 7
 
 
+class _SsimFn(torch.autograd.Function):
+    """Mean SSIM of two [H,W,3] images and its gradient w.r.t. the first in two launches (``dnsplat_ssim``)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x = _f32c(x, "ssim x"); y = _f32c(y, "ssim y")
+        if x.dim() != 3 or x.shape[2] != 3 or x.shape != y.shape:
+            raise ValueError(f"dnsplat_ssim takes two [H,W,3] images, got {tuple(x.shape)} and {tuple(y.shape)}")
+        H, W = x.shape[0], x.shape[1]
+        f32 = dict(dtype=torch.float32, device=x.device)
+        maps = torch.empty(9 * H * W + 512, **f32)
+        need_grad = ctx.needs_input_grad[0]
+        v_x = torch.empty(H, W, 3, **f32) if need_grad else None
+        sums = torch.empty(8, **f32)
+        _lib.run("dnsplat_ssim", _lib.lib().dnsplat_ssim, W, H, _ptr(x), _ptr(y), _ptr(maps), _ptr(v_x), _ptr(sums), _stream())
+        if need_grad:
+            ctx.save_for_backward(v_x)
+        return sums[0] / (3.0 * (W - 10) * (H - 10))
+
+    @staticmethod
+    def backward(ctx, g):
+        (v_x,) = ctx.saved_tensors
+        return v_x * g, None
+
+
+def ssim_hip(pred: Tensor, gt: Tensor) -> Tensor:
+    """Mean SSIM of two [H,W,3] images in [0,1] (pytorch_msssim's definition: 11-tap Gaussian, sigma 1.5, valid padding), with the
+    gradient w.r.t. ``pred`` — ``torch_losses.ssim`` as ONE autograd node on two HIP launches instead of ~45 torch kernels."""
+    return _SsimFn.apply(pred, gt)
+
+
+class SSIM(torch.nn.Module):
+    """Stand-in for the module ``DNSplatterModel`` holds as ``self.ssim`` — ``torchmetrics.StructuralSimilarityIndexMeasure(
+    data_range=1.0, kernel_size=11)`` (dn_model.py:180; nerfstudio's own splatfacto holds ``pytorch_msssim.SSIM(data_range=1.0,
+    size_average=True, channel=3)``: the same 11-tap sigma-1.5 Gaussian statistics averaged over the (W-10)(H-10) windows that do
+    not touch the border — torchmetrics reflect-pads and crops the padded rim away again) — as the inherited RGB term calls it:
+    ``1 - self.ssim(gt.permute(2,0,1)[None], pred.permute(2,0,1)[None])`` (two [1,3,H,W] views of [H,W,3] images: read in place;
+    any other layout is copied), and as the evaluation calls it (dn_model.py:855).  SSIM is symmetric in its arguments; the gradient
+    goes to whichever of the two requires it (the rendered image).  Not restated: recent torchmetrics clamp the two variances at 0
+    before the ratio (a decision on fp32 rounding noise of a quantity that is >= 0 in exact arithmetic).  ``install_ssim(model)``
+    puts it in place."""
+
+    def __init__(self, data_range: float = 1.0, size_average: bool = True, channel: int = 3, kernel_size: int = 11, sigma: float = 1.5):
+        super().__init__()
+        if data_range != 1.0 or not size_average or channel != 3 or kernel_size != 11 or sigma != 1.5:
+            raise NotImplementedError("dnsplat SSIM: data_range=1.0, kernel_size=11, sigma=1.5, mean over 3 channels (the module "
+                                      "dn-splatter / splatfacto construct)")
+
+    def forward(self, X: Tensor, Y: Tensor) -> Tensor:
+        if X.dim() != 4 or X.shape[0] != 1 or X.shape[1] != 3 or X.shape != Y.shape:
+            raise NotImplementedError(f"dnsplat SSIM takes two [1,3,H,W] images, got {tuple(X.shape)} and {tuple(Y.shape)}")
+        x, y = X[0].permute(1, 2, 0), Y[0].permute(1, 2, 0)
+        if y.requires_grad and not x.requires_grad:
+            x, y = y, x
+        elif y.requires_grad:
+            raise NotImplementedError("dnsplat SSIM differentiates one argument (the rendered image)")
+        return _SsimFn.apply(x, y)
+
+
 class _ScaleRegFn(torch.autograd.Function):
     """mean_g min_k exp(scales[g, k]) (regularization_strategy.py:195-199) and its gradient in one launch (dnsplat_scale_reg)."""
 

@@ -124,6 +124,19 @@ def install(model_cls):
     return model_cls
 
 
+def install_ssim(model):
+    """Replaces ``model.ssim`` (dn_model.py:180: torchmetrics' ``StructuralSimilarityIndexMeasure(data_range=1.0, kernel_size=11)``,
+    used by the inherited RGB loss term and by the evaluation, :855) by ``fused_loss.SSIM`` — the one term of the PyTorch loss stack
+    whose library kernels (sixteen depthwise conv2d calls through MIOpen, ~3 ms at 1600 x 1200) cost as much as the render step;
+    everything else of ``get_loss_dict`` stays as it is.  The old module is kept as ``model._dnsplat_original_ssim``."""
+    from .fused_loss import SSIM
+
+    if not isinstance(getattr(model, "ssim", None), SSIM):
+        object.__setattr__(model, "_dnsplat_original_ssim", getattr(model, "ssim", None))
+        model.ssim = SSIM()
+    return model
+
+
 def uninstall(model_cls):
     """Puts the original ``get_outputs`` back."""
     original = model_cls.__dict__.get(_ORIGINAL)

@@ -33,7 +33,7 @@ def ssim(pred: Tensor, gt: Tensor, data_range: float = 1.0) -> Tensor:
     x = pred.permute(2, 0, 1)[None]
     y = gt.permute(2, 0, 1)[None]
     C = x.shape[1]
-    w = _gaussian_window(device=x.device)
+    w = _gaussian_window(device=x.device).to(x.dtype)
     wh = w.view(1, 1, -1, 1).repeat(C, 1, 1, 1)
     ww = w.view(1, 1, 1, -1).repeat(C, 1, 1, 1)
 
@@ -163,13 +163,23 @@ def tv_loss(pred: Tensor) -> Tensor:
     return _dcol(pred).abs().mean() + _drow(pred).abs().mean()
 
 
-def rgb_term(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], ssim_lambda: float = 0.2, fast: bool = False) -> Tensor:
+def _ssim_hip(pred: Tensor, gt: Tensor) -> Tensor:
+    from .fused_loss import ssim_hip
+    return ssim_hip(pred, gt)
+
+
+def rgb_term(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], ssim_lambda: float = 0.2, fast: bool = False,
+             ssim_impl: Optional[str] = None) -> Tensor:
     """nerfstudio splatfacto's main_loss, which DNSplatterModel.get_loss_dict takes over unchanged (dn_model.py:624-627, :663):
     (1 - l) * L1 + l * (1 - SSIM).  Restated from nerfstudio / pytorch_msssim's published definitions (not vendored: unpinned).
-    ``fast``: the SSIM blurs as two GEMMs (``ssim_gemm``) instead of pytorch_msssim's ten grouped conv2d calls."""
+    ``ssim_impl``: "conv" (pytorch_msssim's ten grouped conv2d calls), "gemm", "stacked" (the same sums phrased for other library
+    kernels; both measured slower) or "hip" — the SSIM module alone as one autograd node on ``dnsplat_ssim`` (what
+    ``fused_loss.SSIM`` installs as splatfacto's ``self.ssim``), everything else of the stack in PyTorch."""
     pred_img = outputs["rgb"]
     ll1 = torch.abs(batch["image"] - pred_img).mean()
-    impl = {"gemm": ssim_gemm, "stacked": ssim_stacked}.get(SSIM_FAST_IMPL, ssim) if fast else ssim
+    if ssim_impl is None:
+        ssim_impl = SSIM_FAST_IMPL if fast else "conv"
+    impl = {"gemm": ssim_gemm, "stacked": ssim_stacked, "hip": _ssim_hip}.get(ssim_impl, ssim)
     simloss = 1 - impl(pred_img, batch["image"])
     return (1 - ssim_lambda) * ll1 + ssim_lambda * simloss
 
@@ -202,12 +212,12 @@ def regularization_term(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], sc
 
 def dn_loss(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], scales: Tensor, ssim_lambda: float = 0.2,
             depth_lambda: float = 0.2, depth_tolerance: float = 0.1, use_depth_loss: bool = True,
-            use_normal_loss: bool = True, capturable: bool = False) -> Tensor:
+            use_normal_loss: bool = True, capturable: bool = False, ssim_impl: Optional[str] = None) -> Tensor:
     """main_loss of ``DNSplatterModel.get_loss_dict`` for regularization_strategy == "dn-splatter" with mono depth
     and mono normal supervision (dn_model.py:614-729): rgb_loss + regularization_strategy_loss (:727).
     ``capturable``: the same terms in PyTorch ops that need no host synchronisation and no convolution library — masked means as
     sum / count (``edge_aware_log_l1``), SSIM blurs as GEMMs (``ssim_gemm``): the whole step can be captured into a HIP graph."""
-    return rgb_term(outputs, batch, ssim_lambda, fast=capturable) + regularization_term(outputs, batch, scales, depth_lambda, depth_tolerance,
+    return rgb_term(outputs, batch, ssim_lambda, fast=capturable, ssim_impl=ssim_impl) + regularization_term(outputs, batch, scales, depth_lambda, depth_tolerance,
                                                                        use_depth_loss, use_normal_loss, capturable)
 
 

@@ -48,8 +48,9 @@ extern "C" {
  * from it.  Round 6: 14 = dnsplat_scene.colors_are_logit (the sh_degree == 0 branch of get_outputs in the fused pass),
  * dnsplat_proj_out.skip_culled_records, dnsplat_proj_grads.sh_grad_scale / sh_zero_state (own-camera SH rows in the exchange step;
  * gradient rows of persistently culled Gaussians are not re-zeroed), dnsplat_sh_grads_add_factors, the packed (visible rows only)
- * colour-gradient slabs: dnsplat_visible_index, dnsplat_proj_grads.sh_packed, dnsplat_sh_grads_from_packed. */
-#define DNSPLAT_ABI_VERSION 14
+ * colour-gradient slabs: dnsplat_visible_index, dnsplat_proj_grads.sh_packed, dnsplat_sh_grads_from_packed; 15 = dnsplat_ssim (the
+ * SSIM term alone, for a loss stack that otherwise stays in PyTorch). */
+#define DNSPLAT_ABI_VERSION 15
 #define DNSPLAT_RECORD_FLOATS 16
 #define DNSPLAT_MAX_CHANNELS 8
 
@@ -434,6 +435,16 @@ typedef struct dnsplat_dn_loss_args {
 } dnsplat_dn_loss_args;
 
 int dnsplat_dn_loss(const dnsplat_dn_loss_args *args, dnsplat_stream_t stream);
+
+/* ABI 15.  The SSIM term ALONE, for a loss stack that otherwise stays in PyTorch (BASELINE.json: "losses stay in PyTorch-ROCm"):
+ * what nerfstudio splatfacto's `self.ssim(gt, pred)` computes inside the RGB term dn-splatter inherits (dn_model.py:624-627, :663) —
+ * pytorch_msssim.SSIM(data_range=1, size_average=True, channel=3): 11-tap Gaussian sigma 1.5, valid padding, mean over the
+ * (W-10)(H-10) windows of the 3 channels.  MIOpen runs the sixteen depthwise conv2d calls of that module and its backward at
+ * 250-500 us each on a 1600 x 1200 image (profiles/r06_c5_torch_loss_kernel_stats.txt).
+ *   sums[0] = sum of the per-window SSIM values (mean = sums[0] / (3 (W-10)(H-10))),
+ *   v_x     = d(mean SSIM)/dx, [H,W,3], or NULL (value only);   x, y: [H,W,3] fp32;   maps: scratch, 9 H W + 512 floats. */
+int dnsplat_ssim(int32_t width, int32_t height, const float *x, const float *y, float *maps, float *v_x, float *sums /* device [8] */,
+                 dnsplat_stream_t stream);
 
 /* The per-Gaussian term of the same loss (regularization_strategy.py:195-199): mean_g min_k exp(scales[g][k]).  Adds
  * weight * sum_g min_k exp(s_gk) to *sum (device scalar, caller zeroes it) and WRITES the gradient rows

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(dns, built):
 
 def test_abi_version_and_strerror(dns, built):
     L = dns.load_library()
-    assert L.dnsplat_abi_version() == 14
+    assert L.dnsplat_abi_version() == 15
     msgs = {L.dnsplat_strerror(c).decode() for c in (0, -1, -2, -3, -4)}
     assert len(msgs) == 5 and "ok" in msgs
     assert "unknown" in L.dnsplat_strerror(-99).decode()

@@ -822,6 +822,60 @@ def test_fused_loss_matches_the_torch_loss_stack(dns, W, H):
     assert float(g_f["depth"].abs().max()) == 0.0 and float(g_f["normal"].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("W,H", [(64, 48), (75, 53), (256, 200), (11, 11), (333, 17)])
+def test_ssim_module_matches_the_torch_ssim(dns, W, H):
+    """dnsplat_ssim (ABI 15): splatfacto's SSIM module alone — value and gradient w.r.t. the rendered image == autograd over
+    torch_losses.ssim (pytorch_msssim's ten grouped conv2d calls), in fp64 on the torch side so that the comparison measures the
+    kernel and not MIOpen's summation order.  Also through the module form (``fused_loss.SSIM``: [1,3,H,W] views, either argument
+    order) and inside the otherwise-PyTorch loss stack (``dn_loss(..., ssim_impl="hip")``)."""
+    from dn_splatter_amd import torch_losses as tl
+    from dn_splatter_amd.fused_loss import SSIM, ssim_hip
+
+    g = torch.Generator().manual_seed(77 + W)
+    gt = torch.rand(H, W, 3, generator=g)
+    pred = (gt + 0.2 * torch.randn(H, W, 3, generator=g)).clamp(0, 1)
+    pred[: H // 2, : W // 2] = gt[: H // 2, : W // 2]                   # identical windows: SSIM == 1, variances cancel exactly
+    x64 = pred.double().to(DEV).requires_grad_(True)
+    s_t = tl.ssim(x64, gt.double().to(DEV))
+    s_t.backward()
+    x = pred.to(DEV).requires_grad_(True)
+    s_h = ssim_hip(x, gt.to(DEV))
+    (3.0 * s_h).backward()                                              # an upstream factor reaches the gradient
+    s_h, s_t = s_h.detach(), s_t.detach()
+    assert abs(float(s_h) - float(s_t)) <= 2e-5 * abs(float(s_t)), (float(s_h), float(s_t))
+    assert_close(x.grad / 3.0, x64.grad.float(), "d SSIM / d pred", 2e-4)
+    # value only (no gradient requested: the second launch is skipped)
+    with torch.no_grad():
+        assert float(ssim_hip(pred.to(DEV), gt.to(DEV))) == float(s_h)
+    # module form, as nerfstudio calls it: self.ssim(gt[1,3,H,W], pred[1,3,H,W])
+    m = SSIM(data_range=1.0, size_average=True, channel=3)
+    x2 = pred.to(DEV).requires_grad_(True)
+    s_m = m(gt.to(DEV).permute(2, 0, 1)[None], x2.permute(2, 0, 1)[None])
+    s_m.backward()
+    assert float(s_m.detach()) == float(s_h)
+    assert torch.equal(x2.grad * 3.0, x.grad) or float((x2.grad * 3.0 - x.grad).abs().max()) <= 1e-6 * float(x.grad.abs().max())
+    with pytest.raises(NotImplementedError):
+        SSIM(data_range=255.0)
+    if W > 11:
+        # the whole stack, every other term in PyTorch
+        batch = tl.synthetic_batch(W, H, DEV, seed=W)
+        base = {"rgb": pred, "depth": torch.rand(H, W, 1, generator=g) * 9 + 0.2, "normal": torch.rand(H, W, 3, generator=g)}
+        scales = torch.randn(100, 3, generator=g)
+
+        def run(**kw):
+            out = {k: v.clone().to(DEV).requires_grad_(True) for k, v in base.items()}
+            sc = scales.clone().to(DEV).requires_grad_(True)
+            loss = tl.dn_loss(out, batch, sc, **kw)
+            loss.backward()
+            return float(loss), {k: v.grad for k, v in out.items()}
+
+        l_t, g_t = run()
+        l_h, g_h = run(capturable=True, ssim_impl="hip")
+        assert abs(l_h - l_t) <= 2e-5 * abs(l_t)
+        for k in g_t:
+            assert_close(g_h[k], g_t[k], "hip-SSIM stack d loss / d " + k, 2e-4)
+
+
 def test_batched_render_loop_equals_sequential(dns):
     """N4: get_outputs_batch — all cameras projected, binned (camera, tile, depth) and composited in ONE launch sequence —
     returns exactly what get_outputs returns per camera."""

@@ -136,6 +136,34 @@ def test_install_replaces_get_outputs_and_hands_the_fused_pass_the_reference_arg
     assert Model.get_outputs is original and not hasattr(Model, "_dnsplat_original_get_outputs")
 
 
+def test_install_ssim_swaps_the_module_and_refuses_cpu_tensors(dns):
+    """install_ssim(model): model.ssim (dn_model.py:180) becomes fused_loss.SSIM, the old module is kept; the module has no CPU path
+    and refuses what dnsplat_ssim does not compute (other windows / ranges, batches, two differentiated arguments)."""
+    from dn_splatter_amd.fused_loss import SSIM
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.ssim = torch.nn.Identity()
+
+    m = M()
+    old = m.ssim
+    assert dns.install_ssim(m) is m and isinstance(m.ssim, SSIM) and m._dnsplat_original_ssim is old
+    dns.install_ssim(m)                                                         # idempotent
+    assert m._dnsplat_original_ssim is old
+    SSIM(data_range=1.0, kernel_size=11)                                       # the reference's constructor call
+    for kw in ({"data_range": 255.0}, {"kernel_size": 7}, {"channel": 1}, {"size_average": False}):
+        with pytest.raises(NotImplementedError):
+            SSIM(**kw)
+    a, b = torch.rand(1, 3, 20, 20), torch.rand(1, 3, 20, 20)
+    with pytest.raises(dns.DnsplatError):
+        m.ssim(a, b)                                                           # no CPU fallback
+    with pytest.raises(NotImplementedError):
+        m.ssim(torch.rand(2, 3, 20, 20), torch.rand(2, 3, 20, 20))
+    with pytest.raises(NotImplementedError):
+        m.ssim(a.requires_grad_(True), b.requires_grad_(True))
+
+
 @pytest.mark.gpu
 def test_installed_get_outputs_equals_the_renderer_mirror_on_the_gpu(dns):
     """The installed method on a stand-in model == DNSplatterRenderer(fused=True).get_outputs (the method the parity suite holds to
