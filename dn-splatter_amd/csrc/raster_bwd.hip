@@ -182,7 +182,19 @@ static_assert(!DNS_BWD_FOLD || GROUP == 16, "the folded arrays start at the DPP 
 #ifndef DNS_BWD_FLUSH_REC
 #define DNS_BWD_FLUSH_REC 16
 #endif
-constexpr int FLUSH_REC = DNS_BWD_FLUSH_REC;    // gradient records staged in LDS per round of the transposed flush
+// The group's flush as ONE pass over both splats of every lane (1) instead of an A pass and a B pass (0).  From the ISA of the two
+// passes (round 6): per 16-record round a ds_bpermute for the record's Gaussian id behind a computed lane address, a 64-bit shift of
+// the group's mask and a compare for "was this slot filled", a sign extension + 64-bit shift + 64-bit add for the record's address
+// — ten vector instructions per atomic instruction, eight atomic instructions per switch — and fourteen v_mul / v_mov per pass to
+// line the 16 sums of ONE splat up for four ds_write_b128.  Merged: the partial sums are parked as the (A, B) register pairs they
+// already are (ds_write_b64, the scale factors as packed multiplies on both splats at once), the 16 owning lanes also park the two
+// records' ADDRESSES (64-bit, formed once per record instead of once per (record, column); an unfilled slot parks -1), and every
+// lane of a round reads its (A, B) values with one ds_read_b64 and the two addresses with one ds_read_b128: a sign test and one
+// 64-bit add per atomic.
+#ifndef DNS_BWD_MERGED_FLUSH
+#define DNS_BWD_MERGED_FLUSH 1
+#endif
+[[maybe_unused]] constexpr int FLUSH_REC = DNS_BWD_FLUSH_REC;    // gradient records staged in LDS per round of the transposed flush
 constexpr int PERIOD = NPIX + GROUP - 1;        // steps from one bucket to the next: 256 pixels + GROUP - 1 idle slots
 // the step loop accumulates the mean gradient in units of the half-gradients of the exponent (splat_common.h)
 #if DNS_EXP_SYM
@@ -318,7 +330,12 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT &
     // ALIASES queue entries >= 64: while a pass is flushed only the < 64 left-over entries at the front of the queue are
     // live.  13.5 KiB per wave = 12 tiles in flight per CU (3 waves per SIMD, the VGPR limit) instead of 11.
     __shared__ int32_t queue[BUCKET + DNS_WAVE];
+#if DNS_BWD_MERGED_FLUSH
+    __shared__ f2 flush2[GROUP][DNS_REC];             // [record][column] = (splat A's sum, splat B's sum)
+    __shared__ ulonglong2 flush_addr[GROUP];          // [record] = addresses of A's and B's gradient record (or -1: slot not filled)
+#else
     __shared__ float4 flush[FLUSH_REC][4];
+#endif
 #if DNS_BWD_COORD_TABLE
     __shared__ float2 coord[NPIX];             // pixel-centre coordinates of the half tile, row-major
 #endif
@@ -500,7 +517,9 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT &
 
     const int col = lane & 15;
     const bool col_used = col < REC_CH0 + D || col >= REC_ABSX;
+#if !DNS_BWD_MERGED_FLUSH
     const float *fl = reinterpret_cast<const float *>(&flush[0][0]);
+#endif
     int prev_take = 0;
 
     for (;;) {
@@ -566,6 +585,56 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT &
             // -- flush: transpose through LDS, one atomic row per touched splat (A rows, then B rows): the group's
             //    lanes park their 16 partial sums, then the whole wave adds those records to global memory, each
             //    atomic instruction covering 4 complete 64-byte records.
+#if DNS_BWD_MERGED_FLUSH
+            {
+                static_assert(DNS_BWD_FLUSH_ALL, "the merged flush writes every filled slot");
+                const uint64_t tm = dns_ballot(cmp_a != 0x7fffffff || cmp_b != 0x7fffffff) & gmask;
+                if (tm != 0) {                                                   // wave-uniform
+                    if (mine) {
+                        const int r = lane % GROUP;
+                        // g_o / opacity through v_rcp_f32: 1 ulp on a sum whose order the atomics do not fix anyway
+                        const f2 inv_o = {__builtin_amdgcn_rcpf(opac.x), __builtin_amdgcn_rcpf(opac.y)};
+                        f2 *row = &flush2[r][0];
+                        row[0] = XY_SCALE * g_x; row[1] = XY_SCALE * g_y; row[2] = 0.5f * g_ca; row[3] = g_cb;
+                        row[4] = 0.5f * g_cc; row[5] = g_o * inv_o;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) row[REC_CH0 + k] = g_ch[k];
+                        row[REC_ABSX] = -XY_SCALE * g_ax; row[REC_ABSX + 1] = -XY_SCALE * g_ay;
+                        // DET: the row's own slot, keyed by the splat's list index (every (half tile, entry) is flushed exactly once)
+                        float *base = DET ? a.det + (size_t)part * (size_t)a.det_cap * DNS_REC : a.v_splats;
+                        ulonglong2 ad;
+                        ad.x = cmp_a != 0x7fffffff ? (unsigned long long)(uintptr_t)(base + (size_t)(DET ? cmp_a : gid_a) * DNS_REC) : ~0ull;
+                        ad.y = cmp_b != 0x7fffffff ? (unsigned long long)(uintptr_t)(base + (size_t)(DET ? cmp_b : gid_b) * DNS_REC) : ~0ull;
+                        flush_addr[r] = ad;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // byte offset of the lane's column as a 64-bit register pair, formed ONCE per flush (left alone, hipcc rebuilds the pair —
+                    // a shift and a copy of a zero — in front of each of the eight atomics)
+                    unsigned long long colb = (unsigned long long)(col * 4);
+                    asm volatile("" : "+v"(colb));
+#pragma unroll
+                    for (int j = 0; j < GROUP / 4; ++j) {
+                        const int rec = j * 4 + (lane >> 4);                     // record within the group: 16 lanes per record
+                        if (((tm >> (GROUP * grp + j * 4)) & 0xfull) == 0) continue;   // wave-uniform: none of the round's four slots is filled
+                        const ulonglong2 ad = flush_addr[rec];
+                        const f2 val = flush2[rec][col];
+                        // a device address has a clear top bit; -1 marks a slot that holds no splat
+                        const bool has_a = (int)(ad.x >> 32) >= 0, has_b = (int)(ad.y >> 32) >= 0;
+                        if (DET) {
+                            typedef __attribute__((address_space(1))) float gfloat;
+                            if (has_a) reinterpret_cast<gfloat *>((uintptr_t)ad.x)[col] = col_used ? val.x : 0.f;
+                            if (has_b) reinterpret_cast<gfloat *>((uintptr_t)ad.y)[col] = col_used ? val.y : 0.f;
+                        } else {
+                            // the addresses come back from LDS as integers: say "global memory", or the atomics are issued as flat_atomic
+                            typedef __attribute__((address_space(1))) float gfloat;
+                            if (has_a && col_used) __builtin_amdgcn_global_atomic_fadd_f32(reinterpret_cast<gfloat *>((uintptr_t)(ad.x + colb)), val.x);
+                            if (has_b && col_used) __builtin_amdgcn_global_atomic_fadd_f32(reinterpret_cast<gfloat *>((uintptr_t)(ad.y + colb)), val.y);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+#else
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
 #if DNS_BWD_FLUSH_ALL
@@ -613,6 +682,7 @@ __global__ __launch_bounds__(DNS_WAVE) DNS_BWD_OCCUPANCY(DN && MASKS && !COUNT &
                 }
 #undef SEL
             }
+#endif
             // -- the group's new splats, as packed pairs
             if (mine) {
 #if DNS_BWD_FOLD
