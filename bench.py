@@ -307,6 +307,13 @@ def make_scene(N, dev, scene="reference_init", seed=0):
         with torch.no_grad():
             gp["scales"] += torch.randn(N, 3, device=dev, generator=g) * 0.6
             gp["opacities"] += torch.randn(N, 1, device=dev, generator=g) * 2.0
+    elif scene == "morton":
+        # the reference's initialisation with its rows laid out along a Morton curve (densify.spatial_order: what
+        # refinement_after(spatial_reorder=True) leaves behind) — the same Gaussians, the same images, other memory order
+        from dn_splatter_amd import densify
+
+        new, _ = densify.reorder(gp, densify.spatial_order(gp["means"]))
+        gp = {k: (v.contiguous().requires_grad_(True) if k != "normals" else v.contiguous()) for k, v in new.items()}
     elif scene != "reference_init":
         raise ValueError(scene)
     return gp
@@ -491,6 +498,9 @@ def child_workload(workload, losses, steps, scene=None):
         cmd += ["--scene", scene]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
                                                             "DNSPLAT_FORCE_DIST")}
+    if scene == "morton":
+        # rows along the curve AND the bucket's zero rows tracked: wholly culled workgroups of the projection backward write nothing
+        env["DNSPLAT_SH_ZERO_STATE"] = "1"
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=CHILD_TIMEOUT_S, env=env)
         d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -556,7 +566,7 @@ def main():
     ap.add_argument("--no-strict", action="store_true", help="skip the index-exact (gsplat tile boxes) section after the timed region")
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="skip the short C3 / C5 / C5-with-fused-losses sections a default C2 run appends (extra_workloads in the JSON line)")
-    ap.add_argument("--scene", default="reference_init", choices=["reference_init", "anisotropic"],
+    ap.add_argument("--scene", default="reference_init", choices=["reference_init", "anisotropic", "morton"],
                     help="reference_init: the reference's random initialisation (BASELINE.md); anisotropic: the parity suite's "
                          "anisotropic / spread-opacity scene at the workload's size (make_scene)")
     ap.add_argument("--section", default=None, choices=["train_loop"],
@@ -946,6 +956,11 @@ def main():
             # the north star's C5 ("depth + mono-normal loss enabled", losses in PyTorch-ROCm: regularization_strategy.py:146-199,
             # losses.py:187-224) is c5_torch_loss; c5_fused_loss is the same loss stack as two HIP launches (N2)
             extras["c2_anisotropic"] = child_workload("c2", None, max(5, min(10, args.steps)), scene="anisotropic")
+            # the SAME Gaussians as the headline / c5 with their rows laid out along a Morton curve (densify.spatial_order, what
+            # refinement_after(spatial_reorder=True) leaves behind) and DNSPLAT_SH_ZERO_STATE=1: the per-Gaussian kernels then move
+            # close to their algorithmic bytes (a camera's culled Gaussians are whole workgroups)
+            extras["c2_morton"] = child_workload("c2", None, max(5, min(10, args.steps)), scene="morton")
+            extras["c5_morton"] = child_workload("c5", None, max(5, min(10, args.steps)), scene="morton")
             extras["c2_train_loop"] = child_section("train_loop", 200)
 
     # ---- multi-GPU accounting, all outside the timed region ----------------------------------------

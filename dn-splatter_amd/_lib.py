@@ -135,6 +135,7 @@ class ProjGrads(ctypes.Structure):
         ("sh_grads_skip", c_int32),
         ("sh_factors", c_void_p),
         ("sh_grad_scale", c_float), ("sh_zero_state", c_void_p), ("sh_packed", c_void_p),
+        ("zero_state_geometry", c_int32),
     ]
 
 

@@ -581,6 +581,7 @@ class _ProjectFn(torch.autograd.Function):
                   and C == 1 and GRAD_ARENA.holds(v_sh0) and GRAD_ARENA.holds(v_shN)):
                 # the rows land in the flat bucket, whose zero rows are tracked: a Gaussian that is culled again is not re-zeroed
                 g.sh_zero_state = _ptr(GRAD_ARENA.sh_state)
+                g.zero_state_geometry = int(all(GRAD_ARENA.holds(t) for t in (v_means, v_quats, v_scales, v_opac)))
             _lib.run("dnsplat_project_bwd", _lib.lib().dnsplat_project_bwd, ctypes.byref(scene), ctypes.byref(cam), ctypes.byref(fwd),
                      ctypes.byref(g), _stream())
             outs = [v_means, v_quats, v_scales, v_opac, v_coeffs, v_sh0, v_shN, v_colors]

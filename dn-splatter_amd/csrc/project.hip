@@ -796,7 +796,16 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) DNS_PROJ_BWD_OCC void project_bwd
     uint64_t zero_known = 0ull;
     const bool track_zero = SH_STAGE_THREADS == DNS_WAVE && p.g.sh_zero_state != nullptr && !sh_elsewhere && p.s.sh_degree >= 0;
     if (track_zero) zero_known = p.g.sh_zero_state[blockIdx.x];
-    const bool my_row_stays_zero = ((zero_known & ~vis_rows) >> threadIdx.x) & 1ull;   // culled now, zero in memory already
+#ifndef DNS_PROJ_ZERO_ROWS
+#define DNS_PROJ_ZERO_ROWS 0
+#endif
+    // every row of the workgroup is culled now and zero in memory already (wave-uniform): nothing of it needs writing
+    const bool wg_stays_zero = track_zero && (vis_rows | ~zero_known) == 0ull;
+    // DNS_PROJ_ZERO_ROWS = 1 (round 6, first form): rows skipped one by one — the workgroup's one streaming store becomes 16-byte
+    // pieces with holes (partial lines) and the kernel gets 5-10 % SLOWER for 10 % fewer bytes (profiles/r06_ab_per_gaussian.txt).
+    // 0: all or nothing per workgroup.  In a random row order every 64 rows hold a visible one and nothing is ever skipped; along a
+    // Morton curve (densify.spatial_order) a camera's culled Gaussians are whole workgroups.
+    const bool my_row_stays_zero = DNS_PROJ_ZERO_ROWS ? (((zero_known & ~vis_rows) >> threadIdx.x) & 1ull) != 0ull : wg_stays_zero;
     if (L != SH_DIRECT) {
         const float *base = (L == SH_CAT ? p.s.sh0 : p.s.shN) + (size_t)g0 * ShRowTraits<L>::ROW;
         if (VISIBLE_ROWS && DNS_PROJ_BWD_ROWS_IN) sh_stage_in_rows<L>(base, nG * ShRowTraits<L>::ROW, sh_lds, vis_rows);
@@ -1080,10 +1089,12 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) DNS_PROJ_BWD_OCC void project_bwd
         for (int i = 0; i < 4; ++i) v_quat[i] = (vqn[i] - dot * st.qn[i]) * st.inv_norm;
     }
 
+    if (!(wg_stays_zero && p.g.zero_state_geometry)) {     // dnsplat_proj_grads.zero_state_geometry: these rows are tracked too
     p.g.v_means[3 * g] = v_mean[0]; p.g.v_means[3 * g + 1] = v_mean[1]; p.g.v_means[3 * g + 2] = v_mean[2];
     p.g.v_quats[4 * g] = v_quat[0]; p.g.v_quats[4 * g + 1] = v_quat[1]; p.g.v_quats[4 * g + 2] = v_quat[2]; p.g.v_quats[4 * g + 3] = v_quat[3];
     p.g.v_scales[3 * g] = v_scale[0]; p.g.v_scales[3 * g + 1] = v_scale[1]; p.g.v_scales[3 * g + 2] = v_scale[2];
     p.g.v_opacities[g] = v_opac;
+    }
     if (p.g.sh_packed) {
         // packed slab (dnsplat_visible_index wrote header, masks and offsets from the same radii): rows of the visible Gaussians only
         const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.g.sh_packed);
@@ -1110,8 +1121,9 @@ __global__ __launch_bounds__(SH_STAGE_THREADS) DNS_PROJ_BWD_OCC void project_bwd
     if (L != SH_DIRECT && !p.g.sh_grads_skip) {
         __syncthreads();
         float *base = (L == SH_CAT ? p.g.v_sh0 : p.g.v_shN) + (size_t)g0 * ShRowTraits<L>::ROW;
-        // rows to store: the visible ones and the culled ones whose memory is not known to be zero
-        if (VISIBLE_ROWS && track_zero) sh_stage_out_rows<L>(base, nG * ShRowTraits<L>::ROW, sh_lds, vis_rows | ~zero_known);
+        // rows to store: the visible ones and the culled ones whose memory is not known to be zero (see wg_stays_zero)
+        if (VISIBLE_ROWS && track_zero && DNS_PROJ_ZERO_ROWS) sh_stage_out_rows<L>(base, nG * ShRowTraits<L>::ROW, sh_lds, vis_rows | ~zero_known);
+        else if (VISIBLE_ROWS && wg_stays_zero) { /* nothing */ }
         else sh_stage_out<L>(base, nG * ShRowTraits<L>::ROW, sh_lds);
     }
     // what memory holds now: zero rows exactly where the Gaussian is culled (lanes beyond N: bits unused)

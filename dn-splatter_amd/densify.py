@@ -145,15 +145,57 @@ def split_children(gauss_params: Dict[str, Tensor], parents: Tensor, noise: Tens
     return new_means, new_scales
 
 
+def spatial_order(means: Tensor, bits: int = 10) -> Tensor:
+    """int64 [N] permutation that lays the Gaussians out along a 3-D Morton (Z-order) curve over the bounding box of their means
+    (``bits`` per axis).  The order of the rows of the parameter tensors means nothing to the reference (densification appends and
+    culls, dn_model.py:309-357), but it decides what the per-Gaussian kernels move: a camera culls ~28 % of the benchmark scenes'
+    Gaussians, and in a random order every 64-Gaussian workgroup of ``dnsplat_project_fwd`` / ``_bwd`` holds a few of them, whose SH
+    rows share their cache lines with visible neighbours (1.3 x the algorithmic bytes).  Along the curve any
+    frustum cuts the rows into a few contiguous runs: workgroups are all visible or all culled.  Pure torch (one sort); identical on
+    every rank for identical parameters (stable sort on integer keys)."""
+    m = torch.nan_to_num(means.detach().float())
+    lo, hi = m.amin(0), m.amax(0)
+    top = (1 << bits) - 1
+    q = ((m - lo) / (hi - lo).clamp_min(1e-30) * top).to(torch.int64).clamp_(0, top)
+
+    def spread(v):                      # bit i -> bit 3 i (bits <= 21)
+        out = torch.zeros_like(v)
+        for i in range(bits):
+            out |= ((v >> i) & 1) << (3 * i)
+        return out
+
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    return torch.sort(code, stable=True)[1]
+
+
+def reorder(gauss_params: Dict[str, Tensor], perm: Tensor, adam_state: Optional[Dict[str, Dict[str, Tensor]]] = None):
+    """Rows of every per-Gaussian tensor (parameters, ``normals``, Adam moments) gathered in the order ``perm``.  Returns
+    ``(new_gauss_params, new_adam_state)`` as plain tensors, like ``refinement_after``; per-Gaussian statistics
+    (``DensifyStats``) belong to the old order and start over (``after_refinement``)."""
+    n = int(perm.shape[0])
+    with torch.no_grad():
+        new_params = {k: (v.detach().index_select(0, perm) if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n else v)
+                      for k, v in gauss_params.items()}
+        new_adam = adam_state
+        if adam_state is not None:
+            new_adam = {name: {key: (t.index_select(0, perm) if torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == n else t)
+                               for key, t in st.items()} for name, st in adam_state.items()}
+    return new_params, new_adam
+
+
 def refinement_after(gauss_params: Dict[str, Tensor], stats: Optional[DensifyStats], cfg: RefineConfig, step: int,
                      num_train_data: int, last_size, adam_state: Optional[Dict[str, Dict[str, Tensor]]] = None,
-                     seed: int = 0, classify_fn: Optional[Callable] = None, split_fn: Optional[Callable] = None):
+                     seed: int = 0, classify_fn: Optional[Callable] = None, split_fn: Optional[Callable] = None,
+                     spatial_reorder: bool = False):
     """One refinement step (dn_model.py:271-386) on device.  Returns ``(new_gauss_params, new_adam_state, report)`` —
     plain tensors (the caller re-wraps them as Parameters / re-seats the optimizer state, as nerfstudio's
     dup_in_all_optim / remove_from_all_optim do); ``report`` counts what happened.  ``stats`` must already be combined
     across ranks (``DensifyStats.allreduce``); ``seed`` (plus the step) seeds the split noise identically on every rank.
     ``classify_fn`` / ``split_fn`` exist so that tests can run this very function over another implementation of the two
-    kernels; the package only ever passes its HIP ones."""
+    kernels; the package only ever passes its HIP ones.
+    ``spatial_reorder``: whenever the set changed (rows were appended / removed anyway), lay the new set out along the Morton curve
+    (``spatial_order``; the reference appends children and duplicates at the end — the result is then a permutation of the
+    reference's, ``report["perm"]``)."""
     classify_fn = classify_fn or classify
     split_fn = split_fn or split_children
     report = dict(step=step, n_before=int(gauss_params["means"].shape[0]), n_split=0, n_dup=0, n_culled=0, opacity_reset=False)
@@ -229,6 +271,10 @@ def refinement_after(gauss_params: Dict[str, Tensor], stats: Optional[DensifySta
                 new_adam["opacities"] = {k: (torch.zeros_like(v) if k in ("exp_avg", "exp_avg_sq") else v)
                                          for k, v in new_adam["opacities"].items()}
             report["opacity_reset"] = True
+        if spatial_reorder and (do_densify or cull_only):
+            perm = spatial_order(params["means"])
+            params, new_adam = reorder(params, perm, new_adam)
+            report["perm"] = perm
     report["n_after"] = int(params["means"].shape[0])
     return params, new_adam, report
 

@@ -49,7 +49,8 @@ extern "C" {
  * dnsplat_proj_out.skip_culled_records, dnsplat_proj_grads.sh_grad_scale / sh_zero_state (own-camera SH rows in the exchange step;
  * gradient rows of persistently culled Gaussians are not re-zeroed), dnsplat_sh_grads_add_factors, the packed (visible rows only)
  * colour-gradient slabs: dnsplat_visible_index, dnsplat_proj_grads.sh_packed, dnsplat_sh_grads_from_packed; 15 = dnsplat_ssim (the
- * SSIM term alone, for a loss stack that otherwise stays in PyTorch). */
+ * SSIM term alone, for a loss stack that otherwise stays in PyTorch), dnsplat_proj_grads.zero_state_geometry (zero gradient rows of
+ * culled Gaussians skipped per workgroup). */
 #define DNSPLAT_ABI_VERSION 15
 #define DNSPLAT_RECORD_FLOATS 16
 #define DNSPLAT_MAX_CHANNELS 8
@@ -493,6 +494,12 @@ typedef struct dnsplat_proj_grads {
                                     the same radii (see there): the launch fills its rows — the colour gradients of the VISIBLE Gaussians
                                     only, row offsets[g / 64] + popcount(mask bits below g % 64) — beside or instead of sh_factors.  Whole
                                     scenes only (the slices of dp.SlicedShExchange keep dense slabs). */
+    int32_t zero_state_geometry; /* ABI 15.  1: the words of sh_zero_state describe ALL gradient rows of a Gaussian that this launch writes —
+                                    v_means / v_quats / v_scales / v_opacities beside the coefficient rows (their owner keeps the same
+                                    contract for them).  Rows are then skipped per WORKGROUP of 64 Gaussians, all or nothing: a workgroup
+                                    whose rows are all culled now and all known zero writes nothing at all (236 B per Gaussian); any other
+                                    workgroup stores its whole span as without the state.  Pays when the rows follow a space-filling
+                                    curve (densify.spatial_order: a camera's culled Gaussians are then runs of rows). */
 } dnsplat_proj_grads;
 
 int dnsplat_project_bwd(const dnsplat_scene *scene, const dnsplat_camera *cam,

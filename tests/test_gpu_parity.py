@@ -876,6 +876,43 @@ def test_ssim_module_matches_the_torch_ssim(dns, W, H):
             assert_close(g_h[k], g_t[k], "hip-SSIM stack d loss / d " + k, 2e-4)
 
 
+def test_spatially_reordered_gaussians_render_the_same_frame(dns):
+    """densify.spatial_order / reorder (what refinement_after(spatial_reorder=True) leaves behind): the same Gaussians in another
+    row order give the same images — bit for bit in deterministic mode's forward (the depth sort decides the blend order, rows
+    only break exact depth ties) — the same per-Gaussian outputs row for row under the permutation, and the same parameter
+    gradients up to the order of the fp32 atomics."""
+    from dn_splatter_amd import densify, synthetic
+
+    N, W, H = 60_000, 320, 240
+    gp = synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=9, device=DEV)
+    perm = densify.spatial_order(gp["means"])
+    assert perm.device.type == "cuda" and torch.equal(torch.sort(perm)[0], torch.arange(N, device=DEV))
+    new, _ = densify.reorder(gp, perm)
+    gq = {k: (v.clone().requires_grad_(True) if k != "normals" else v) for k, v in new.items()}
+    cam = synthetic.orbit_camera(1, width=W, height=H, focal=200.0).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    cot = {k: torch.randn(H, W, c, generator=g).to(DEV) for k, c in (("rgb", 3), ("depth", 1), ("normal", 3))}
+
+    def run(params):
+        m = dns.DNSplatterRenderer(params, fused=True)
+        out = m.get_outputs(cam)
+        torch.autograd.backward([out[k] for k in cot], [cot[k] for k in cot])
+        return out, m
+
+    out_a, m_a = run(gp)
+    out_b, m_b = run(gq)
+    for k in ("rgb", "depth", "normal", "surface_normal", "accumulation"):
+        assert_close(out_b[k], out_a[k], "reordered " + k, 1e-6)
+    assert torch.equal(m_b.radii, m_a.radii[perm]) and torch.equal(m_b.num_tiles_hit.reshape(-1), m_a.num_tiles_hit.reshape(-1)[perm])
+    for k in ("means", "quats", "scales", "opacities", "features_dc", "features_rest"):
+        assert_close(gq[k].grad, gp[k].grad[perm], "reordered d/d " + k, 1e-4)
+    # the culled rows are runs along the curve: far fewer 64-row workgroups hold both kinds
+    def mixed(radii):
+        b = (radii[: (N // 64) * 64] > 0).view(-1, 64).float().mean(1)
+        return float(((b > 0) & (b < 1)).float().mean())
+    assert mixed(m_b.radii) < 0.5 * mixed(m_a.radii)
+
+
 def test_batched_render_loop_equals_sequential(dns):
     """N4: get_outputs_batch — all cameras projected, binned (camera, tile, depth) and composited in ONE launch sequence —
     returns exactly what get_outputs returns per camera."""
@@ -1128,8 +1165,9 @@ def test_own_rows_and_visible_row_slabs_equal_the_dense_mean(dns, packed):
         ex_small.meta = None
 
 
+@pytest.mark.parametrize("order", ["random", "morton"])
 @pytest.mark.usefixtures("hip_deterministic")
-def test_zero_rows_of_persistently_culled_gaussians_are_not_rewritten_and_stay_exact(dns, monkeypatch):
+def test_zero_rows_of_persistently_culled_gaussians_are_not_rewritten_and_stay_exact(dns, monkeypatch, order):
     """with the gradients in a dp.GradArena the projection backward skips the zero SH rows of Gaussians that
     were culled before and are culled again (dnsplat_proj_grads.sh_zero_state).  A pose sequence in which Gaussians enter and leave
     the frustum must give, frame by frame, the bits of the run without the bucket — in particular a Gaussian visible in frame k
@@ -1138,6 +1176,13 @@ def test_zero_rows_of_persistently_culled_gaussians_are_not_rewritten_and_stay_e
 
     N, W, H = 30_000, 320, 240
     gp = synthetic.make_gauss_params(N, sh_rest_std=0.2, seed=6, device=DEV)
+    if order == "morton":
+        # rows along a Morton curve (densify.spatial_order): a camera's culled Gaussians are runs of rows, whole 64-row workgroups
+        # are culled and — second time round — written by nobody (sh_zero_state + zero_state_geometry: all or nothing per workgroup)
+        from dn_splatter_amd import densify
+
+        new, _ = densify.reorder(gp, densify.spatial_order(gp["means"]))
+        gp = {k: (v.contiguous().requires_grad_(True) if k != "normals" else v.contiguous()) for k, v in new.items()}
     cams = [synthetic.orbit_camera(v, width=W, height=H, focal=260.0).to(DEV) for v in (0, 3, 0, 5, 3)]
     m = dns.DNSplatterRenderer(gp, fused=True)
 
@@ -1150,7 +1195,6 @@ def test_zero_rows_of_persistently_culled_gaussians_are_not_rewritten_and_stay_e
         return {k: gp[k].grad.clone() for k in GRAD_NAMES}, m.radii.clone()
 
     plain = [frame(c) for c in cams]
-    assert dp.GradArena(gp).sh_state is None      # off by default: measured slower than re-writing the rows (profiles/r06_ab_per_gaussian.txt)
     monkeypatch.setenv("DNSPLAT_SH_ZERO_STATE", "1")
     arena = dp.GradArena(gp)
     assert arena.sh_state is not None and bool((arena.sh_state == -1).all())       # zero-filled bucket: every row known zero
@@ -1172,12 +1216,32 @@ def test_zero_rows_of_persistently_culled_gaussians_are_not_rewritten_and_stay_e
             for b in range(64):
                 bits[b::64] = ((words >> b) & 1).bool()
             assert torch.equal(bits[:N], ~vis), f"frame {i}: sh_zero_state does not describe the bucket"
+            if order == "morton":
+                culled_wgs = int((~vis[: (N // 64) * 64]).view(-1, 64).all(dim=1).sum())
+                assert culled_wgs >= 8, culled_wgs                    # there ARE wholly culled workgroups (the skip is checked below)
         # an in-place all-reduce of the bucket (or any foreign write) must be followed by invalidate_sh_state(): after it every row is
         # written again
         arena.view("features_rest").fill_(7.0)
+        arena.view("means").fill_(7.0)
         arena.invalidate_sh_state()
         g, radii = frame(cams[1])
-        assert torch.equal(g["features_rest"], plain[1][0]["features_rest"])
+        for k in GRAD_NAMES:
+            assert torch.equal(g[k], plain[1][0][k]), k
+        if order == "morton":
+            # the same frame again: workgroups that are wholly culled are written by NOBODY now — a mark left in their rows survives
+            vis = radii > 0
+            wg_culled = (~vis[: (N // 64) * 64]).view(-1, 64).all(dim=1)
+            rows = wg_culled.repeat_interleave(64)
+            for k in GRAD_NAMES:
+                gp[k].grad = None
+            arena.view("means")[: rows.numel()][rows] = 5.0
+            arena.view("features_rest")[: rows.numel()][rows] = 5.0
+            out = m.get_outputs(cams[1])
+            (out["rgb"].sum() + out["depth"].sum() + out["normal"].sum()).backward()
+            torch.cuda.synchronize()
+            assert bool((gp["means"].grad[: rows.numel()][rows] == 5.0).all()) and bool((gp["features_rest"].grad[: rows.numel()][rows] == 5.0).all())
+            assert torch.equal(gp["means"].grad[: rows.numel()][~rows], plain[1][0]["means"][: rows.numel()][~rows])
+            arena.flat.zero_()
     finally:
         dns.set_grad_arena(None)
 

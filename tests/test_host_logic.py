@@ -194,6 +194,60 @@ def test_refinement_step_equals_the_reference_sequence(step, kw):
         assert float(new_adam["opacities"]["exp_avg"].abs().max()) == 0.0
 
 
+def test_spatial_reorder_is_a_permutation_of_the_reference_refinement():
+    """densify.spatial_order / reorder / refinement_after(spatial_reorder=True): a Morton-curve layout of the rows.  The refined set
+    is the reference's refined set row for row under report["perm"] (parameters, normals, Adam moments); the order is a bijection,
+    neighbouring rows are neighbours in space, and what a frustum culls are runs of rows, not scattered ones."""
+    from dn_splatter_amd import densify, synthetic
+    from oracle import densify_ref as ref
+
+    N = 4000
+    gp = {k: v.detach() for k, v in synthetic.make_gauss_params(N, sh_rest_std=0.1, seed=1).items()}
+    g = torch.Generator().manual_seed(2)
+    gp["scales"] = gp["scales"] + torch.randn(N, 3, generator=g) * 1.5 - 3.5
+    gp["opacities"] = gp["opacities"] + torch.randn(N, 1, generator=g) * 2
+    gp["normals"] = torch.randn(N, 3, generator=g)
+    stats = densify.DensifyStats(N, "cpu")
+    stats.xys_grad_norm = torch.rand(N, generator=g) * 0.01
+    stats.vis_counts = torch.randint(1, 5, (N,), generator=g).float()
+    stats.max_2Dsize = torch.rand(N, generator=g) * 0.1
+    adam = {k: {"exp_avg": torch.randn(v.shape, generator=g), "exp_avg_sq": torch.rand(v.shape, generator=g), "step": torch.tensor(7.0)}
+            for k, v in gp.items() if k != "normals"}
+    cfg = densify.RefineConfig()
+    kw = dict(adam_state=adam, seed=3, classify_fn=ref.classify_torch, split_fn=ref.split_children_torch)
+    plain, plain_adam, rep0 = densify.refinement_after(gp, stats, cfg, 3500, 100, (480, 640), **kw)
+    new, new_adam, rep = densify.refinement_after(gp, stats, cfg, 3500, 100, (480, 640), spatial_reorder=True, **kw)
+    perm = rep["perm"]
+    assert "perm" not in rep0 and rep["n_after"] == rep0["n_after"] == perm.shape[0]
+    assert torch.equal(torch.sort(perm)[0], torch.arange(perm.shape[0]))
+    for k in plain:
+        assert torch.equal(new[k], plain[k][perm]), k
+    for k in adam:
+        assert torch.equal(new_adam[k]["exp_avg"], plain_adam[k]["exp_avg"][perm]) and float(new_adam[k]["step"]) == 7.0
+    # warm-up (nothing changes): no reorder either
+    same, _, rep_w = densify.refinement_after(gp, stats, cfg, 400, 100, (480, 640), spatial_reorder=True, **kw)
+    assert same is gp and "perm" not in rep_w
+    # locality of the curve on the reference's initialisation
+    big = synthetic.make_gauss_params(100_000, seed=0)
+    order = densify.spatial_order(big["means"])
+    assert torch.equal(order, densify.spatial_order(big["means"]))               # deterministic (every rank gets the same order)
+    m, _ = densify.reorder(big, order)
+    step_sorted = (m["means"][1:] - m["means"][:-1]).norm(dim=1).mean()
+    step_random = (big["means"][1:] - big["means"][:-1]).norm(dim=1).mean()
+    assert float(step_sorted) < 0.06 * float(step_random)
+    cam = synthetic.orbit_camera(0)
+    R, t = cam.camera_to_worlds[0][:, :3], cam.camera_to_worlds[0][:, 3]
+
+    def mixed_blocks(means):
+        pc = (means.detach() - t) @ R
+        z = -pc[:, 2]
+        vis = (z > 0.01) & ((pc[:, 0] / z * cam.fx).abs() < cam.cx * 1.15) & ((pc[:, 1] / z * cam.fy).abs() < cam.cy * 1.15)
+        b = vis[: (means.shape[0] // 64) * 64].view(-1, 64).float().mean(1)
+        return float(((b > 0) & (b < 1)).float().mean())
+
+    assert mixed_blocks(big["means"]) > 0.99 and mixed_blocks(m["means"]) < 0.3
+
+
 def test_bench_gpus_n_starts_n_ranks():
     """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run with two ranks (gloo here:
     no GPU) and refuses to print a line for fewer ranks than it was asked for (a single-GPU run must never be
