@@ -132,6 +132,49 @@ def extract_method(path, cls, name):
     raise KeyError(f"{cls}.{name} not found in {path}")
 
 
+def extract_function(path, name):
+    """Source text of the module-level function ``name`` in the file at ``path``."""
+    import ast
+
+    src = open(path).read()
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            return ast.get_source_segment(src, node, padded=True)
+    raise KeyError(f"{name} not found in {path}")
+
+
+def helpers_case(path, N=48, seed=29):
+    """The module-level plain-torch helpers of dn_model.py, executed from their own text: they state the conventions the gsplat
+    symbols are USED with, in the reference's own words —
+      * ``random_quat_tensor`` (:1497-1509) with a seeded generator: the initial rotations;
+      * ``SH2RGB`` (:1512-1517): band 0 of the SH colour is ``0.28209479177387814 * coefficient + 0.5``;
+      * ``rotate_vector_to_vector`` + ``matrix_to_quaternion`` (:1520-1600, the normal initialisation of :200-218): quaternions
+        are (w, x, y, z) and ``quat_to_rotmat(matrix_to_quaternion(R)) == R`` — the file feeds these quaternions to gsplat's
+        ``quat_to_rotmat`` (:34, :552, :1199) and reads the columns of the result as the Gaussian's axes;
+      * ``invert_quaternion`` (:1615-1626): the inverse rotation is the conjugate in that convention;
+      * ``scale_rot_to_inv_cov3d`` (:1603-1612) with quat_to_rotmat supplied by the caller: Sigma^-1 = R diag(1/s^2) R^T."""
+    import math
+
+    src = os.path.join(REF, "dn_splatter/dn_model.py")
+    ns = {"torch": torch, "math": math, "Tensor": torch.Tensor, "quat_to_rotmat": quat_to_rotmat_published}
+    for fn in ("random_quat_tensor", "SH2RGB", "rotate_vector_to_vector", "matrix_to_quaternion", "invert_quaternion",
+               "scale_rot_to_inv_cov3d"):
+        exec(compile(extract_function(src, fn), src + ":" + fn, "exec"), ns)
+    g = torch.Generator().manual_seed(seed)
+    quats0 = ns["random_quat_tensor"](N, generator=torch.Generator().manual_seed(seed + 1))
+    sh = torch.randn(N, 3, generator=g) * 2
+    v1 = torch.randn(N, 3, generator=g)
+    v2 = torch.randn(N, 3, generator=g)
+    R = ns["rotate_vector_to_vector"](v1, v2)
+    q = ns["matrix_to_quaternion"](R)
+    scale = torch.rand(N, 3, generator=g) * 0.5 + 0.01
+    np.savez_compressed(path, N=N, seed=seed, random_quats=quats0.numpy(), sh=sh.numpy(), sh2rgb=ns["SH2RGB"](sh).numpy(),
+                        v1=v1.numpy(), v2=v2.numpy(), R=R.numpy(), quat_of_R=q.numpy(),
+                        quat_inverse=ns["invert_quaternion"](q).numpy(), scale=scale.numpy(),
+                        inv_cov3d=ns["scale_rot_to_inv_cov3d"](scale, q).numpy())
+    print("wrote", path)
+
+
 class StubCameras:
     """What get_outputs reads from nerfstudio.cameras.Cameras (dn_model.py:417-421, 474-479, 585-597)."""
 
@@ -454,6 +497,7 @@ def refinement_case(path, N=200, seed=23):
 
 if __name__ == "__main__":
     cam_mod, nrm_mod, los_mod = load_reference()
+    helpers_case(os.path.join(HERE, "reference_helpers.npz"))
     depth_normal_case(nrm_mod, os.path.join(HERE, "reference_depth_normal.npz"))
     loss_case(los_mod, os.path.join(HERE, "reference_losses.npz"))
     get_outputs_case(nrm_mod, os.path.join(HERE, "reference_get_outputs.npz"))

@@ -867,7 +867,7 @@ def test_ssim_module_matches_the_torch_ssim(dns, W, H):
             sc = scales.clone().to(DEV).requires_grad_(True)
             loss = tl.dn_loss(out, batch, sc, **kw)
             loss.backward()
-            return float(loss), {k: v.grad for k, v in out.items()}
+            return float(loss.detach()), {k: v.grad for k, v in out.items()}
 
         l_t, g_t = run()
         l_h, g_h = run(capturable=True, ssim_impl="hip")

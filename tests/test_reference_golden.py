@@ -43,7 +43,7 @@ def test_loss_terms_equal_the_reference():
     pn = torch.from_numpy(g["pred_normal"]).requires_grad_(True)
 
     def check(value, wrt, key, tol=2e-6):
-        assert abs(float(value) - float(g[key])) < tol * max(1.0, abs(float(g[key]))), key
+        assert abs(float(value.detach()) - float(g[key])) < tol * max(1.0, abs(float(g[key]))), key
         (gr,) = torch.autograd.grad(value, wrt)
         ref = torch.from_numpy(g[key + "_grad"])
         assert float((gr - ref).abs().max()) < tol * max(1.0, float(ref.abs().max())), key + " gradient"
@@ -54,6 +54,76 @@ def test_loss_terms_equal_the_reference():
     # the plain terms the strategy falls back to (losses.py:154-185): trivial, pinned for completeness
     check(torch.log(1 + (pred - gt).abs()).mean(), pred, "logl1_scalar")
     check((pred - gt).abs().mean(), pred, "l1_scalar")
+
+
+def test_conventions_stated_by_the_reference_helpers():
+    """dn_model.py's own module-level torch helpers (executed from their text: golden/reference_helpers.npz) state the conventions
+    the un-vendored gsplat symbols are used with.  Pinned to them: the quaternion -> rotation map of the package, of the oracle and
+    of the stand-in the get_outputs fixture was generated with (w, x, y, z; R, not its transpose: ``quat_to_rotmat(
+    matrix_to_quaternion(R)) == R`` for the reference's own matrix_to_quaternion, :1554-1600), the conjugate as inverse (:1615-1626),
+    Sigma^-1 = R diag(1 / s^2) R^T (:1603-1612), band 0 of the SH colour (SH2RGB, :1512-1517: C0 x coefficient + 0.5) and the seeded
+    initial rotations (random_quat_tensor, :1497-1509)."""
+    import dn_splatter_amd as dns
+    from dn_splatter_amd import synthetic
+    from oracle import oracle as orc
+
+    g = _load("reference_helpers.npz")
+    N, seed = int(g["N"]), int(g["seed"])
+    R, q = torch.from_numpy(g["R"]), torch.from_numpy(g["quat_of_R"])
+    assert torch.allclose(q.norm(dim=-1), torch.ones(N), atol=1e-5)
+    for name, fn in (("package", dns.quat_to_rotmat), ("oracle", orc.quat_to_rotmat)):
+        got = fn(q)
+        assert float((got - R).abs().max()) < 5e-6, name
+        assert float((fn(torch.from_numpy(g["quat_inverse"])) - R.transpose(1, 2)).abs().max()) < 5e-6, name
+        M = got * (1.0 / torch.from_numpy(g["scale"]).clamp(min=1e-3))[:, None, :]
+        ref = torch.from_numpy(g["inv_cov3d"])
+        assert float((M @ M.transpose(1, 2) - ref).abs().max()) < 2e-5 * float(ref.abs().max()), name
+    # the rotation really moves v1 onto v2 (rotate_vector_to_vector, the normal initialisation dn_model.py:200-218)
+    v1, v2 = torch.from_numpy(g["v1"]), torch.from_numpy(g["v2"])
+    moved = torch.bmm(dns.quat_to_rotmat(q), torch.nn.functional.normalize(v1, dim=-1)[:, :, None])[:, :, 0]
+    assert float((moved - torch.nn.functional.normalize(v2, dim=-1)).abs().max()) < 1e-5
+    # SH band 0: what gsplat's rasterization() makes of degree-0 coefficients, clamp_min(SH + 0.5, 0), is clamp_min(SH2RGB, 0)
+    sh = torch.from_numpy(g["sh"])
+    dirs = torch.nn.functional.normalize(torch.randn(N, 3, generator=torch.Generator().manual_seed(1)), dim=-1)
+    col = orc.sh_fwd(0, dirs, sh[:, None, :].contiguous())
+    assert float((col + 0.5 - torch.from_numpy(g["sh2rgb"])).abs().max()) < 1e-6
+    # seeded initial rotations: same variates, same order, same formula
+    mine = synthetic.random_quat_tensor(N, generator=torch.Generator().manual_seed(seed + 1))
+    assert torch.equal(mine, torch.from_numpy(g["random_quats"]))
+
+
+@pytest.mark.gpu
+def test_hip_projection_follows_the_reference_helpers_conventions():
+    """The same fixture through the HIP projection: Gaussians whose rotations are the reference's matrix_to_quaternion(R) report the
+    column of R that belongs to their smallest scale as their normal (A7, dn_model.py:543-556) and degree-0 SH2RGB colours."""
+    from dn_splatter_amd import _ops, fused, synthetic
+    from dn_splatter_amd._ops import ProjCfg
+
+    g = _load("reference_helpers.npz")
+    dev = "cuda:0"
+    N = int(g["N"])
+    R, q = torch.from_numpy(g["R"]), torch.from_numpy(g["quat_of_R"])
+    gen = torch.Generator().manual_seed(4)
+    means = (torch.rand(N, 3, generator=gen) - 0.5) * 2.0
+    scales = torch.from_numpy(g["scale"])
+    sh0 = torch.from_numpy(g["sh"]) * 0.5
+    cam = synthetic.orbit_camera(0, width=64, height=48, focal=40.0).to(dev)
+    viewmat, K, nf = _ops.camera_prepare(cam.camera_to_worlds[0], cam.fx, cam.fy, cam.cx, cam.cy)
+    cfg = ProjCfg(width=64, height=48, scales_are_log=True, opacities_are_logit=True, sh_degree=0, with_depth=True, with_normals=True,
+                  want_normals_world=True)
+    pr = _ops.project(means.to(dev), (q * 3.0).to(dev), torch.log(scales).to(dev), torch.zeros(N, device=dev), sh0=sh0.to(dev),
+                      shN=torch.zeros(N, 15, 3, device=dev), viewmat=viewmat, K=K, normal_frame=nf, cfg=cfg)
+    vis = (pr["radii"][0] > 0).cpu()
+    assert int(vis.sum()) > N // 2
+    axis = R[torch.arange(N), :, torch.argmin(scales, dim=-1)]                  # column argmin(scale) of R
+    nw = pr["normals_world"][0].cpu()
+    dots = (nw * axis).sum(-1)
+    assert float((dots.abs() - 1.0).abs().max()) < 1e-5                          # +- that column (flipped towards the camera)
+    to_cam = cam.camera_to_worlds[0, :3, 3].cpu() - means
+    assert bool(((nw * to_cam).sum(-1) >= 0).all())
+    rec = pr["splats"].detach().cpu()
+    want = torch.from_numpy(g["sh2rgb"]) * 0.5 + 0.25                            # SH2RGB(0.5 sh) = 0.5 SH2RGB(sh) + 0.25
+    assert float((rec[vis][:, 6:9] - want.clamp(min=0)[vis]).abs().max()) < 1e-6
 
 
 @pytest.mark.gpu
