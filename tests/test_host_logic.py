@@ -144,7 +144,7 @@ def test_torch_loss_stack_restatement():
     assert float(tl.edge_aware_log_l1(batch["mono_depth"], batch["mono_depth"], batch["image"], batch["mono_depth"] > 0.1)) == 0.0
     # scale term: mean over Gaussians of the smallest exp(scale)  (regularization_strategy.py:195-199)
     only_scale = tl.dn_loss({k: v.detach() for k, v in out.items()}, {"image": out["rgb"].detach()}, scales)
-    assert abs(float(only_scale) - float(torch.exp(scales).min(dim=1)[0].mean())) < 1e-6
+    assert abs(float(only_scale.detach()) - float(torch.exp(scales.detach()).min(dim=1)[0].mean())) < 1e-6
 
 
 @pytest.mark.parametrize("step,kw", [(3500, {}), (2500, {}), (3100, {}), (16000, {}), (3500, dict(cull_alpha_thresh=0.005)),
@@ -233,7 +233,7 @@ def test_spatial_reorder_is_a_permutation_of_the_reference_refinement():
     assert torch.equal(order, densify.spatial_order(big["means"]))               # deterministic (every rank gets the same order)
     m, _ = densify.reorder(big, order)
     step_sorted = (m["means"][1:] - m["means"][:-1]).norm(dim=1).mean()
-    step_random = (big["means"][1:] - big["means"][:-1]).norm(dim=1).mean()
+    step_random = (big["means"].detach()[1:] - big["means"].detach()[:-1]).norm(dim=1).mean()
     assert float(step_sorted) < 0.06 * float(step_random)
     cam = synthetic.orbit_camera(0)
     R, t = cam.camera_to_worlds[0][:, :3], cam.camera_to_worlds[0][:, 3]
