@@ -546,7 +546,7 @@ def test_occluded_and_transparent_gaussians(dns, orc):
     r1, a1, _ = dns.rasterization(**e, viewmats=viewmat.to(DEV), Ks=K.to(DEV), width=96, height=80, packed=False,
                                   sh_degree=3, render_mode="RGB+ED")
     assert torch.equal(r0, r1) and torch.equal(a0, a1)
-    assert float(a1.min()) >= 0.0 and float(a1.max()) < 1.0
+    assert float(a1.detach().min()) >= 0.0 and float(a1.detach().max()) < 1.0
     (r1.sum() + a1.sum()).backward()
     assert float(e["colors"].grad[3000:].abs().max()) == 0.0
 
@@ -1870,6 +1870,7 @@ def test_graphed_step_replays_equal_eager_frames(dns):
                 del _ops.BUFFERS.static_cap[kk]
 
 
+@pytest.mark.filterwarnings("ignore:The AccumulateGrad node's stream does not match")       # the re-capture runs on a new side stream by design
 def test_graphed_step_overflow_is_reported_and_a_recapture_fits(dns):
     """a pose copied into a captured step may need more intersections than the buffers captured at the
     warm-up pose hold.  check() must say so, and a NEW capture after the error must get buffers that fit (the capacity guess is
