@@ -873,12 +873,13 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
-            ent_w = json.load(open(pmc_path)).get(args.workload, {})
+            traffic_key = args.workload if args.scene == "reference_init" else f"{args.workload}_{args.scene}"
+            ent_w = json.load(open(pmc_path)).get(traffic_key, {})
             if ent_w.get("source_sha16") == kernel_source_sha16():
                 stage_traffic = {k: v["hbm_bytes_per_launch"] for k, v in ent_w.items() if isinstance(v, dict)}
                 pmc_traffic = stage_traffic.get(dominant)
             else:
-                traffic_note = (f"profiles/pmc_traffic.json[{args.workload}] was measured on kernel sources "
+                traffic_note = (f"profiles/pmc_traffic.json[{traffic_key}] was measured on kernel sources "
                                 f"{ent_w.get('source_sha16')}, this build is {kernel_source_sha16()}: re-run tools/pmc_traffic.sh")
         except Exception as e:
             traffic_note = f"profiles/pmc_traffic.json unreadable: {e!r}"

@@ -14,6 +14,13 @@ for w in c2 c3 c5; do
   cp gpurun_out/pmc_traffic/pmc_traffic.merged.json $O/pmc_traffic.merged.json
   cp gpurun_out/pmc_traffic/summary.json $O/pmc_traffic_summary_$w.json
 done
+# the same Gaussians along a Morton curve, zero rows skipped per workgroup (bench.py --scene morton; keys c2_morton / c5_morton)
+for w in c2 c5; do
+  rm -rf gpurun_out/pmc_traffic; mkdir -p gpurun_out/pmc_traffic
+  DNSPLAT_SH_ZERO_STATE=1 WORKLOAD=${w}_morton BENCH_ARGS="--workload $w --scene morton" bash tools/pmc_traffic.sh > $O/pmc_traffic_${w}_morton.log 2>&1
+  cp gpurun_out/pmc_traffic/pmc_traffic.merged.json $O/pmc_traffic.merged.json
+  cp gpurun_out/pmc_traffic/summary.json $O/pmc_traffic_summary_${w}_morton.json
+done
 python - <<'PY'
 import json
 d = json.load(open("gpurun_out/round_end/pmc_traffic.merged.json"))
@@ -25,6 +32,9 @@ python bench.py --steps 30 --warmup 5 > $O/bench_c2.json 2> $O/bench_c2.err; tai
 python bench.py --steps 20 --warmup 3 --workload c3 --no-cpu-baseline > $O/bench_c3.json 2>/dev/null; tail -1 $O/bench_c3.json | cut -c1-200
 python bench.py --steps 20 --warmup 3 --workload c5 --no-cpu-baseline > $O/bench_c5.json 2>/dev/null; tail -1 $O/bench_c5.json | cut -c1-200
 python bench.py --steps 20 --warmup 3 --workload c5 --no-cpu-baseline --losses fused > $O/bench_c5_fused_loss.json 2>/dev/null; tail -1 $O/bench_c5_fused_loss.json | cut -c1-200
+python bench.py --steps 20 --warmup 3 --workload c5 --no-cpu-baseline --no-strict --losses torch_hip_ssim > $O/bench_c5_torch_loss_hip_ssim.json 2>/dev/null; tail -1 $O/bench_c5_torch_loss_hip_ssim.json | cut -c1-200
+DNSPLAT_SH_ZERO_STATE=1 python bench.py --steps 20 --warmup 3 --workload c2 --scene morton --no-cpu-baseline --no-strict > $O/bench_c2_morton.json 2>/dev/null; tail -1 $O/bench_c2_morton.json | cut -c1-200
+DNSPLAT_SH_ZERO_STATE=1 python bench.py --steps 20 --warmup 3 --workload c5 --scene morton --no-cpu-baseline --no-strict > $O/bench_c5_morton.json 2>/dev/null; tail -1 $O/bench_c5_morton.json | cut -c1-200
 DNSPLAT_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_c2_single_rank_rccl.json 2>/dev/null; tail -1 $O/bench_c2_single_rank_rccl.json | cut -c1-200
 DNSPLAT_TIGHT_TILES=0 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_c2_gsplat_tile_boxes.json 2>/dev/null; tail -1 $O/bench_c2_gsplat_tile_boxes.json | cut -c1-200
 echo "== kernel stats"
