@@ -31,6 +31,37 @@
 #ifndef DNS_FWD_UNROLL2
 #define DNS_FWD_UNROLL2 0
 #endif
+// 1: the lane's TWO PIXELS as packed fp32 pairs wherever gfx950 has a packed instruction (v_pk_mul / v_pk_add / v_pk_fma / v_pk_mov):
+// (na, nb) dx, nc dy + b dx, the exponent's last FMA, opacity x exp, 1 - alpha, T (1 - alpha), alpha T, the odd seventh channel and
+// the hand-over T <- T' are one instruction for both pixels instead of two (left to itself hipcc packs only along the channels), and
+// the weights are broadcast out of their pair by operand selection: 32 instead of 39 vector instructions per splat (SQ_INSTS_VALU
+// 274 M -> 229 M per C2 frame), same operations on the same operands, bit-identical images, 64 instead of 66 VGPRs.  MEASURED
+// (profiles/r06s_fwd_sensitivity.txt): the kernel takes the same number of cycles (GRBM_GUI_ACTIVE 8.77 M vs 8.76 M), -1.0 % ... +1.3 %
+// in paired replays — this loop is not short of vector issue slots.  N extra operations per splat (DNS_FWD_X_*) cost: a vector
+// instruction 1.4 %, a scalar one 0.8 %, a taken branch 1.7 %, a v_exp 5 %, an LDS read 3 %; one wave per SIMD less 3 %, one MORE
+// (64 VGPRs) +2-4 %: a chain of dependent vector -> scalar -> vector hand-overs per splat whose every link costs, at its balance
+// point with seven waves.  Off (the long-tested form stays the default); kept as a switch with the experiment.
+#ifndef DNS_FWD_PACKED
+#define DNS_FWD_PACKED 0
+#endif
+#ifndef DNS_FWD_X_VALU
+#define DNS_FWD_X_VALU 0
+#endif
+#ifndef DNS_FWD_X_EXP
+#define DNS_FWD_X_EXP 0
+#endif
+#ifndef DNS_FWD_X_SALU
+#define DNS_FWD_X_SALU 0
+#endif
+#ifndef DNS_FWD_X_BR
+#define DNS_FWD_X_BR 0
+#endif
+#ifndef DNS_FWD_X_LDS
+#define DNS_FWD_X_LDS 0
+#endif
+#ifndef DNS_FWD_EXP_NOBRANCH
+#define DNS_FWD_EXP_NOBRANCH 0
+#endif
 
 namespace {
 
@@ -149,6 +180,12 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
     float acc0[D], acc1[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
+    typedef float f2p __attribute__((ext_vector_type(2)));
+    [[maybe_unused]] f2p Tp = {1.f, 1.f};            // DNS_FWD_PACKED: (T0, T1) as a register pair, carried through the splat loop
+    [[maybe_unused]] f2p acc_odd = {0.f, 0.f};       // DNS_FWD_PACKED, D odd: channel D - 1 of both pixels as a pair
+    [[maybe_unused]] f2p accp0[4], accp1[4];         // DNS_FWD_PACKED: channels (2 k, 2 k + 1) of pixel 0 / pixel 1 as pairs
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { accp0[k] = f2p{0.f, 0.f}; accp1[k] = f2p{0.f, 0.f}; }
     // last_ids: for a pixel that saturated the index before the saturating entry, else the end of the last batch it blended anything
     // of; in both cases no entry in (last blended, last_ids] applies to the pixel.  Raw bits (sel() moves floats).
     float last0 = 0.f, last1 = 0.f;
@@ -161,7 +198,10 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
     const float ryl = (float)(tile_y * TILE + wave * 8) + 0.5f, ryh = ryl + 7.f;
 
     // prefetch batch 0
-    float4 r0, r1, r2, r3;
+    // D == 7 needs one float of the record's last quarter (channel 6): prefetched as one dword, three VGPRs less across the splat loop
+    float4 r0, r1, r2;
+    [[maybe_unused]] float4 r3;
+    [[maybe_unused]] float r3x = 0.f;
     {
         const int idx = range_start + lane;
         if (idx < range_end) {
@@ -169,7 +209,8 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
             const float4 *rec = a.splats + (size_t)g * 4;
             r0 = rec[0]; r1 = rec[1];
             if (D > 2) r2 = rec[2];
-            if (D > 6) r3 = rec[3];
+            if (D == 7) r3x = reinterpret_cast<const float *>(rec + 3)[0];
+            else if (D > 6) r3 = rec[3];
         }
     }
 
@@ -190,7 +231,8 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
             my[lane][0] = make_float4(r0.x, r0.y, q.na, q.nb);
             my[lane][1] = make_float4(q.nc, r1.y, r1.z, r1.w);
             if (D > 2) my[lane][2] = r2;
-            if (D > 6) my[lane][3] = r3;
+            if (D == 7) reinterpret_cast<float *>(&my[lane][3])[0] = r3x;
+            else if (D > 6) my[lane][3] = r3;
         }
         {
             const int idx = batch_start + DNS_WAVE + lane;
@@ -199,7 +241,8 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
                 const float4 *rec = a.splats + (size_t)g * 4;
                 r0 = rec[0]; r1 = rec[1];
                 if (D > 2) r2 = rec[2];
-                if (D > 6) r3 = rec[3];
+                if (D == 7) r3x = reinterpret_cast<const float *>(rec + 3)[0];
+                else if (D > 6) r3 = rec[3];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -299,6 +342,141 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
             }
         }
 #else
+#if DNS_FWD_PACKED
+        while (todo) {
+            const int t = __ffsll((unsigned long long)todo) - 1;
+            asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(t));      // todo &= todo - 1 as one scalar instruction instead of three
+            const float4 g0 = my[t][0];  // x y na nb
+            const float4 g1 = my[t][1];  // nc opac ch0 ch1
+            float4 g2, g3;
+            if (D > 2) g2 = my[t][2];
+            if (D > 6) g3 = my[t][3];
+            DnsConicE q;
+            q.na = g0.z; q.nb = g0.w; q.nc = g1.x;
+            const float dx = g0.x - px;
+            const float dy0 = g0.y - py0, dy1 = g0.y - py1;
+#if DNS_EXP_SYM && DNS_FWD_PAIR_OPSEL
+            // dns_exponent() for both pixels of the lane: (na, nb) x dx as ONE packed multiply, then nb dy + adx and nc dy + bdx as two
+            // packed FMAs whose broadcast operands (nb, adx, nc, bdx) are picked out of the pairs they sit in by operand selection
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 nab = {q.na, q.nb}, ncp = {g1.x, g1.y}, dyv = {dy0, dy1};
+            const f2 abdx = nab * dx;
+            f2 hu, hw;
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(hu) : "v"(nab), "v"(dyv), "v"(abdx));
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(hw) : "v"(ncp), "v"(dyv), "v"(abdx));
+            const f2 ev = __builtin_elementwise_fma(f2{dx, dx}, hu, dyv * hw);
+            const float e0 = ev.x, e1 = ev.y;
+#elif DNS_EXP_SYM
+            // dns_exponent() for both pixels of the lane, with the two products that only depend on dx formed once
+            const float adx = q.na * dx, bdx = q.nb * dx;
+#if DNS_FWD_PAIR_OPSEL
+            // nb * dy + adx for both pixels as ONE packed FMA on the register pair (adx, nb) the record's (na, nb) turns into:
+            // nb is the pair's high half broadcast as the multiplier, adx its low half broadcast as the addend.  hipcc only finds
+            // low-half broadcasts and copies nb into a fresh pair first.
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 an = {adx, q.nb}, dyv = {dy0, dy1};
+            f2 hu;
+            asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(hu) : "v"(an), "v"(dyv));
+            const float e0 = __builtin_fmaf(dx, hu.x, dy0 * __builtin_fmaf(q.nc, dy0, bdx));
+            const float e1 = __builtin_fmaf(dx, hu.y, dy1 * __builtin_fmaf(q.nc, dy1, bdx));
+#else
+            const float e0 = __builtin_fmaf(dx, __builtin_fmaf(q.nb, dy0, adx), dy0 * __builtin_fmaf(q.nc, dy0, bdx));
+            const float e1 = __builtin_fmaf(dx, __builtin_fmaf(q.nb, dy1, adx), dy1 * __builtin_fmaf(q.nc, dy1, bdx));
+#endif
+#else
+            const float e0 = dns_exponent(q, dx, dy0);
+            const float e1 = dns_exponent(q, dx, dy1);
+#endif
+            // opacity x exp for both pixels in one packed multiply
+            f2p al = f2p{dns_exp2(e0), dns_exp2(e1)} * g1.y;
+            const float alpha0 = fminf((float)DNS_ALPHA_MAX, al.x), alpha1 = fminf((float)DNS_ALPHA_MAX, al.y);
+            float ch[8];
+            ch[0] = g1.z; ch[1] = g1.w;
+            if (D > 2) { ch[2] = g2.x; ch[3] = g2.y; ch[4] = g2.z; ch[5] = g2.w; }
+            if (D > 6) { ch[6] = g3.x; ch[7] = g3.y; }
+            const uint64_t valid0 = dns_ballot(e0 <= 0.f) & dns_ballot(alpha0 >= (float)DNS_ALPHA_MIN) & ~done0;
+            const uint64_t valid1 = dns_ballot(e1 <= 0.f) & dns_ballot(alpha1 >= (float)DNS_ALPHA_MIN) & ~done1;
+            const f2p a = {sel0(valid0, alpha0), sel0(valid1, alpha1)};
+            const f2p nT = Tp * (1.f - a);                           // v_pk_add (1 - alpha), v_pk_mul
+            const uint64_t stop0 = dns_ballot(nT.x <= (float)DNS_T_MIN), stop1 = dns_ballot(nT.y <= (float)DNS_T_MIN);
+            const f2p vw = a * Tp;
+            any0 |= valid0; any1 |= valid1;
+            if (COUNT) {
+                n_walked += 1;
+                n_live += __popcll(~done0) + __popcll(~done1);
+                n_blend += __popcll(valid0 & ~stop0) + __popcll(valid1 & ~stop1);
+            }
+            float v0 = vw.x, v1 = vw.y, nT0 = nT.x, nT1 = nT.y;
+            {
+                const int before = batch_start + t - 1;
+                const float T0c = Tp.x, T1c = Tp.y;
+                float tmp;
+                [[maybe_unused]] uint64_t tmp_s;
+                asm volatile(
+#if !DNS_FWD_EXP_NOBRANCH  // experiment: the six selects unconditionally, no branch around them (same images)
+                    "s_or_b64 vcc, %9, %10\n\t"
+                    "s_cmp_eq_u64 vcc, 0\n\t"
+                    "s_cbranch_scc1 1f\n\t"
+#endif
+                    "v_mov_b32_e32 %8, %13\n\t"
+                    "v_cndmask_b32_e64 %0, %0, 0, %9\n\t"
+                    "v_cndmask_b32_e64 %1, %1, 0, %10\n\t"
+                    "v_cndmask_b32_e64 %2, %2, %11, %9\n\t"
+                    "v_cndmask_b32_e64 %3, %3, %12, %10\n\t"
+                    "v_cndmask_b32_e64 %4, %4, %8, %9\n\t"
+                    "v_cndmask_b32_e64 %5, %5, %8, %10\n\t"
+                    "s_or_b64 %6, %6, %9\n\t"
+                    "s_or_b64 %7, %7, %10\n\t"
+                    "1:"
+                    : "+v"(v0), "+v"(v1), "+v"(nT0), "+v"(nT1), "+v"(last0), "+v"(last1), "+s"(done0), "+s"(done1), "=&v"(tmp)
+                    : "s"(stop0), "s"(stop1), "v"(T0c), "v"(T1c), "s"(before)
+                    : "vcc", "scc");
+                asm("s_and_b64 %1, %2, %3\n\ts_cmp_eq_u64 %1, -1\n\ts_cselect_b64 %0, 0, %0"
+                    : "+s"(todo), "=&s"(tmp_s) : "s"(done0), "s"(done1) : "scc");
+            }
+            {
+                // channel pairs x the pixel's weight, the weight broadcast from the LOW (pixel 0) or the HIGH (pixel 1) half of the
+                // (v0, v1) pair by operand selection: hipcc only finds low-half broadcasts and copies v1 into a fresh pair first
+                const f2p vv = {v0, v1};
+                const f2p chp[4] = {f2p{ch[0], ch[1]}, f2p{ch[2], ch[3]}, f2p{ch[4], ch[5]}, f2p{ch[6], ch[7]}};
+#pragma unroll
+                for (int kp = 0; kp < D / 2; ++kp) {
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(accp0[kp]) : "v"(chp[kp]), "v"(vv));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(accp1[kp]) : "v"(chp[kp]), "v"(vv));
+                }
+                if (D & 1) acc_odd += vv * ch[D - 1];               // the odd channel: both pixels in one packed FMA
+                // T <- T' for both pixels in one instruction
+                const f2p nTp = {nT0, nT1};
+                asm("v_pk_mov_b32 %0, %1, %1 op_sel:[0,1]" : "=v"(Tp) : "v"(nTp));
+            }
+            // ---- sensitivity experiments (tools/r06s_fwd_sensitivity.sh): N extra operations of ONE kind per splat, results unused, the
+            // dynamic work unchanged; the slope of the kernel time in N says which resource the loop is short of
+#if DNS_FWD_X_VALU > 0
+            { float d = px;
+#pragma unroll
+              for (int x = 0; x < DNS_FWD_X_VALU; ++x) asm volatile("v_mov_b32_e32 %0, %0" : "+v"(d)); }
+#endif
+#if DNS_FWD_X_EXP > 0
+            { float d = px;
+#pragma unroll
+              for (int x = 0; x < DNS_FWD_X_EXP; ++x) asm volatile("v_exp_f32_e32 %0, %0" : "+v"(d)); }
+#endif
+#if DNS_FWD_X_SALU > 0
+            { uint32_t d = 0;
+#pragma unroll
+              for (int x = 0; x < DNS_FWD_X_SALU; ++x) asm volatile("s_add_u32 %0, %0, 1" : "+s"(d) : : "scc"); }
+#endif
+#if DNS_FWD_X_BR > 0
+#pragma unroll
+            for (int x = 0; x < DNS_FWD_X_BR; ++x) asm volatile("s_cmp_eq_u32 0, 0\n\ts_cbranch_scc1 2f\n\ts_nop 0\n\t2:" : : : "scc");
+#endif
+#if DNS_FWD_X_LDS > 0
+            { float4 d;
+#pragma unroll
+              for (int x = 0; x < DNS_FWD_X_LDS; ++x) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(d) : "v"((uint32_t)(uintptr_t)&my[t][0]) : "memory"); }
+#endif
+        }
+#else
         while (todo) {
             const int t = __ffsll((unsigned long long)todo) - 1;
             asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(t));      // todo &= todo - 1 as one scalar instruction instead of three
@@ -396,6 +574,7 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
             T0 = nT0; T1 = nT1;
         }
 #endif
+#endif
         // A pixel that blended anything in this batch and is still open: every entry of the batch behind its last blended one was
         // skipped for it, so the END of the batch serves as its "last index" — the backward replays a few no-ops more, and the loop
         // above does not have to remember the index splat by splat (two selects per splat).
@@ -408,6 +587,12 @@ __global__ __launch_bounds__(FWD_THREADS) DNS_FWD_OCCUPANCY void raster_fwd_kern
         __builtin_amdgcn_wave_barrier();
     }
 
+#if DNS_FWD_PACKED && !DNS_FWD_UNROLL2
+    T0 = Tp.x; T1 = Tp.y;
+#pragma unroll
+    for (int k = 0; k < (D & ~1); ++k) { acc0[k] = (k & 1) ? accp0[k >> 1].y : accp0[k >> 1].x; acc1[k] = (k & 1) ? accp1[k >> 1].y : accp1[k >> 1].x; }
+    if (D & 1) { acc0[D - 1] = acc_odd.x; acc1[D - 1] = acc_odd.y; }
+#endif
     // epilogue: background, expected-depth normalisation, stores.  The (wave-uniform) background values are requested together, once
     float dmax = 0.f;
     float bgk[D], bgc[3] = {0.f, 0.f, 0.f};
