@@ -37,6 +37,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool: the host driver only supports dmabuf IPC (without it RCCL fails with
+# `hipIpcGetMemHandle: invalid argument`).  Already exported on the boxes; a default here covers a bare shell.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import faulthandler  # noqa: E402
 

@@ -453,6 +453,7 @@ def init_from_env(device_type: Optional[str] = None):
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
         backend = os.environ.get("DNSPLAT_DIST_BACKEND") or ("nccl" if device_type == "cuda" else "gloo")
         kw = {"device_id": device} if backend == "nccl" else {}
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
