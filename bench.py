@@ -173,7 +173,8 @@ def cpu_baseline(workload, crop=None):
 def torch_loss_kwargs(losses):
     """--losses mode -> keyword arguments of torch_losses.dn_loss."""
     return {"capturable": losses in ("torch_capturable", "torch_hip_ssim"),
-            "ssim_impl": "hip" if losses in ("torch_hip_ssim", "torch_eager_hip_ssim") else None}
+            "ssim_impl": "hip" if losses in ("torch_hip_ssim", "torch_eager_hip_ssim", "torch_hip_modules") else None,
+            "hip_modules": losses == "torch_hip_modules"}
 
 
 def side_section(workload, steps, losses=None, tight=True, shared=None, rank=0):
@@ -558,14 +559,16 @@ def main():
                          "step has no collective in it (one rank) and runs the fused path; falls back to eager launches if the capture fails")
     ap.add_argument("--two-call", action="store_true", help="reference's two-pass sequence instead of the fused pass")
     ap.add_argument("--torch-postops", action="store_true", help="keep dn_model.py:526-603 in torch instead of the HIP epilogue")
-    ap.add_argument("--losses", nargs="?", const="torch", default=None, choices=["torch", "torch_capturable", "torch_hip_ssim", "torch_eager_hip_ssim", "fused"],
+    ap.add_argument("--losses", nargs="?", const="torch", default=None, choices=["torch", "torch_capturable", "torch_hip_ssim", "torch_eager_hip_ssim", "torch_hip_modules", "fused"],
                     help="time dn-splatter's loss stack (L1+SSIM, EdgeAwareLogL1 depth, normal L1+TV, scale) instead of feeding "
                          "random cotangents (BASELINE config C5): 'torch' = as the reference does (its boolean-mask gathers need the "
                          "host: no graph capture, eager launches), 'torch_capturable' = the same PyTorch stack with the masked means as "
                          "sum / count (capturable), 'torch_hip_ssim' = the capturable PyTorch stack with splatfacto's SSIM module on dnsplat_ssim "
                          "(fused_loss.SSIM; every other term in PyTorch), 'torch_eager_hip_ssim' = the reference's stack AS IT IS (boolean-mask "
                          "gathers, eager) with only that module swapped: what install() + install_ssim() give without touching the loss "
-                         "code, 'fused' = dnsplat_dn_loss")
+                         "code, 'torch_hip_modules' = the reference's stack with the three modules install_losses(model) swaps (SSIM, "
+                         "EdgeAwareLogL1, TVLoss) on HIP and everything else — L1 terms, masks, weights, the scale term — in PyTorch, "
+                         "'fused' = dnsplat_dn_loss")
     ap.add_argument("--lean", action="store_true",
                     help="profiling runs (rocprofv3 --kernel-trace / --pmc serialise every launch): eager launches, no pre-roll, no "
                          "counting step, no strict-index-parity section")
@@ -959,7 +962,7 @@ def main():
             extras = {}
             for name, wl, ls in (("c3", "c3", None), ("c5", "c5", None), ("c5_fused_loss", "c5", "fused"), ("c5_torch_loss", "c5", "torch"),
                                  ("c5_torch_loss_capturable", "c5", "torch_capturable"), ("c5_torch_loss_hip_ssim", "c5", "torch_hip_ssim"),
-                                 ("c5_torch_loss_eager_hip_ssim", "c5", "torch_eager_hip_ssim")):
+                                 ("c5_torch_loss_eager_hip_ssim", "c5", "torch_eager_hip_ssim"), ("c5_torch_loss_hip_modules", "c5", "torch_hip_modules")):
                 extras[name] = child_workload(wl, ls, max(5, min(10, args.steps)))
             # the north star's C5 ("depth + mono-normal loss enabled", losses in PyTorch-ROCm: regularization_strategy.py:146-199,
             # losses.py:187-224) is c5_torch_loss; c5_fused_loss is the same loss stack as two HIP launches (N2)

@@ -19,10 +19,10 @@ from .model import Camera, DNSplatterRenderer, RendererConfig, get_viewmat  # no
 from ._ops import set_bin_policy, set_deterministic, set_grad_arena, set_sh_exchange  # noqa: F401
 from . import dp  # noqa: F401
 from .densify import DensifyStats  # noqa: F401
-from .install import install, install_ssim, uninstall  # noqa: F401
+from .install import install, install_losses, install_ssim, uninstall  # noqa: F401
 
 __all__ = [
     "rasterization", "rasterize_gaussians", "quat_to_rotmat", "num_sh_bases", "render_dn",
     "DNSplatterRenderer", "RendererConfig", "Camera", "get_viewmat", "set_bin_policy", "set_deterministic", "set_grad_arena", "set_sh_exchange", "dp", "DensifyStats",
-    "install", "install_ssim", "uninstall", "build_library", "load_library", "DnsplatError",
+    "install", "install_losses", "install_ssim", "uninstall", "build_library", "load_library", "DnsplatError",
 ]

@@ -147,7 +147,7 @@ EXPORTS = [
     "dnsplat_bin_workspace_bytes", "dnsplat_bin_status_offset", "dnsplat_bin_prepare", "dnsplat_bin_emit_sort", "dnsplat_bin_isect_ids",
     "dnsplat_raster_fwd", "dnsplat_raster_bwd", "dnsplat_det_workspace_bytes", "dnsplat_det_reduce",
     "dnsplat_dn_depth_normals", "dnsplat_camera_prepare", "dnsplat_densify_stats", "dnsplat_densify_classify",
-    "dnsplat_densify_split", "dnsplat_dn_loss", "dnsplat_ssim", "dnsplat_scale_reg", "dnsplat_sh_grads_from_factors", "dnsplat_sh_factors",
+    "dnsplat_densify_split", "dnsplat_dn_loss", "dnsplat_ssim", "dnsplat_edge_aware_logl1", "dnsplat_tv_loss", "dnsplat_scale_reg", "dnsplat_sh_grads_from_factors", "dnsplat_sh_factors",
     "dnsplat_project_bwd", "dnsplat_sh_grads_add_factors", "dnsplat_packed_slab_floats", "dnsplat_visible_index",
     "dnsplat_sh_grads_from_packed",
 ]
@@ -207,6 +207,8 @@ def lib() -> ctypes.CDLL:
         L.dnsplat_dn_loss.argtypes = [ctypes.POINTER(DnLossArgs), c_void_p]
         L.dnsplat_scale_reg.argtypes = [c_int32, c_void_p, c_float, c_void_p, c_void_p, c_void_p]
         L.dnsplat_ssim.argtypes = [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.dnsplat_edge_aware_logl1.argtypes = [c_int32, c_int32] + [c_void_p] * 9
+        L.dnsplat_tv_loss.argtypes = [c_int32, c_int32, c_int32] + [c_void_p] * 5
         L.dnsplat_camera_prepare.argtypes = [c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_int32, c_void_p]
         L.dnsplat_sh_factors.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]

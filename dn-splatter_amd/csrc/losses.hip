@@ -354,6 +354,80 @@ __global__ __launch_bounds__(256) void scale_reg_kernel(int N, const float *__re
     if (threadIdx.x == 0 && tot != 0.f) atomicAdd(sum, tot);
 }
 
+
+// ---- the reference's loss MODULES one by one (ABI 15), for a loss stack that otherwise stays in PyTorch: same arithmetic as the
+// stencils of dn_loss_grad_kernel, as separate entry points behind drop-in nn.Modules (fused_loss.EdgeAwareLogL1 / TVLoss).
+
+// EdgeAwareLogL1, "scalar" implementation (losses.py:187-224).  One thread per pixel: sums[0] += lambda_x log(1 + |d|), sums[1] +=
+// lambda_y log(1 + |d|), sums[2] / sums[3] += 1 for every pixel that counts in the x / y mean (mask, and a right / lower neighbour);
+// v_x / v_y = d/d(pred) of the two UNNORMALISED sums (the caller divides by the counts: they are only known when the launch ends).
+__global__ __launch_bounds__(LS_THREADS) void edge_aware_logl1_kernel(int W, int H, const float *__restrict__ pred, const float *__restrict__ gt,
+                                                                       const float *__restrict__ rgb, const uint8_t *__restrict__ mask,
+                                                                       float *__restrict__ v_x, float *__restrict__ v_y, float *__restrict__ slots)
+{
+    __shared__ float red[4];
+    const long long P = (long long)W * H;
+    float s_x = 0.f, s_y = 0.f, c_x = 0.f, c_y = 0.f;
+    for (long long px = (long long)blockIdx.x * LS_THREADS + threadIdx.x; px < P; px += (long long)gridDim.x * LS_THREADS) {
+        const int i = (int)(px / W), j = (int)(px - (long long)i * W);
+        const bool has_r = j < W - 1, has_b = i < H - 1;
+        const long long pr = has_r ? px + 1 : px, pb = has_b ? px + W : px;
+        const float d = pred[px] - gt[px];
+        float g0[3], gr[3], gb[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { g0[c] = rgb[px * 3 + c]; gr[c] = rgb[pr * 3 + c]; gb[c] = rgb[pb * 3 + c]; }
+        const bool m = mask ? mask[px] != 0 : true;
+        const float l = logf(1.f + fabsf(d)), dl = sgn(d) / (1.f + fabsf(d));
+        float vx = 0.f, vy = 0.f;
+        if (m && has_r) {
+            const float lam = expf(-(fabsf(g0[0] - gr[0]) + fabsf(g0[1] - gr[1]) + fabsf(g0[2] - gr[2])) / 3.f);
+            s_x += lam * l; c_x += 1.f; vx = lam * dl;
+        }
+        if (m && has_b) {
+            const float lam = expf(-(fabsf(g0[0] - gb[0]) + fabsf(g0[1] - gb[1]) + fabsf(g0[2] - gb[2])) / 3.f);
+            s_y += lam * l; c_y += 1.f; vy = lam * dl;
+        }
+        if (v_x) { v_x[px] = vx; v_y[px] = vy; }
+    }
+    float part[4] = {s_x, s_y, c_x, c_y};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float tot = block_sum(part[q], red);
+        if (threadIdx.x == 0 && tot != 0.f) atomicAdd(slots + 8 * (blockIdx.x % LS_SLOTS) + q, tot);
+    }
+}
+
+// TVLoss (losses.py:279-295) of an [H,W,C] image: sums[0] += |p - right|, sums[1] += |p - lower|; v = d/d(pred) of
+// sums[0] / (H (W-1) C) + sums[1] / ((H-1) W C), final (the normalisers are constants).
+__global__ __launch_bounds__(LS_THREADS) void tv_loss_kernel(int W, int H, int C, const float *__restrict__ pred, float *__restrict__ v,
+                                                              float *__restrict__ slots)
+{
+    __shared__ float red[4];
+    const long long P = (long long)W * H;
+    const float w_h = 1.f / ((float)C * (float)H * (float)(W - 1)), w_w = 1.f / ((float)C * (float)(H - 1) * (float)W);
+    float s_h = 0.f, s_w = 0.f;
+    for (long long px = (long long)blockIdx.x * LS_THREADS + threadIdx.x; px < P; px += (long long)gridDim.x * LS_THREADS) {
+        const int i = (int)(px / W), j = (int)(px - (long long)i * W);
+        const bool has_r = j < W - 1, has_l = j > 0, has_b = i < H - 1, has_t = i > 0;
+        const long long pr = has_r ? px + 1 : px, pl = has_l ? px - 1 : px, pb = has_b ? px + W : px, pt = has_t ? px - W : px;
+        for (int c = 0; c < C; ++c) {
+            const float n = pred[px * C + c], nr = pred[pr * C + c], nl = pred[pl * C + c], nb = pred[pb * C + c], nt = pred[pt * C + c];
+            float g = 0.f;
+            if (has_r) { const float t = n - nr; s_h += fabsf(t); g += w_h * sgn(t); }
+            if (has_l) g -= w_h * sgn(nl - n);
+            if (has_b) { const float t = n - nb; s_w += fabsf(t); g += w_w * sgn(t); }
+            if (has_t) g -= w_w * sgn(nt - n);
+            if (v) v[px * C + c] = g;
+        }
+    }
+    float part[2] = {s_h, s_w};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float tot = block_sum(part[q], red);
+        if (threadIdx.x == 0 && tot != 0.f) atomicAdd(slots + 8 * (blockIdx.x % LS_SLOTS) + q, tot);
+    }
+}
+
 }  // namespace
 
 extern "C" int dnsplat_scale_reg(int32_t N, const float *scales_log, float weight, float *v_scales, float *sum, dnsplat_stream_t stream)
@@ -392,6 +466,36 @@ extern "C" int dnsplat_ssim(int32_t width, int32_t height, const float *x, const
     hipLaunchKernelGGL(dn_ssim_stats_kernel, grid_v, dim3(LS_THREADS), 0, stream, a);
     if (v_x) hipLaunchKernelGGL(dn_loss_grad_kernel<true>, grid, dim3(LS_THREADS), 0, stream, a);
     hipLaunchKernelGGL(dn_loss_fold_kernel, dim3(1), dim3(DNS_WAVE), 0, stream, (const float *)a.slots, a.sums);
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}
+
+extern "C" int dnsplat_edge_aware_logl1(int32_t width, int32_t height, const float *pred, const float *gt, const float *rgb,
+                                        const uint8_t *mask, float *v_x, float *v_y, float *scratch, float *sums, dnsplat_stream_t stream_)
+{
+    if (width < 2 || height < 2) return DNSPLAT_ERR_UNSUPPORTED;
+    if (!pred || !gt || !rgb || !scratch || !sums || ((v_x == nullptr) != (v_y == nullptr))) return DNSPLAT_ERR_INVALID_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (hipMemsetAsync(scratch, 0, LS_SLOTS * 8 * sizeof(float), stream) != hipSuccess) return DNSPLAT_ERR_LAUNCH;
+    const long long P = (long long)width * height;
+    const int blocks = (int)((P + LS_THREADS - 1) / LS_THREADS < 4096 ? (P + LS_THREADS - 1) / LS_THREADS : 4096);
+    hipLaunchKernelGGL(edge_aware_logl1_kernel, dim3(blocks), dim3(LS_THREADS), 0, stream, width, height, pred, gt, rgb, mask, v_x, v_y, scratch);
+    hipLaunchKernelGGL(dn_loss_fold_kernel, dim3(1), dim3(DNS_WAVE), 0, stream, (const float *)scratch, sums);
+    DNS_CHECK_LAUNCH();
+    return DNSPLAT_OK;
+}
+
+extern "C" int dnsplat_tv_loss(int32_t width, int32_t height, int32_t channels, const float *pred, float *v_pred, float *scratch, float *sums,
+                               dnsplat_stream_t stream_)
+{
+    if (width < 2 || height < 2 || channels < 1) return DNSPLAT_ERR_UNSUPPORTED;
+    if (!pred || !scratch || !sums) return DNSPLAT_ERR_INVALID_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (hipMemsetAsync(scratch, 0, LS_SLOTS * 8 * sizeof(float), stream) != hipSuccess) return DNSPLAT_ERR_LAUNCH;
+    const long long P = (long long)width * height;
+    const int blocks = (int)((P + LS_THREADS - 1) / LS_THREADS < 4096 ? (P + LS_THREADS - 1) / LS_THREADS : 4096);
+    hipLaunchKernelGGL(tv_loss_kernel, dim3(blocks), dim3(LS_THREADS), 0, stream, width, height, channels, pred, v_pred, scratch);
+    hipLaunchKernelGGL(dn_loss_fold_kernel, dim3(1), dim3(DNS_WAVE), 0, stream, (const float *)scratch, sums);
     DNS_CHECK_LAUNCH();
     return DNSPLAT_OK;
 }

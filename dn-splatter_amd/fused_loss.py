@@ -125,6 +125,91 @@ class SSIM(torch.nn.Module):
         return _SsimFn.apply(x, y)
 
 
+class _EdgeAwareLogL1Fn(torch.autograd.Function):
+    """EdgeAwareLogL1 ("scalar", losses.py:187-224): value and gradient w.r.t. the prediction in one pass (``dnsplat_edge_aware_logl1``)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, rgb, mask):
+        shape = pred.shape
+        H, W = shape[0], shape[1]
+        p2 = _f32c(pred.reshape(H, W), "pred"); g2 = _f32c(gt.reshape(H, W).float(), "gt"); rgb = _f32c(rgb, "rgb")
+        if rgb.shape != (H, W, 3):
+            raise ValueError(f"EdgeAwareLogL1: rgb must be [H,W,3] for a [{H},{W}] depth, got {tuple(rgb.shape)}")
+        m = None
+        if mask is not None:
+            if mask.dtype != torch.bool or mask.numel() != H * W:
+                raise ValueError("EdgeAwareLogL1: mask must be a bool tensor of the depth's shape")
+            m = mask.reshape(H, W).contiguous()
+        f32 = dict(dtype=torch.float32, device=p2.device)
+        need = ctx.needs_input_grad[0]
+        v_x = torch.empty(H, W, **f32) if need else None
+        v_y = torch.empty(H, W, **f32) if need else None
+        scratch = torch.empty(512, **f32)
+        sums = torch.empty(8, **f32)
+        _lib.run("dnsplat_edge_aware_logl1", _lib.lib().dnsplat_edge_aware_logl1, W, H, _ptr(p2), _ptr(g2), _ptr(rgb), _ptr(m),
+                 _ptr(v_x), _ptr(v_y), _ptr(scratch), _ptr(sums), _stream())
+        if need:
+            ctx.save_for_backward(v_x, v_y, sums)
+            ctx.shape = shape
+        return sums[0] / sums[2] + sums[1] / sums[3]        # mean over the counted pixels of each term (an empty mask: nan, as the reference)
+
+    @staticmethod
+    def backward(ctx, g):
+        v_x, v_y, sums = ctx.saved_tensors
+        return (v_x * (g / sums[2]) + v_y * (g / sums[3])).reshape(ctx.shape), None, None, None
+
+
+class EdgeAwareLogL1(torch.nn.Module):
+    """Drop-in for ``dn_splatter.losses.EdgeAwareLogL1(implementation="scalar")`` (losses.py:187-224) as
+    ``DNRegularization.get_depth_loss`` calls it (regularization_strategy.py:162-170): ``loss(pred_depth, gt_depth, gt_img, valid_mask)``
+    with [H,W,1] depths, an [H,W,3] image and an [H,W,1] bool mask (or None).  One launch instead of ~20 torch kernels and — what costs
+    more in an eager step — instead of the two boolean-mask gathers ``loss_x[mask]``, whose data-dependent size is a host
+    synchronisation each.  Gradient w.r.t. ``pred`` only (the reference differentiates nothing else here)."""
+
+    def __init__(self, implementation: str = "scalar", **kwargs):
+        super().__init__()
+        if implementation != "scalar":
+            raise NotImplementedError('dnsplat EdgeAwareLogL1: implementation="scalar" (what DNRegularization constructs)')
+        self.implementation = implementation
+
+    def forward(self, pred: Tensor, gt: Tensor, rgb: Tensor, mask: Optional[Tensor]) -> Tensor:
+        if pred.dim() not in (2, 3) or (pred.dim() == 3 and pred.shape[2] != 1):
+            raise NotImplementedError(f"dnsplat EdgeAwareLogL1 takes one [H,W,1] depth image, got {tuple(pred.shape)}")
+        if gt.requires_grad or rgb.requires_grad:
+            raise NotImplementedError("dnsplat EdgeAwareLogL1 differentiates the prediction only")
+        return _EdgeAwareLogL1Fn.apply(pred, gt, rgb, mask)
+
+
+class _TVLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred):
+        pred = _f32c(pred, "pred")
+        H, W, C = pred.shape
+        f32 = dict(dtype=torch.float32, device=pred.device)
+        v = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
+        scratch = torch.empty(512, **f32)
+        sums = torch.empty(8, **f32)
+        _lib.run("dnsplat_tv_loss", _lib.lib().dnsplat_tv_loss, W, H, C, _ptr(pred), _ptr(v), _ptr(scratch), _ptr(sums), _stream())
+        if v is not None:
+            ctx.save_for_backward(v)
+        return sums[0] / float(C * H * (W - 1)) + sums[1] / float(C * (H - 1) * W)
+
+    @staticmethod
+    def backward(ctx, g):
+        (v,) = ctx.saved_tensors
+        return v * g
+
+
+class TVLoss(torch.nn.Module):
+    """Drop-in for ``dn_splatter.losses.TVLoss`` (losses.py:279-295) on one [H,W,C] image, as ``NormalLoss(Smooth)`` applies it to
+    the rendered normals (regularization_strategy.py:188-193): one launch for value and gradient instead of ~14 torch kernels."""
+
+    def forward(self, pred: Tensor) -> Tensor:
+        if pred.dim() != 3:
+            raise NotImplementedError(f"dnsplat TVLoss takes one [H,W,C] image, got {tuple(pred.shape)}")
+        return _TVLossFn.apply(pred)
+
+
 class _ScaleRegFn(torch.autograd.Function):
     """mean_g min_k exp(scales[g, k]) (regularization_strategy.py:195-199) and its gradient in one launch (dnsplat_scale_reg)."""
 

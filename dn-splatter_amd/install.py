@@ -137,6 +137,32 @@ def install_ssim(model):
     return model
 
 
+def install_losses(model):
+    """Swaps the two stencil modules of the model's regularisation strategy for their one-launch HIP drop-ins, when they are the ones
+    ``DNRegularization`` / ``AGSMeshRegularization`` construct (regularization_strategy.py:131-144): ``strategy.depth_loss.loss``
+    (``EdgeAwareLogL1(implementation="scalar")`` -> ``fused_loss.EdgeAwareLogL1``) and ``strategy.normal_smooth_loss.loss``
+    (``TVLoss`` -> ``fused_loss.TVLoss``); also ``install_ssim(model)``.  Everything else of ``get_loss_dict`` stays the reference's
+    PyTorch code.  Returns the list of what was swapped."""
+    from . import fused_loss
+
+    swapped = []
+    strategy = getattr(model, "regularization_strategy", None)
+    for holder_name, cls_name, make in (("depth_loss", "EdgeAwareLogL1", fused_loss.EdgeAwareLogL1),
+                                        ("normal_smooth_loss", "TVLoss", fused_loss.TVLoss)):
+        holder = getattr(strategy, holder_name, None)
+        inner = getattr(holder, "loss", None)
+        if inner is None or type(inner).__name__ != cls_name or isinstance(inner, make):
+            continue
+        if cls_name == "EdgeAwareLogL1" and getattr(inner, "implementation", "scalar") != "scalar":
+            continue
+        holder.loss = make()
+        swapped.append(f"regularization_strategy.{holder_name}.loss")
+    if hasattr(model, "ssim"):
+        install_ssim(model)
+        swapped.append("ssim")
+    return swapped
+
+
 def uninstall(model_cls):
     """Puts the original ``get_outputs`` back."""
     original = model_cls.__dict__.get(_ORIGINAL)

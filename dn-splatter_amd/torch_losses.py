@@ -186,11 +186,12 @@ def rgb_term(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], ssim_lambda: 
 
 def regularization_term(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], scales: Tensor, depth_lambda: float = 0.2,
                         depth_tolerance: float = 0.1, use_depth_loss: bool = True, use_normal_loss: bool = True,
-                        capturable: bool = False) -> Tensor:
+                        capturable: bool = False, hip_modules: bool = False) -> Tensor:
     """What dn-splatter itself adds in get_loss_dict (dn_model.py:629-727) for regularization_strategy == "dn-splatter" with mono
     depth / mono normal supervision: ``DNRegularization.get_loss`` (regularization_strategy.py:146-199) on the ground truths the
     method picks — the image clamped at 10/255 for the edge weights (:633), depth, both normals and their ground truths multiplied
-    by ``batch["mask"]`` if there is one (:646-659).  Pinned to the reference's own text: tests/golden/reference_regularization.npz."""
+    by ``batch["mask"]`` if there is one (:646-659).  Pinned to the reference's own text: tests/golden/reference_regularization.npz.
+    ``hip_modules``: the two stencil modules as ``install_losses(model)`` swaps them (``fused_loss.EdgeAwareLogL1`` / ``TVLoss``)."""
     gt_img = batch["image"].clamp(min=10 / 255.0)                                   # dn_model.py:633
     depth_out, pred_normal = outputs["depth"], outputs["normal"]
     gt_depth, gt_normal = batch.get("mono_depth"), batch.get("normal")
@@ -203,22 +204,31 @@ def regularization_term(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], sc
     loss = torch.min(torch.exp(scales), dim=1, keepdim=True)[0].mean()              # regularization_strategy.py:195-199
     if use_depth_loss and gt_depth is not None:
         valid = gt_depth > depth_tolerance                                          # :162
-        d = edge_aware_log_l1(depth_out, gt_depth.float(), gt_img, valid, capturable)
+        if hip_modules:
+            from .fused_loss import EdgeAwareLogL1
+            d = EdgeAwareLogL1()(depth_out, gt_depth.float(), gt_img, valid)
+        else:
+            d = edge_aware_log_l1(depth_out, gt_depth.float(), gt_img, valid, capturable)
         loss = loss + (d + depth_lambda * d)                                        # :184
     if use_normal_loss and gt_normal is not None:
-        loss = loss + torch.abs(pred_normal - gt_normal).mean() + tv_loss(pred_normal)   # :188-193
+        if hip_modules:
+            from .fused_loss import TVLoss
+            tv = TVLoss()(pred_normal)
+        else:
+            tv = tv_loss(pred_normal)
+        loss = loss + torch.abs(pred_normal - gt_normal).mean() + tv                     # :188-193
     return loss
 
 
 def dn_loss(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], scales: Tensor, ssim_lambda: float = 0.2,
             depth_lambda: float = 0.2, depth_tolerance: float = 0.1, use_depth_loss: bool = True,
-            use_normal_loss: bool = True, capturable: bool = False, ssim_impl: Optional[str] = None) -> Tensor:
+            use_normal_loss: bool = True, capturable: bool = False, ssim_impl: Optional[str] = None, hip_modules: bool = False) -> Tensor:
     """main_loss of ``DNSplatterModel.get_loss_dict`` for regularization_strategy == "dn-splatter" with mono depth
     and mono normal supervision (dn_model.py:614-729): rgb_loss + regularization_strategy_loss (:727).
     ``capturable``: the same terms in PyTorch ops that need no host synchronisation and no convolution library — masked means as
     sum / count (``edge_aware_log_l1``), SSIM blurs as GEMMs (``ssim_gemm``): the whole step can be captured into a HIP graph."""
     return rgb_term(outputs, batch, ssim_lambda, fast=capturable, ssim_impl=ssim_impl) + regularization_term(outputs, batch, scales, depth_lambda, depth_tolerance,
-                                                                       use_depth_loss, use_normal_loss, capturable)
+                                                                       use_depth_loss, use_normal_loss, capturable, hip_modules)
 
 
 def synthetic_batch(width: int, height: int, device, seed: int = 0) -> Dict[str, Tensor]:

@@ -50,7 +50,7 @@ extern "C" {
  * gradient rows of persistently culled Gaussians are not re-zeroed), dnsplat_sh_grads_add_factors, the packed (visible rows only)
  * colour-gradient slabs: dnsplat_visible_index, dnsplat_proj_grads.sh_packed, dnsplat_sh_grads_from_packed; 15 = dnsplat_ssim (the
  * SSIM term alone, for a loss stack that otherwise stays in PyTorch), dnsplat_proj_grads.zero_state_geometry (zero gradient rows of
- * culled Gaussians skipped per workgroup). */
+ * culled Gaussians skipped per workgroup), dnsplat_edge_aware_logl1, dnsplat_tv_loss. */
 #define DNSPLAT_ABI_VERSION 15
 #define DNSPLAT_RECORD_FLOATS 16
 #define DNSPLAT_MAX_CHANNELS 8
@@ -446,6 +446,21 @@ int dnsplat_dn_loss(const dnsplat_dn_loss_args *args, dnsplat_stream_t stream);
  *   v_x     = d(mean SSIM)/dx, [H,W,3], or NULL (value only);   x, y: [H,W,3] fp32;   maps: scratch, 9 H W + 512 floats. */
 int dnsplat_ssim(int32_t width, int32_t height, const float *x, const float *y, float *maps, float *v_x, float *sums /* device [8] */,
                  dnsplat_stream_t stream);
+
+/* ABI 15.  Two more MODULES of the reference's loss stack one by one (the rest stays PyTorch), behind drop-in nn.Modules
+ * (fused_loss.EdgeAwareLogL1 / TVLoss, install_losses(model)):
+ * dnsplat_edge_aware_logl1 — losses.py:187-224, "scalar" implementation, as DNRegularization.get_depth_loss calls it
+ *   (regularization_strategy.py:162-170): pred, gt [H,W] fp32, rgb [H,W,3], mask [H,W] bytes (torch.bool) or NULL.
+ *   sums[0..3] = { sum lambda_x log(1+|d|), sum lambda_y log(1+|d|), pixels counted in x, pixels counted in y }  (loss = s0/s2 + s1/s3;
+ *   the reference's boolean-mask gathers `loss_x[mask]` have a data-dependent size = a host synchronisation per call: none here);
+ *   v_x, v_y [H,W] (both or neither): d s0 / d pred, d s1 / d pred — the caller divides by the counts.
+ * dnsplat_tv_loss — losses.py:279-295 on an [H,W,C] image: sums[0..1] = { sum |p - right|, sum |p - lower| },
+ *   v_pred = d/d pred of the loss s0 / (H (W-1) C) + s1 / ((H-1) W C) (or NULL).
+ * scratch: 512 floats; sums: device [8]. */
+int dnsplat_edge_aware_logl1(int32_t width, int32_t height, const float *pred, const float *gt, const float *rgb, const uint8_t *mask,
+                             float *v_x, float *v_y, float *scratch, float *sums, dnsplat_stream_t stream);
+int dnsplat_tv_loss(int32_t width, int32_t height, int32_t channels, const float *pred, float *v_pred, float *scratch, float *sums,
+                    dnsplat_stream_t stream);
 
 /* The per-Gaussian term of the same loss (regularization_strategy.py:195-199): mean_g min_k exp(scales[g][k]).  Adds
  * weight * sum_g min_k exp(s_gk) to *sum (device scalar, caller zeroes it) and WRITES the gradient rows

@@ -874,6 +874,13 @@ def test_ssim_module_matches_the_torch_ssim(dns, W, H):
         assert abs(l_h - l_t) <= 2e-5 * abs(l_t)
         for k in g_t:
             assert_close(g_h[k], g_t[k], "hip-SSIM stack d loss / d " + k, 2e-4)
+        # ... and with all three swapped modules (install_losses): SSIM, EdgeAwareLogL1, TVLoss on HIP, the rest in PyTorch
+        batch["mono_depth"][: H // 3, : W // 4] = 0.0                   # part of the depth map invalid
+        l_t, g_t = run()
+        l_m, g_m = run(ssim_impl="hip", hip_modules=True)
+        assert abs(l_m - l_t) <= 2e-5 * abs(l_t)
+        for k in g_t:
+            assert_close(g_m[k], g_t[k], "hip-modules stack d loss / d " + k, 2e-4)
 
 
 def test_spatially_reordered_gaussians_render_the_same_frame(dns):

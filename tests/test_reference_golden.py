@@ -180,6 +180,53 @@ def test_hip_loss_kernels_equal_the_reference_terms():
     assert abs(float(loss) - want) < 2e-5 * want
 
 
+@pytest.mark.gpu
+def test_hip_loss_modules_equal_the_reference_modules():
+    """fused_loss.EdgeAwareLogL1 / TVLoss (dnsplat_edge_aware_logl1 / dnsplat_tv_loss, what install_losses(model) puts in place of
+    the reference's modules) against the values and gradients the reference's OWN classes produced (losses.py:187-224 with and
+    without a mask, :279-295; tests/golden/reference_losses.npz), and the swap itself on a stand-in model."""
+    import dn_splatter_amd as dns
+    from dn_splatter_amd import fused_loss
+
+    g = _load("reference_losses.npz")
+    dev = "cuda:0"
+    pred = torch.from_numpy(g["pred"]).to(dev)
+    gt, rgb, mask = torch.from_numpy(g["gt"]).to(dev), torch.from_numpy(g["rgb"]).to(dev), torch.from_numpy(g["mask"]).to(dev)
+    pn = torch.from_numpy(g["pred_normal"]).to(dev)
+
+    def check(fn, x, key, tol=2e-6):
+        x = x.clone().requires_grad_(True)
+        value = fn(x)
+        (3.0 * value).backward()                                            # an upstream factor reaches the gradient
+        ref, ref_g = float(g[key]), torch.from_numpy(g[key + "_grad"]).to(dev)
+        assert abs(float(value.detach()) - ref) < tol * max(1.0, abs(ref)), (key, float(value.detach()), ref)
+        assert x.grad.shape == ref_g.shape
+        assert float((x.grad / 3.0 - ref_g).abs().max()) < tol * max(1.0, float(ref_g.abs().max())), key + " gradient"
+
+    ea, tv = fused_loss.EdgeAwareLogL1(), fused_loss.TVLoss()
+    check(lambda x: ea(x, gt, rgb, mask), pred, "edge_aware_logl1_masked")
+    check(lambda x: ea(x, gt, rgb, None), pred, "edge_aware_logl1_nomask")
+    check(lambda x: tv(x), pn, "tv_normal")
+    with torch.no_grad():                                                   # value only: no gradient planes are written
+        assert abs(float(ea(pred, gt, rgb, mask)) - float(g["edge_aware_logl1_masked"])) < 2e-6
+    with pytest.raises(NotImplementedError):
+        fused_loss.EdgeAwareLogL1(implementation="per-pixel")
+    # the swap: a model whose strategy holds the reference's kind of modules (class NAMES are what install_losses goes by)
+    EdgeAwareLogL1 = type("EdgeAwareLogL1", (torch.nn.Module,), {"implementation": "scalar"})
+    TVLoss = type("TVLoss", (torch.nn.Module,), {})
+    Holder = type("Holder", (torch.nn.Module,), {})
+    strategy = torch.nn.Module()
+    strategy.depth_loss, strategy.normal_smooth_loss, strategy.normal_loss = Holder(), Holder(), Holder()
+    strategy.depth_loss.loss, strategy.normal_smooth_loss.loss, strategy.normal_loss.loss = EdgeAwareLogL1(), TVLoss(), torch.nn.L1Loss()
+    model = torch.nn.Module()
+    model.regularization_strategy, model.ssim = strategy, torch.nn.Identity()
+    swapped = dns.install_losses(model)
+    assert swapped == ["regularization_strategy.depth_loss.loss", "regularization_strategy.normal_smooth_loss.loss", "ssim"]
+    assert isinstance(strategy.depth_loss.loss, fused_loss.EdgeAwareLogL1) and isinstance(strategy.normal_smooth_loss.loss, fused_loss.TVLoss)
+    assert isinstance(strategy.normal_loss.loss, torch.nn.L1Loss) and isinstance(model.ssim, fused_loss.SSIM)
+    assert dns.install_losses(model) == ["ssim"]                            # idempotent (ssim reports itself, nothing is replaced twice)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # DNSplatterModel.get_outputs executed from the reference's own text (reference_get_outputs.npz): pins A0 (what is
 # handed to gsplat.rasterization), A7 (per-Gaussian normals, dn_model.py:543-560) and A9 (the per-pixel post-ops,
