@@ -8,9 +8,10 @@ with the renderer; nothing here is a kernel of ours.  It follows
 * ``DNRegularization.get_loss`` / depth / normal / scale dn_splatter/regularization_strategy.py:146-199
 * ``EdgeAwareLogL1``, ``LogL1``, ``L1``, ``TVLoss``      dn_splatter/losses.py:154-224, 279-295
 * the inherited RGB term of nerfstudio's ``SplatfactoModel.get_loss_dict``: ``(1 - l) * L1 + l * (1 - SSIM)`` with
-  ``l = ssim_lambda = 0.2`` and pytorch_msssim's SSIM (11x11 Gaussian window, sigma 1.5, valid padding,
-  data_range 1) — neither nerfstudio nor pytorch_msssim is vendored in the reference, so that term is restated
-  from their published definitions.
+  ``l = ssim_lambda = 0.2``; ``self.ssim`` is, in dn-splatter, torchmetrics' ``StructuralSimilarityIndexMeasure(data_range=1.0,
+  kernel_size=11)`` (dn_model.py:180; nerfstudio itself holds pytorch_msssim's SSIM): an 11 x 11 Gaussian window, sigma 1.5, averaged
+  over the windows that do not touch the border (pytorch_msssim: valid convolution; torchmetrics: reflect-pad, then crop the rim) —
+  neither package is vendored in the reference, so that term is restated from their published definitions.
 """
 from __future__ import annotations
 

@@ -164,6 +164,42 @@ def test_install_ssim_swaps_the_module_and_refuses_cpu_tensors(dns):
         m.ssim(a.requires_grad_(True), b.requires_grad_(True))
 
 
+def test_install_losses_swaps_only_the_modules_it_knows(dns):
+    """install_losses(model): the reference's EdgeAwareLogL1("scalar") and TVLoss inside the strategy's holder modules are replaced (by
+    class name: the reference need not be importable), other implementations / loss types are left alone, the modules refuse CPU
+    tensors (no CPU fallback) and what they do not compute."""
+    from dn_splatter_amd import fused_loss
+
+    EdgeAwareLogL1 = type("EdgeAwareLogL1", (torch.nn.Module,), {"implementation": "scalar"})
+    PerPixel = type("EdgeAwareLogL1", (torch.nn.Module,), {"implementation": "per-pixel"})
+    TVLoss = type("TVLoss", (torch.nn.Module,), {})
+    Holder = type("Holder", (torch.nn.Module,), {})
+
+    def model_with(depth_inner, smooth_inner):
+        st = torch.nn.Module()
+        st.depth_loss, st.normal_smooth_loss = Holder(), Holder()
+        st.depth_loss.loss, st.normal_smooth_loss.loss = depth_inner, smooth_inner
+        m = torch.nn.Module()
+        m.regularization_strategy = st
+        return m, st
+
+    m, st = model_with(EdgeAwareLogL1(), TVLoss())
+    assert dns.install_losses(m) == ["regularization_strategy.depth_loss.loss", "regularization_strategy.normal_smooth_loss.loss"]
+    assert isinstance(st.depth_loss.loss, fused_loss.EdgeAwareLogL1) and isinstance(st.normal_smooth_loss.loss, fused_loss.TVLoss)
+    assert dns.install_losses(m) == []
+    m2, st2 = model_with(PerPixel(), torch.nn.L1Loss())
+    assert dns.install_losses(m2) == [] and isinstance(st2.depth_loss.loss, PerPixel)
+    assert dns.install_losses(torch.nn.Module()) == []                         # no strategy, no ssim: nothing to do
+    with pytest.raises(dns.DnsplatError):
+        st.depth_loss.loss(torch.rand(8, 8, 1), torch.rand(8, 8, 1), torch.rand(8, 8, 3), None)
+    with pytest.raises(dns.DnsplatError):
+        st.normal_smooth_loss.loss(torch.rand(8, 8, 3))
+    with pytest.raises(NotImplementedError):
+        st.normal_smooth_loss.loss(torch.rand(2, 8, 8, 3))
+    with pytest.raises(NotImplementedError):
+        st.depth_loss.loss(torch.rand(8, 8, 1), torch.rand(8, 8, 1).requires_grad_(True), torch.rand(8, 8, 3), None)
+
+
 @pytest.mark.gpu
 def test_installed_get_outputs_equals_the_renderer_mirror_on_the_gpu(dns):
     """The installed method on a stand-in model == DNSplatterRenderer(fused=True).get_outputs (the method the parity suite holds to
