@@ -229,6 +229,12 @@ class _ScaleRegFn(torch.autograd.Function):
         return v * g
 
 
+def scale_reg(scales: Tensor) -> Tensor:
+    """``torch.min(torch.exp(scales), dim=1, keepdim=True)[0].mean()`` (``DNRegularization.get_scale_loss``,
+    regularization_strategy.py:195-199) and its gradient in one launch (``dnsplat_scale_reg``) instead of ten kernels over [N,3]."""
+    return _ScaleRegFn.apply(scales)
+
+
 def dn_loss_fused(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], scales: Tensor, ssim_lambda: float = 0.2,
                   depth_lambda: float = 0.2, depth_tolerance: float = 0.1, counts: Optional[Tensor] = None) -> Tensor:
     """Drop-in for ``torch_losses.dn_loss`` (mono depth + mono normal supervision)."""

@@ -141,7 +141,8 @@ def install_losses(model):
     """Swaps the two stencil modules of the model's regularisation strategy for their one-launch HIP drop-ins, when they are the ones
     ``DNRegularization`` / ``AGSMeshRegularization`` construct (regularization_strategy.py:131-144): ``strategy.depth_loss.loss``
     (``EdgeAwareLogL1(implementation="scalar")`` -> ``fused_loss.EdgeAwareLogL1``) and ``strategy.normal_smooth_loss.loss``
-    (``TVLoss`` -> ``fused_loss.TVLoss``); also ``install_ssim(model)``.  Everything else of ``get_loss_dict`` stays the reference's
+    (``TVLoss`` -> ``fused_loss.TVLoss``), the strategy's ``get_scale_loss`` method (-> ``fused_loss.scale_reg``); also
+    ``install_ssim(model)``.  Everything else of ``get_loss_dict`` stays the reference's
     PyTorch code.  Returns the list of what was swapped."""
     from . import fused_loss
 
@@ -157,6 +158,14 @@ def install_losses(model):
             continue
         holder.loss = make()
         swapped.append(f"regularization_strategy.{holder_name}.loss")
+    if strategy is not None and type(strategy).__name__ in ("DNRegularization", "AGSMeshRegularization") \
+            and getattr(strategy.get_scale_loss, "__name__", "") != "_hip_scale_loss":
+        # a method, not a module (regularization_strategy.py:195-199): mean_g min_k exp(scales[g, k]), ten torch kernels over [N,3]
+        def _hip_scale_loss(scales):
+            return fused_loss.scale_reg(scales)
+
+        strategy.get_scale_loss = _hip_scale_loss
+        swapped.append("regularization_strategy.get_scale_loss")
     if hasattr(model, "ssim"):
         install_ssim(model)
         swapped.append("ssim")

@@ -202,7 +202,11 @@ def regularization_term(outputs: Dict[str, Tensor], batch: Dict[str, Tensor], sc
         gt_depth = gt_depth * mask if gt_depth is not None else None
         gt_normal = gt_normal * mask if gt_normal is not None else None
         pred_normal = pred_normal * mask
-    loss = torch.min(torch.exp(scales), dim=1, keepdim=True)[0].mean()              # regularization_strategy.py:195-199
+    if hip_modules:
+        from .fused_loss import scale_reg
+        loss = scale_reg(scales)
+    else:
+        loss = torch.min(torch.exp(scales), dim=1, keepdim=True)[0].mean()          # regularization_strategy.py:195-199
     if use_depth_loss and gt_depth is not None:
         valid = gt_depth > depth_tolerance                                          # :162
         if hip_modules:

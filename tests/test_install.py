@@ -190,6 +190,13 @@ def test_install_losses_swaps_only_the_modules_it_knows(dns):
     m2, st2 = model_with(PerPixel(), torch.nn.L1Loss())
     assert dns.install_losses(m2) == [] and isinstance(st2.depth_loss.loss, PerPixel)
     assert dns.install_losses(torch.nn.Module()) == []                         # no strategy, no ssim: nothing to do
+    # the scale term is a METHOD of the reference's strategies (regularization_strategy.py:195-199): patched on those classes only
+    DNRegularization = type("DNRegularization", (torch.nn.Module,), {"get_scale_loss": lambda self, scales: scales.sum()})
+    m3 = torch.nn.Module()
+    m3.regularization_strategy = DNRegularization()
+    assert dns.install_losses(m3) == ["regularization_strategy.get_scale_loss"] and dns.install_losses(m3) == []
+    with pytest.raises(dns.DnsplatError):
+        m3.regularization_strategy.get_scale_loss(scales=torch.zeros(4, 3))
     with pytest.raises(dns.DnsplatError):
         st.depth_loss.loss(torch.rand(8, 8, 1), torch.rand(8, 8, 1), torch.rand(8, 8, 3), None)
     with pytest.raises(dns.DnsplatError):

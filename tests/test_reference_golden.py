@@ -171,13 +171,13 @@ def test_hip_loss_kernels_equal_the_reference_terms():
     loss = fused_loss.dn_loss_fused(out, batch, scales, counts=fused_loss.depth_counts(gt))
     ref_torch = tl.dn_loss({k: v.detach() for k, v in out.items()}, batch, scales)
     torch.cuda.synchronize()
-    assert abs(float(loss) - float(ref_torch)) < 1e-5 * max(1.0, abs(float(ref_torch)))
+    assert abs(float(loss.detach()) - float(ref_torch.detach())) < 1e-5 * max(1.0, abs(float(ref_torch)))
     # reference terms: rgb error 0 (pred == gt image: L1 = 0, SSIM = 1), normal L1 = 0, so
     # loss = 1.2 x EdgeAwareLogL1(pred, gt, clamp(rgb), gt > 0.1) + TV(normal) + mean(min exp(scales)) = ... + 1
     valid = (gt > 0.1)
     ea = tl.edge_aware_log_l1(pred.cpu(), gt.cpu(), rgb.cpu(), valid.cpu())
     want = 1.2 * float(ea) + float(g["tv_normal"]) + 1.0
-    assert abs(float(loss) - want) < 2e-5 * want
+    assert abs(float(loss.detach()) - want) < 2e-5 * want
 
 
 @pytest.mark.gpu
@@ -222,6 +222,12 @@ def test_hip_loss_modules_equal_the_reference_modules():
     model.regularization_strategy, model.ssim = strategy, torch.nn.Identity()
     swapped = dns.install_losses(model)
     assert swapped == ["regularization_strategy.depth_loss.loss", "regularization_strategy.normal_smooth_loss.loss", "ssim"]
+    sc = torch.randn(1000, 3, device=dev, requires_grad=True)
+    fused_loss.scale_reg(sc).backward()
+    sc2 = sc.detach().clone().requires_grad_(True)
+    want = torch.min(torch.exp(sc2), dim=1, keepdim=True)[0].mean()            # regularization_strategy.py:195-199
+    want.backward()
+    assert abs(float(fused_loss.scale_reg(sc.detach())) - float(want.detach())) < 1e-6 and float((sc.grad - sc2.grad).abs().max()) < 1e-9
     assert isinstance(strategy.depth_loss.loss, fused_loss.EdgeAwareLogL1) and isinstance(strategy.normal_smooth_loss.loss, fused_loss.TVLoss)
     assert isinstance(strategy.normal_loss.loss, torch.nn.L1Loss) and isinstance(model.ssim, fused_loss.SSIM)
     assert dns.install_losses(model) == ["ssim"]                            # idempotent (ssim reports itself, nothing is replaced twice)
@@ -432,7 +438,7 @@ def test_hip_fused_loss_equals_the_reference_combination():
     out = {"rgb": rgb, "depth": pd, "normal": pn}
     batch = {"image": t("image").to(dev), "mono_depth": t("gt_depth").to(dev), "normal": t("gt_normal").to(dev)}
     loss = fused_loss.dn_loss_fused(out, batch, sc)
-    reg = float(loss) - float(tl.rgb_term({k: v.detach() for k, v in out.items()}, batch))
+    reg = float(loss.detach()) - float(tl.rgb_term({k: v.detach() for k, v in out.items()}, batch))
     assert abs(reg - float(g["reg_value"])) < 2e-5, (reg, float(g["reg_value"]))
     gd, gn, gs = torch.autograd.grad(loss, [pd, pn, sc])
     for got, key in ((gd, "loss_dict_v_depth"), (gn, "loss_dict_v_normal"), (gs, "loss_dict_v_scales")):
