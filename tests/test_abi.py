@@ -146,3 +146,14 @@ def test_integration_md_ctypes_stub_matches_the_binding(dns):
         assert getattr(stub, name).offset == getattr(_lib.RasterArgs, name).offset, name
     v = re.search(r"dnsplat_abi_version\(\) == (\d+)", text)
     assert v and int(v.group(1)) == _lib.ABI_VERSION
+
+
+def test_integration_md_names_every_exported_symbol(dns):
+    """INTEGRATION.md section C is the maintainer's map from the reference's call sites to the C ABI: every symbol include/dnsplat.h
+    declares appears in it."""
+    import os
+
+    from dn_splatter_amd import _lib
+
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    assert [e for e in _lib.EXPORTS if e not in text] == []
