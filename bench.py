@@ -489,7 +489,7 @@ def child_section(section, steps, timeout=None):
         return {"section": section, "value": None, "error": repr(e), "stdout_tail": out[-300:]}
 
 
-def child_workload(workload, losses, steps, scene=None):
+def child_workload(workload, losses, steps, scene=None, extra_args=()):
     """Another BASELINE workload measured by THIS script in a process of its own (same method as the headline: graph replay,
     pre-roll, device stamps around the dominant stage, counting step), started after the headline's timed region; returns the
     fields of its JSON line that BASELINE.md section 2 asks for.  A process of its own, because a second and third HIP-graph
@@ -501,6 +501,7 @@ def child_workload(workload, losses, steps, scene=None):
            "--no-cpu-baseline", "--no-strict", "--no-extra-workloads"] + (["--losses", losses] if losses else [])
     if scene:
         cmd += ["--scene", scene]
+    cmd += list(extra_args)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
                                                             "DNSPLAT_FORCE_DIST")}
     if scene == "morton":
@@ -972,6 +973,9 @@ def main():
             # close to their algorithmic bytes (a camera's culled Gaussians are whole workgroups)
             extras["c2_morton"] = child_workload("c2", None, max(5, min(10, args.steps)), scene="morton")
             extras["c5_morton"] = child_workload("c5", None, max(5, min(10, args.steps)), scene="morton")
+            # INTEGRATION.md section A as it stands: the reference's two passes through the two drop-in symbols plus its own ~40 torch
+            # kernels, launched eagerly (where the time goes: profiles/r06_two_call_breakdown.txt)
+            extras["c2_two_call"] = child_workload("c2", None, max(5, min(10, args.steps)), extra_args=["--two-call"])
             extras["c2_train_loop"] = child_section("train_loop", 200)
 
     # ---- multi-GPU accounting, all outside the timed region ----------------------------------------
