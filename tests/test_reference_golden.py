@@ -405,8 +405,8 @@ def test_regularization_combination_equals_the_reference():
     out = {"rgb": t("pred_rgb"), "depth": pd, "normal": pn}
     batch = {"image": t("image"), "mono_depth": t("gt_depth"), "normal": t("gt_normal")}
     v = tl.regularization_term(out, batch, sc)
-    assert abs(float(v) - float(g["reg_value"])) < 2e-6
-    assert abs(float(v) - (float(g["loss_dict_main"]) - float(g["loss_dict_rgb_term"]))) < 2e-6     # main = rgb + regularization
+    assert abs(float(v.detach()) - float(g["reg_value"])) < 2e-6
+    assert abs(float(v.detach()) - (float(g["loss_dict_main"]) - float(g["loss_dict_rgb_term"]))) < 2e-6     # main = rgb + regularization
     assert abs(float(g["reg_depth_term"]) + float(g["reg_normal_term"]) + float(g["reg_scale_term"]) - float(g["reg_value"])) < 2e-6
     gd, gn, gs = torch.autograd.grad(v, [pd, pn, sc])
     for got, key in ((gd, "v_depth"), (gn, "v_normal"), (gs, "v_scales")):
@@ -416,12 +416,12 @@ def test_regularization_combination_equals_the_reference():
     # with a mask in the batch
     pd3, pn3 = t("pred_depth").requires_grad_(True), t("pred_normal").requires_grad_(True)
     v3 = tl.regularization_term({"rgb": t("pred_rgb"), "depth": pd3, "normal": pn3}, dict(batch, mask=t("mask")), sc)
-    assert abs(float(v3) - (float(g["masked_main"]) - float(g["loss_dict_rgb_term"]))) < 2e-6
+    assert abs(float(v3.detach()) - (float(g["masked_main"]) - float(g["loss_dict_rgb_term"]))) < 2e-6
     gd3, gn3 = torch.autograd.grad(v3, [pd3, pn3])
     assert float((gd3 - t("masked_v_depth")).abs().max()) < 2e-6 and float((gn3 - t("masked_v_normal")).abs().max()) < 2e-6
     # dn_loss = rgb term + regularization (dn_model.py:727); the rgb term is nerfstudio's L1 + SSIM (unpinned: SSIM is restated)
     full = tl.dn_loss(out, batch, sc)
-    assert abs(float(full) - float(tl.rgb_term(out, batch)) - float(v)) < 1e-6
+    assert abs(float(full.detach()) - float(tl.rgb_term(out, batch).detach()) - float(v.detach())) < 1e-6
 
 
 @pytest.mark.gpu
