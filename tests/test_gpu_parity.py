@@ -1462,7 +1462,7 @@ def test_c2_full_frame_fused_pass_matches_oracle(dns, orc):
     cam = synthetic.orbit_camera(0, width=W, height=H)
     hip, ora, keep = _mirror_pair(dns, orc, gp, cam, dict(fused=True), cot_seed=1, what="C2 full frame")
     assert hip[2].last_info["n_isects"] > 12_000_000      # tight tile boxes; 21 M with gsplat's
-    assert float(hip[0]["accumulation"].min()) > 0.999                # every pixel saturates, as in the benchmark
+    assert float(hip[0]["accumulation"].detach().min()) > 0.999                # every pixel saturates, as in the benchmark
     _check_mirror(hip, ora, keep, "C2 full frame", quat_atol=1e-4)    # isotropic init: d/d(quats) is rounding noise
 
 
